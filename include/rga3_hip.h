@@ -1,0 +1,110 @@
+/*
+ * rga3_hip.h — C ABI of librga3_hip.so, the MI355X (gfx950) kernel library behind the RGA3 / UniGR hot path.
+ *
+ * The reference (qirui-chen/RGA3-release) is pure Python and reaches all arithmetic through third-party
+ * CUDA libraries (flash-attn, cuBLAS, cuDNN via torch).  Each entry point below replaces one such call
+ * site; the reference file:line it stands in for is cited on every declaration ("HF" = the transformers
+ * Qwen2.5-VL modeling file the reference subclasses, model/qwen_2_5_vl_sam2.py:9-12,104).
+ *
+ * Conventions:
+ *  - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (PyTorch caching
+ *    allocator), including workspaces.  The library allocates nothing and keeps no mutable global state.
+ *  - every call enqueues on `stream` (a hipStream_t passed as void*) and returns without synchronising.
+ *  - return 0 on success, a negative code otherwise (-hipError_t for runtime errors, RGA3_EINVAL for
+ *    argument errors); the message is retrievable with rga3_last_error() (thread-local).
+ *  - bf16 tensors are passed as raw 16-bit words; "ld*" / strides are in ELEMENTS.
+ */
+#ifndef RGA3_HIP_H
+#define RGA3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGA3_EINVAL (-22)
+
+/* dtype codes */
+#define RGA3_BF16 0
+#define RGA3_F32 1
+
+/* GEMM epilogue activation codes */
+#define RGA3_ACT_NONE 0
+#define RGA3_ACT_GELU 1   /* exact erf GELU (nn.GELU default) */
+#define RGA3_ACT_SWIGLU 2 /* W rows interleaved [16 gate | 16 up]; out[:, j] = silu(gate_j) * up_j, N_out = N/2 */
+#define RGA3_ACT_RELU 3
+
+int rga3_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
+int rga3_last_error(char* buf, size_t n);
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual).  bf16 in, f32 accumulate, bf16 or f32 out.
+ * Replaces nn.Linear / 1x1 conv / Conv3d-as-GEMM call sites: HF modeling_qwen2_5_vl.py:84-96 (MLP),
+ * :99-122 (patch embed), :137-150 (merger), :211-291 (ViT qkv/proj), :602-757 (decoder projections),
+ * :1383 (lm_head); reference model/qwen_2_5_vl_sam2.py:131-137 (text_hidden_fcs), model/sam2.py:986-1117
+ * (Hiera qkv/proj/mlp), :857-889 (FPN 1x1), :1417-1481 (decoder attention projections).
+ * K must be a multiple of 64, lda/ldw multiples of 8; tile = -1 lets the library choose. */
+int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N,
+                   int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, int out_dtype, int tile,
+                   void* stream);
+
+/* Variable-length fused attention forward (online softmax, fp32 statistics), bf16 in/out.
+ *   q: [total_q, Hq, D], k/v: [total_k, Hkv, D] addressed through (token, head) element strides so the
+ *   kernel reads straight out of a fused QKV projection; segments given by cu_q / cu_k (int32, nseg+1).
+ *   causal != 0: key j visible to query i iff j <= i + (Lk - Lq) (bottom-right aligned).
+ *   lse (optional, f32 [Hq, total_q]) receives log-sum-exp of the scaled scores for the backward pass.
+ * Replaces flash_attn_varlen_func / F.scaled_dot_product_attention at HF modeling_qwen2_5_vl.py:211-291
+ * (ViT windows), :602-700 (causal GQA), reference model/sam2.py:1021 (Hiera), :1476 (two-way decoder),
+ * :1543 (memory attention).  D in {16..256}, multiple of 8. impl: 0 = transposed LDS read, 1 = scalar-read
+ * variant (debug cross-check). */
+int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q,
+                         const int32_t* cu_k, int nseg, int max_q, int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh,
+                         int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
+                         float scale, int causal, int impl, void* stream);
+
+/* y = weight * (x * rsqrt(mean(x^2) + eps)) rounded to bf16 before the weight multiply, exactly as
+ * HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:65-79).  x,y: [rows, dim] bf16; optional fused residual:
+ * if `res_out` != NULL the kernel first writes res_out = x + add (bf16) and normalises that sum. */
+int rga3_rmsnorm_fwd(const void* x, const void* add, const void* weight, void* y, void* res_out, int64_t rows,
+                     int64_t dim, int64_t ldx, float eps, void* stream);
+
+/* LayerNorm over the last dim with affine, fp32 statistics (nn.LayerNorm; reference model/sam2.py:1050-1051,
+ * :474-476).  x,y [rows, dim] bf16. */
+int rga3_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int64_t dim,
+                       int64_t ldx, int64_t ldy, float eps, void* stream);
+
+/* In-place rotary embedding on q and k heads living inside one [T, nheads_total, D] buffer (fused QKV output):
+ * x = x*cos + rotate_half(x)*sin in fp32, cos/sin: [T, D] f32 tables (HF apply_rotary_pos_emb_vision
+ * modeling_qwen2_5_vl.py:160-171 and apply_multimodal_rotary_pos_emb :557-599 after section interleave).
+ * Heads [h0, h0+nh) are rotated; st/sh are the token/head element strides. */
+int rga3_rope_inplace(void* x, const float* cos, const float* sin, int64_t T, int h0, int nh, int D, int64_t st,
+                      int64_t sh, void* stream);
+
+/* out[i, :] = table[idx[i], :] (embedding lookup / row gather; HF modeling_qwen2_5_vl.py:1206, window reorder
+ * :434-438). 16-bit rows; `rows_per_idx` consecutive rows move together (merge-unit granularity). */
+int rga3_gather_rows(const void* table, const int64_t* idx, void* out, int64_t n_idx, int64_t rows_per_idx,
+                     int64_t dim, int64_t ld_table, int64_t ld_out, void* stream);
+/* out[idx[i], :] = src[i, :] (masked_scatter of video embeds, HF :1217-1223; inverse window permutation :464-466) */
+int rga3_scatter_rows(const void* src, const int64_t* idx, void* out, int64_t n_idx, int64_t rows_per_idx, int64_t dim,
+                      int64_t ld_src, int64_t ld_out, void* stream);
+
+/* copy [rows, cols] bf16 into a [rows, ld_out] buffer, zero-filling columns cols..ld_out-1 (K padding for GEMM) */
+int rga3_pad_cols(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, void* stream);
+
+/* elementwise helpers on bf16: out = silu(a) * b ; out = a + b */
+int rga3_silu_mul(const void* a, const void* b, void* out, int64_t n, void* stream);
+int rga3_add(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* Shifted-label cross entropy over bf16/f32 logits rows, fp32 math, ignore_index = -100
+ * (HF ForCausalLMLoss, modeling_qwen2_5_vl.py:1383-1393).  logits [rows, V] (ld in elements), labels [rows]
+ * already shifted by the caller.  Writes per-row loss (0 for ignored rows) and, if dlogits != NULL,
+ * (softmax - onehot) * grad_scale in bf16. */
+int rga3_cross_entropy_rows(const void* logits, int logits_dtype, const int64_t* labels, float* row_loss,
+                            void* dlogits, int64_t rows, int64_t V, int64_t ld, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGA3_HIP_H */

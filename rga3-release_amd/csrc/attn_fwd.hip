@@ -1,0 +1,320 @@
+// Variable-length fused attention forward for CDNA4 (wave64, v_mfma_f32_16x16x32_bf16).
+//
+// One kernel family covers every softmax(QK^T)V call site on the RGA3 hot path (SURVEY.md 2.2 K3, K8, K12,
+// K16, K18): ViT window/full attention (HF modeling_qwen2_5_vl.py:211-291), causal GQA decoder attention
+// (:602-700), Hiera windowed attention (reference model/sam2.py:1021), two-way decoder attention (:1476)
+// and memory attention (:1543).
+//
+// Layout of the computation (chosen for the MFMA register maps, not translated from a CUDA kernel):
+//  * S^T = K . Q^T  — K fragment is the MFMA "A" operand (rows = keys, straight ds_read_b128 from a row-major
+//    LDS image), Q fragment the "B" operand (registers, loaded once).  The 16x16 result puts the QUERY on the
+//    lane (lane&15) and 4 keys in the registers, so the online-softmax state (m, l, alpha) is one scalar per lane.
+//  * O^T = V^T . P^T — the P registers are, as they stand, the "B" operand of the next MFMA (k order
+//    permuted: element j of lane group g is key 16*(j>>2) + 4g + (j&3) of the 32-key step); the V^T "A"
+//    operand with the same k permutation is exactly what two ds_read_b64_tr_b16 transposed reads of the
+//    row-major V image deliver.  Result again has the query on the lane: alpha scaling is lane-local.
+//  * K/V tiles are register-staged (global_load 16 B -> ds_write_b128) one tile ahead, into rows padded by
+//    32 B so that both the b128 K reads and the transposed V reads are bank-conflict-free.
+#include "common.h"
+
+namespace rga3 {
+
+struct AttnArgs {
+    const unsigned short* q;
+    const unsigned short* k;
+    const unsigned short* v;
+    unsigned short* o;
+    float* lse;
+    const int* cu_q;
+    const int* cu_k;
+    long q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh;
+    int Hq, Hkv, D;
+    long total_q;
+    float scale_log2;  // softmax scale * log2(e)
+    int causal;
+};
+
+constexpr int KV_TILE = 64;
+
+template <int DP, int QT, int NWAVE, bool USE_TR>
+__global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int NT = 64 * NWAVE;
+    constexpr int BLOCK_M = NWAVE * QT * 16;
+    constexpr int CH = DP / 8;            // 16-byte chunks per (padded) row
+    constexpr int STRIDE = DP * 2 + 32;   // LDS row stride in bytes (see header comment)
+    constexpr int DS = DP / 32;           // 32-wide d steps of the QK^T contraction
+    constexpr int DT = DP / 16;           // 16-wide d tiles of the output
+    constexpr int LOADS = (KV_TILE * CH) / NT;
+    static_assert((KV_TILE * CH) % NT == 0, "tile chunks must divide evenly over threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + KV_TILE * STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+
+    const int seg = blockIdx.z, hq = blockIdx.y;
+    const int hk = hq / (p.Hq / p.Hkv);
+    const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
+    const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
+    const int qb0 = blockIdx.x * BLOCK_M;
+    if (qb0 >= Lq) return;
+    const int shift = Lk - Lq;  // causal: key j visible to query i iff j <= i + shift
+
+    // ---- Q fragments (B operand): lane (c, g) holds Q[q = c][d = 32*ds + 8g .. +7]
+    bf16x8 qf[QT][DS];
+    const int qw0 = qb0 + wid * (QT * 16);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = qw0 + t * 16 + c;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+            const int d = ds * 32 + g * 8;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (qi < Lq && d < p.D) z = *(const u32x4*)(p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh + d);
+            qf[t][ds] = __builtin_bit_cast(bf16x8, z);
+        }
+    }
+
+    f32x4 oacc[QT][DT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) oacc[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { m_run[t] = -INFINITY; l_run[t] = 0.f; }
+
+    // ---- KV range for this q block
+    int kv_end = Lk;
+    if (p.causal) kv_end = min(Lk, qb0 + BLOCK_M + shift);  // last visible key + 1 (for the block's last row)
+    if (kv_end < 0) kv_end = 0;
+    const int ntiles = (kv_end + KV_TILE - 1) / KV_TILE;
+
+    u32x4 kreg[LOADS], vreg[LOADS];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / CH, ch = idx % CH;
+            const int key = kt * KV_TILE + r;
+            u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+            if (key < Lk && ch * 8 < p.D) {
+                zk = *(const u32x4*)(p.k + (long)(ks + key) * p.k_st + (long)hk * p.k_sh + ch * 8);
+                zv = *(const u32x4*)(p.v + (long)(ks + key) * p.v_st + (long)hk * p.v_sh + ch * 8);
+            }
+            kreg[i] = zk;
+            vreg[i] = zv;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / CH, ch = idx % CH;
+            *(u32x4*)(Ks + r * STRIDE + ch * 16) = kreg[i];
+            *(u32x4*)(Vs + r * STRIDE + ch * 16) = vreg[i];
+        }
+    };
+
+    if (ntiles > 0) load_tile(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();  // everyone finished reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < ntiles) load_tile(kt + 1);  // in flight under the MFMAs below
+
+        // ---- S^T tiles: s[t][j] = keys 16j..16j+15 (lane holds keys 16j + 4g + r) x query c of q-tile t
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                bf16x8 kf = *(const bf16x8*)(Ks + (j * 16 + c) * STRIDE + ds * 64 + g * 16);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ds], s[t][j], 0, 0, 0);
+            }
+        }
+
+        // ---- scale, mask, online softmax (per lane: one query per q-tile)
+        const int k0 = kt * KV_TILE;
+        const bool need_mask = (k0 + KV_TILE > Lk) || (p.causal && (k0 + KV_TILE - 1 > qb0 + shift));
+        bf16x8 pf[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int qi = qw0 + t * 16 + c;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = s[t][j][r] * p.scale_log2;
+                    if (need_mask) {
+                        const int key = k0 + j * 16 + 4 * g + r;
+                        const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
+                        x = ok ? x : -INFINITY;
+                    }
+                    s[t][j][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = exp2f(m_run[t] - m_use);  // m_run = -inf -> 0
+            m_run[t] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = exp2f(s[t][j][r] - m_use);
+                    s[t][j][r] = e;
+                    ps += e;
+                }
+            l_run[t] = l_run[t] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) oacc[t][d] *= alpha;
+            // P^T B-operand fragments: 32-key step ss uses s[t][2ss] (elements 0..3) and s[t][2ss+1] (4..7)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                u32x4 pk;
+                pk[0] = pack_bf2(s[t][2 * ss][0], s[t][2 * ss][1]);
+                pk[1] = pack_bf2(s[t][2 * ss][2], s[t][2 * ss][3]);
+                pk[2] = pack_bf2(s[t][2 * ss + 1][0], s[t][2 * ss + 1][1]);
+                pk[3] = pack_bf2(s[t][2 * ss + 1][2], s[t][2 * ss + 1][3]);
+                pf[t][ss] = __builtin_bit_cast(bf16x8, pk);
+            }
+        }
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                bf16x8 vf;
+                if constexpr (USE_TR) {
+                    // lane i of group g supplies row (key) i>>2, columns 4*(i&3)..+3 of the 4x16 block
+                    const char* a0 = Vs + (ss * 32 + 4 * g + (c >> 2)) * STRIDE + (d * 16 + 4 * (c & 3)) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(a0 + 16 * STRIDE));
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int key = ss * 32 + 16 * (e >> 2) + 4 * g + (e & 3);
+                        unsigned short u = *(const unsigned short*)(Vs + key * STRIDE + (d * 16 + c) * 2);
+                        vf[e] = __builtin_bit_cast(__bf16, u);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) oacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ss], oacc[t][d], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- finalize: lane holds query c, output dims 16d + 4g + r
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = l_run[t];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = (l > 0.f) ? 1.f / l : 0.f;
+        const int qi = qw0 + t * 16 + c;
+        if (qi < Lq) {
+            unsigned short* orow = p.o + (long)(qs + qi) * p.o_st + (long)hq * p.o_sh;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int dd = d * 16 + 4 * g;
+                if (dd < p.D) {
+                    u32x2 pk;
+                    pk[0] = pack_bf2(oacc[t][d][0] * inv, oacc[t][d][1] * inv);
+                    pk[1] = pack_bf2(oacc[t][d][2] * inv, oacc[t][d][3] * inv);
+                    *(u32x2*)(orow + dd) = pk;
+                }
+            }
+            if (p.lse && g == 0) {
+                // natural-log LSE of the scaled scores
+                p.lse[(long)hq * p.total_q + qs + qi] = (l > 0.f) ? (m_run[t] * 0.6931471805599453f + logf(l)) : -INFINITY;
+            }
+        }
+    }
+}
+
+template <int DP, int QT, int NWAVE, bool USE_TR>
+static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
+    constexpr int BLOCK_M = NWAVE * QT * 16;
+    constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
+    auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR>;
+    static bool attr_done = false;
+    if (!attr_done && LDS > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    dim3 grid((unsigned)cdiv(max_q, BLOCK_M), (unsigned)a.Hq, (unsigned)nseg);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWAVE), LDS, st, a);
+    RGA3_CHECK_LAUNCH("attn_fwd_kernel");
+    return 0;
+}
+
+template <int DP, bool USE_TR>
+static int launch_dp(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
+    if constexpr (DP >= 256) {
+        return launch_attn<DP, 1, 4, USE_TR>(a, nseg, max_q, st);
+    } else {
+        if (max_q <= 64) return launch_attn<DP, 1, 4, USE_TR>(a, nseg, max_q, st);
+        return launch_attn<DP, 2, 4, USE_TR>(a, nseg, max_q, st);
+    }
+}
+
+template <bool USE_TR>
+static int launch_any(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
+    const int D = a.D;
+    if (D <= 32) return launch_dp<32, USE_TR>(a, nseg, max_q, st);
+    if (D <= 64) return launch_dp<64, USE_TR>(a, nseg, max_q, st);
+    if (D <= 96) return launch_dp<96, USE_TR>(a, nseg, max_q, st);
+    if (D <= 128) return launch_dp<128, USE_TR>(a, nseg, max_q, st);
+    return launch_dp<256, USE_TR>(a, nseg, max_q, st);
+}
+
+}  // namespace rga3
+
+using namespace rga3;
+
+extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                                    const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q, int64_t total_q,
+                                    int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh,
+                                    int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal,
+                                    int impl, void* stream) {
+    RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k, "attn: null pointer");
+    RGA3_CHECK_ARG(nseg > 0 && max_q > 0 && total_q > 0, "attn: nseg=%d max_q=%d total_q=%ld", nseg, max_q, (long)total_q);
+    RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attn: Hq=%d Hkv=%d", Hq, Hkv);
+    RGA3_CHECK_ARG(D >= 8 && D <= 256 && D % 8 == 0, "attn: head dim %d unsupported (need multiple of 8, <= 256)", D);
+    RGA3_CHECK_ARG(q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0,
+                   "attn: q/k/v strides must be multiples of 8 elements");
+    RGA3_CHECK_ARG(o_st % 4 == 0 && o_sh % 4 == 0, "attn: o strides must be multiples of 4 elements");
+    RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && (((uintptr_t)o) & 7) == 0,
+                   "attn: pointer alignment");
+    RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
+    RGA3_CHECK_ARG(impl == 0 || impl == 1, "attn: impl %d", impl);
+    AttnArgs a;
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.o = (unsigned short*)o; a.lse = lse; a.cu_q = cu_q; a.cu_k = cu_k;
+    a.q_st = q_st; a.q_sh = q_sh; a.k_st = k_st; a.k_sh = k_sh; a.v_st = v_st; a.v_sh = v_sh; a.o_st = o_st; a.o_sh = o_sh;
+    a.Hq = Hq; a.Hkv = Hkv; a.D = D;
+    a.total_q = total_q;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.causal = causal;
+    hipStream_t st = (hipStream_t)stream;
+    if (impl == 0) return launch_any<true>(a, nseg, max_q, st);
+    return launch_any<false>(a, nseg, max_q, st);
+}

@@ -1,0 +1,75 @@
+// Shared device/host helpers for the rga3 HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/rga3_hip.h"
+
+namespace rga3 {
+
+// ---- error convention: 0 = ok, negative code otherwise; message is thread-local.
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define RGA3_CHECK_ARG(cond, ...)                                   \
+    do {                                                            \
+        if (!(cond)) return ::rga3::fail(RGA3_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define RGA3_CHECK_LAUNCH(name)                                                                  \
+    do {                                                                                         \
+        hipError_t e__ = hipGetLastError();                                                      \
+        if (e__ != hipSuccess) return ::rga3::fail(-(int)e__, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- vector types
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned int)u) << 16); }
+// plain cast keeps NaN a NaN and lowers to v_cvt_pk_bf16_f32 (MI355X_MICROARCH.md, correctness boundaries)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned int, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// number of XCDs on MI355X (MI355X_MICROARCH.md chip table); used only for speed (L2 affinity), never correctness
+constexpr int kNumXCD = 8;
+
+// Bijective XCD-aware block remap (cdna_hip_programming.md 5, "XCD swizzle must be bijective"):
+// blocks that share an XCD (same id % 8) get a contiguous chunk of the logical tile range.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    unsigned q = nwg / kNumXCD, r = nwg % kNumXCD, x = bid % kNumXCD;
+    unsigned base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + bid / kNumXCD;
+}
+
+}  // namespace rga3

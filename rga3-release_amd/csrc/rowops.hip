@@ -1,0 +1,373 @@
+// HBM-bound row kernels: RMSNorm / LayerNorm, rotary embedding, row gather/scatter, padding, elementwise, CE.
+// All are 16-byte-per-lane vectorised, fp32 math, bf16 storage (cdna_hip_programming.md Guideline 13).
+#include "common.h"
+
+namespace rga3 {
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ RMSNorm
+// one wave per row; the row stays in registers between the statistics pass and the scale pass.
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ add,
+                                                      const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
+                                                      unsigned short* __restrict__ res_out, long rows, int dim, long ldx, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = dim / 8;
+    u32x4 buf[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            u32x4 v = *(const u32x4*)(x + row * ldx + ch * 8);
+            float f[8];
+            unpack8(v, f);
+            if (add) {
+                u32x4 a = *(const u32x4*)(add + row * ldx + ch * 8);
+                float fa[8];
+                unpack8(a, fa);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bf2f(f2bf(f[e] + fa[e]));  // bf16 residual stream
+                v = pack8(f);
+                if (res_out) *(u32x4*)(res_out + row * ldx + ch * 8) = v;
+            }
+            buf[i] = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rinv = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            float f[8], fw[8];
+            unpack8(buf[i], f);
+            unpack8(*(const u32x4*)(w + ch * 8), fw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fw[e] * bf2f(f2bf(f[e] * rinv));  // HF: weight * normed.to(bf16)
+            *(u32x4*)(y + row * ldx + ch * 8) = pack8(f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                        const unsigned short* __restrict__ b, unsigned short* __restrict__ y,
+                                                        long rows, int dim, long ldx, long ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = dim / 8;
+    u32x4 buf[MAXC];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            buf[i] = *(const u32x4*)(x + row * ldx + ch * 8);
+            float f[8];
+            unpack8(buf[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1 += f[e];
+        }
+    }
+    const float mean = wave_sum(s1) / (float)dim;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            float f[8];
+            unpack8(buf[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float d = f[e] - mean; s2 += d * d; }
+        }
+    }
+    const float rinv = rsqrtf(wave_sum(s2) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            float f[8], fw[8], fb[8];
+            unpack8(buf[i], f);
+            unpack8(*(const u32x4*)(w + ch * 8), fw);
+            if (b) unpack8(*(const u32x4*)(b + ch * 8), fb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rinv * fw[e] + (b ? fb[e] : 0.f);
+            *(u32x4*)(y + row * ldy + ch * 8) = pack8(f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rotary
+// thread = (token, head, 8-wide chunk of the first half); rotates the chunk and its partner in the second half.
+__global__ __launch_bounds__(256) void rope_kernel(unsigned short* __restrict__ x, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                   long T, int h0, int nh, int D, long st, long sh) {
+    const int half = D / 2, cph = half / 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = T * nh * cph;
+    if (idx >= total) return;
+    const int ch = (int)(idx % cph);
+    const int h = (int)((idx / cph) % nh);
+    const long t = idx / ((long)cph * nh);
+    unsigned short* p1 = x + t * st + (long)(h0 + h) * sh + ch * 8;
+    unsigned short* p2 = p1 + half;
+    float a[8], b[8];
+    unpack8(*(const u32x4*)p1, a);
+    unpack8(*(const u32x4*)p2, b);
+    const float* c1 = cs + t * D + ch * 8;
+    const float* s1 = sn + t * D + ch * 8;
+    float o1[8], o2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o1[e] = a[e] * c1[e] - b[e] * s1[e];                 // x*cos + rotate_half(x)*sin, first half: -x2
+        o2[e] = b[e] * c1[e + half] + a[e] * s1[e + half];   // second half: +x1
+    }
+    *(u32x4*)p1 = pack8(o1);
+    *(u32x4*)p2 = pack8(o2);
+}
+
+// ------------------------------------------------------------------------------------------------ gather / scatter rows
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(const unsigned short* __restrict__ src, const long* __restrict__ idx,
+                                                        unsigned short* __restrict__ dst, long n_idx, long rpi, int dim, long ld_src,
+                                                        long ld_dst) {
+    const int nch = dim / 8;
+    const long total = n_idx * rpi * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long r = i / nch;          // linear row in the "dense" side
+        const long u = r / rpi, w = r % rpi;
+        const long other = idx[u] * rpi + w;  // row on the indexed side
+        const long srow = SCATTER ? r : other, drow = SCATTER ? other : r;
+        *(u32x4*)(dst + drow * ld_dst + ch * 8) = *(const u32x4*)(src + srow * ld_src + ch * 8);
+    }
+}
+
+__global__ __launch_bounds__(256) void pad_cols_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, long rows,
+                                                       int cols, long ld_src, long ld_dst) {
+    const int nch = (int)(ld_dst / 8);
+    const long total = rows * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long r = i / nch;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ch * 8 + 8 <= cols) {
+            v = *(const u32x4*)(src + r * ld_src + ch * 8);
+        } else if (ch * 8 < cols) {
+            unsigned short tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int e = 0; e < 8 && ch * 8 + e < cols; ++e) tmp[e] = src[r * ld_src + ch * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (unsigned)tmp[2 * e] | ((unsigned)tmp[2 * e + 1] << 16);
+        }
+        *(u32x4*)(dst + r * ld_dst + ch * 8) = v;
+    }
+}
+
+template <int OP>  // 0: silu(a)*b   1: a+b
+__global__ __launch_bounds__(256) void ew2_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                                                  unsigned short* __restrict__ o, long n) {
+    const long nv = n / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float fa[8], fb[8];
+        unpack8(*(const u32x4*)(a + i * 8), fa);
+        unpack8(*(const u32x4*)(b + i * 8), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (OP == 0) fa[e] = bf2f(f2bf(fa[e] / (1.f + __expf(-fa[e])))) * fb[e];
+            else fa[e] = fa[e] + fb[e];
+        }
+        *(u32x4*)(o + i * 8) = pack8(fa);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (long i = nv * 8; i < n; ++i) {
+            float x = bf2f(a[i]), y = bf2f(b[i]);
+            o[i] = f2bf(OP == 0 ? bf2f(f2bf(x / (1.f + __expf(-x)))) * y : x + y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cross entropy
+// one 256-thread block per row: online max / sum-exp in fp32, then optional gradient pass.
+template <bool F32>
+__global__ __launch_bounds__(256) void ce_rows_kernel(const void* __restrict__ logits, const long* __restrict__ labels, float* __restrict__ row_loss,
+                                                      unsigned short* __restrict__ dlogits, long V, long ld, float gscale) {
+    __shared__ float red_m[4], red_s[4];
+    const long row = blockIdx.x;
+    const long lab = labels[row];
+    const int tid = threadIdx.x;
+    if (lab < 0) {  // ignore_index
+        if (tid == 0) row_loss[row] = 0.f;
+        if (dlogits)
+            for (long i = tid; i < V; i += 256) dlogits[row * ld + i] = 0;
+        return;
+    }
+    auto ld1 = [&](long i) -> float {
+        if (F32) return ((const float*)logits)[row * ld + i];
+        return bf2f(((const unsigned short*)logits)[row * ld + i]);
+    };
+    float m = -INFINITY, s = 0.f;
+    for (long i = tid; i < V; i += 256) {
+        float x = ld1(i);
+        float mn = fmaxf(m, x);
+        s = s * __expf(m - mn) + __expf(x - mn);
+        m = mn;
+    }
+    // wave reduce (m, s)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float mo = __shfl_xor(m, o, 64), so = __shfl_xor(s, o, 64);
+        float mn = fmaxf(m, mo);
+        float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+        float sb = (mo == -INFINITY) ? 0.f : so * __expf(mo - mn);
+        s = sa + sb;
+        m = mn;
+    }
+    if ((tid & 63) == 0) { red_m[tid >> 6] = m; red_s[tid >> 6] = s; }
+    __syncthreads();
+    float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S += (red_m[i] == -INFINITY) ? 0.f : red_s[i] * __expf(red_m[i] - M);
+    const float lse = M + logf(S);
+    if (tid == 0) row_loss[row] = lse - ld1(lab);
+    if (dlogits) {
+        for (long i = tid; i < V; i += 256) {
+            float pr = __expf(ld1(i) - lse);
+            dlogits[row * ld + i] = f2bf((pr - (i == lab ? 1.f : 0.f)) * gscale);
+        }
+    }
+}
+
+static inline unsigned grid_for(long total, int per_block = 256, long cap = 256L * 8 * 4) {
+    long b = cdiv(total, per_block);
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace rga3
+
+using namespace rga3;
+
+extern "C" int rga3_rmsnorm_fwd(const void* x, const void* add, const void* weight, void* y, void* res_out, int64_t rows,
+                                int64_t dim, int64_t ldx, float eps, void* stream) {
+    RGA3_CHECK_ARG(x && weight && y, "rmsnorm: null pointer");
+    RGA3_CHECK_ARG(rows > 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && dim <= 8192, "rmsnorm: rows=%ld dim=%ld ldx=%ld", (long)rows, (long)dim, (long)ldx);
+    RGA3_CHECK_ARG(!res_out || add, "rmsnorm: res_out requires add");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(rows, 4));
+    const unsigned short *xp = (const unsigned short*)x, *ap = (const unsigned short*)add, *wp = (const unsigned short*)weight;
+    unsigned short *yp = (unsigned short*)y, *rp = (unsigned short*)res_out;
+    if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
+    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
+    else hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
+    RGA3_CHECK_LAUNCH("rmsnorm_kernel");
+    return 0;
+}
+
+extern "C" int rga3_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int64_t dim,
+                                  int64_t ldx, int64_t ldy, float eps, void* stream) {
+    RGA3_CHECK_ARG(x && weight && y, "layernorm: null pointer");
+    RGA3_CHECK_ARG(rows > 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && dim <= 8192, "layernorm: rows=%ld dim=%ld", (long)rows, (long)dim);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(rows, 4));
+    const unsigned short *xp = (const unsigned short*)x, *wp = (const unsigned short*)weight, *bp = (const unsigned short*)bias;
+    unsigned short* yp = (unsigned short*)y;
+    if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps);
+    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps);
+    RGA3_CHECK_LAUNCH("layernorm_kernel");
+    return 0;
+}
+
+extern "C" int rga3_rope_inplace(void* x, const float* cos, const float* sin, int64_t T, int h0, int nh, int D, int64_t st,
+                                 int64_t sh, void* stream) {
+    RGA3_CHECK_ARG(x && cos && sin, "rope: null pointer");
+    RGA3_CHECK_ARG(T > 0 && nh > 0 && D > 0 && D % 16 == 0 && st % 8 == 0 && sh % 8 == 0, "rope: T=%ld nh=%d D=%d", (long)T, nh, D);
+    const long total = (long)T * nh * (D / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cos, sin, (long)T, h0,
+                       nh, D, (long)st, (long)sh);
+    RGA3_CHECK_LAUNCH("rope_kernel");
+    return 0;
+}
+
+extern "C" int rga3_gather_rows(const void* table, const int64_t* idx, void* out, int64_t n_idx, int64_t rows_per_idx,
+                                int64_t dim, int64_t ld_table, int64_t ld_out, void* stream) {
+    RGA3_CHECK_ARG(table && idx && out, "gather_rows: null pointer");
+    RGA3_CHECK_ARG(n_idx > 0 && rows_per_idx > 0 && dim > 0 && dim % 8 == 0 && ld_table % 8 == 0 && ld_out % 8 == 0, "gather_rows: bad shape");
+    const long total = n_idx * rows_per_idx * (dim / 8);
+    hipLaunchKernelGGL(move_rows_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)table,
+                       (const long*)idx, (unsigned short*)out, (long)n_idx, (long)rows_per_idx, (int)dim, (long)ld_table, (long)ld_out);
+    RGA3_CHECK_LAUNCH("gather_rows");
+    return 0;
+}
+
+extern "C" int rga3_scatter_rows(const void* src, const int64_t* idx, void* out, int64_t n_idx, int64_t rows_per_idx, int64_t dim,
+                                 int64_t ld_src, int64_t ld_out, void* stream) {
+    RGA3_CHECK_ARG(src && idx && out, "scatter_rows: null pointer");
+    RGA3_CHECK_ARG(n_idx > 0 && rows_per_idx > 0 && dim > 0 && dim % 8 == 0 && ld_src % 8 == 0 && ld_out % 8 == 0, "scatter_rows: bad shape");
+    const long total = n_idx * rows_per_idx * (dim / 8);
+    hipLaunchKernelGGL(move_rows_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src,
+                       (const long*)idx, (unsigned short*)out, (long)n_idx, (long)rows_per_idx, (int)dim, (long)ld_src, (long)ld_out);
+    RGA3_CHECK_LAUNCH("scatter_rows");
+    return 0;
+}
+
+extern "C" int rga3_pad_cols(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, void* stream) {
+    RGA3_CHECK_ARG(src && dst, "pad_cols: null pointer");
+    RGA3_CHECK_ARG(rows > 0 && cols > 0 && ld_dst >= cols && ld_dst % 8 == 0 && ld_src % 8 == 0, "pad_cols: bad shape");
+    hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(rows * (ld_dst / 8))), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src,
+                       (unsigned short*)dst, (long)rows, (int)cols, (long)ld_src, (long)ld_dst);
+    RGA3_CHECK_LAUNCH("pad_cols");
+    return 0;
+}
+
+extern "C" int rga3_silu_mul(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    RGA3_CHECK_ARG(a && b && out && n > 0, "silu_mul: bad args");
+    hipLaunchKernelGGL(ew2_kernel<0>, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)a,
+                       (const unsigned short*)b, (unsigned short*)out, (long)n);
+    RGA3_CHECK_LAUNCH("silu_mul");
+    return 0;
+}
+
+extern "C" int rga3_add(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    RGA3_CHECK_ARG(a && b && out && n > 0, "add: bad args");
+    hipLaunchKernelGGL(ew2_kernel<1>, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)a,
+                       (const unsigned short*)b, (unsigned short*)out, (long)n);
+    RGA3_CHECK_LAUNCH("add");
+    return 0;
+}
+
+extern "C" int rga3_cross_entropy_rows(const void* logits, int logits_dtype, const int64_t* labels, float* row_loss,
+                                       void* dlogits, int64_t rows, int64_t V, int64_t ld, float grad_scale, void* stream) {
+    RGA3_CHECK_ARG(logits && labels && row_loss, "cross_entropy: null pointer");
+    RGA3_CHECK_ARG(rows > 0 && V > 0 && ld >= V, "cross_entropy: bad shape");
+    RGA3_CHECK_ARG(logits_dtype == RGA3_BF16 || logits_dtype == RGA3_F32, "cross_entropy: dtype");
+    hipStream_t st = (hipStream_t)stream;
+    if (logits_dtype == RGA3_F32)
+        hipLaunchKernelGGL(ce_rows_kernel<true>, dim3((unsigned)rows), dim3(256), 0, st, logits, (const long*)labels, row_loss,
+                           (unsigned short*)dlogits, (long)V, (long)ld, grad_scale);
+    else
+        hipLaunchKernelGGL(ce_rows_kernel<false>, dim3((unsigned)rows), dim3(256), 0, st, logits, (const long*)labels, row_loss,
+                           (unsigned short*)dlogits, (long)V, (long)ld, grad_scale);
+    RGA3_CHECK_LAUNCH("ce_rows_kernel");
+    return 0;
+}

@@ -1,0 +1,68 @@
+"""ctypes loader for librga3_hip.so (C ABI declared in include/rga3_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing or a symbol is
+absent, importing / calling raises.  Build it with ``make -C rga3-release_amd/csrc`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "librga3_hip.so"))
+
+_p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# symbol -> argtypes; mirrors include/rga3_hip.h one to one (tests/test_abi.py checks header <-> table <-> .so)
+SIGNATURES = {
+    "rga3_version": [],
+    "rga3_last_error": [C.c_char_p, _sz],
+    "rga3_gemm_bf16": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _p],
+    "rga3_attn_varlen_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
+                             _i64, _i64, _f, _i, _i, _p],
+    "rga3_rmsnorm_fwd": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p],
+    "rga3_layernorm_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
+    "rga3_rope_inplace": [_p, _p, _p, _i64, _i, _i, _i, _i64, _i64, _p],
+    "rga3_gather_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "rga3_scatter_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "rga3_pad_cols": [_p, _p, _i64, _i64, _i64, _i64, _p],
+    "rga3_silu_mul": [_p, _p, _p, _i64, _p],
+    "rga3_add": [_p, _p, _p, _i64, _p],
+    "rga3_cross_entropy_rows": [_p, _i, _p, _p, _p, _i64, _i64, _i64, _f, _p],
+}
+
+_lib = None
+
+
+class Rga3Error(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Rga3Error(
+            f"{LIB_PATH} not found: the HIP extension is required (no fallback path). "
+            "Run `make -C rga3-release_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().rga3_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise Rga3Error(f"{what} failed (rc={rc}): {last_error()}")

@@ -1,0 +1,209 @@
+"""Tensor-level wrappers over the C ABI (include/rga3_hip.h).
+
+PyTorch is used for device memory and streams only; every function here enqueues hand-written HIP kernels
+on ``torch.cuda.current_stream()`` and raises if the extension is missing or rejects its arguments.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import lib as _lib
+
+BF16, F32 = 0, 1
+ACT = {"none": 0, "gelu": 1, "swiglu": 2, "relu": 3}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.Rga3Error("rga3 HIP ops need device tensors (no CPU fallback on the product path)")
+
+
+def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:
+    """[rows, cols] bf16 -> [rows, ld] with zero-filled tail columns."""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    if x.stride(0) % 8 != 0:
+        raise _lib.Rga3Error("pad_cols: source row stride must be a multiple of 8 elements")
+    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().rga3_pad_cols(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), ld, _stream()), "pad_cols")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = "none", out_dtype=torch.bfloat16,
+         out=None, tile: int = -1) -> torch.Tensor:
+    """out = act(a @ w.T + bias) (+ residual).  a [M,K], w [N,K] (nn.Linear layout), bf16."""
+    _need_cuda(a, w, bias, residual, out)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+    assert a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    if K % 64 != 0 or a.stride(0) % 8 != 0 or w.stride(0) % 8 != 0:
+        Kp = (K + 63) // 64 * 64
+        if a.stride(0) % 8 != 0:
+            a = _repack_rows(a)
+        if w.stride(0) % 8 != 0:
+            w = _repack_rows(w)
+        a = pad_cols(a, Kp) if a.shape[1] != Kp else a
+        w = pad_cols(w, Kp) if w.shape[1] != Kp else w
+        K = Kp
+    n_out = N // 2 if act == "swiglu" else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=out_dtype, device=a.device)
+    assert out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == out_dtype
+    if bias is not None:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == N and bias.is_contiguous()
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == (M, n_out) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    rc = _lib.load().rga3_gemm_bf16(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K,
+                                    a.stride(0), w.stride(0), out.stride(0), ldr, ACT[act],
+                                    BF16 if out_dtype == torch.bfloat16 else F32, tile, _stream())
+    _lib.check(rc, "gemm_bf16")
+    return out
+
+
+def _repack_rows(x):
+    """Row stride not 16-byte aligned (e.g. K=3420): copy into an 8-element-aligned buffer (device-side copy)."""
+    rows, cols = x.shape
+    ld = (cols + 7) // 8 * 8
+    buf = torch.zeros((rows, ld), dtype=x.dtype, device=x.device)
+    buf[:, :cols].copy_(x)
+    return buf[:, :cols] if ld == cols else buf.as_strided((rows, cols), (ld, 1))
+
+
+def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = False, out=None, return_lse=False,
+                impl: int = 0):
+    """softmax(q k^T * scale) v over packed variable-length segments.
+
+    q [Tq, Hq, D], k/v [Tk, Hkv, D] (arbitrary token/head strides, unit stride on D); cu_* int32 [nseg+1].
+    """
+    _need_cuda(q, k, v, cu_q, cu_k)
+    assert q.dtype == k.dtype == v.dtype == torch.bfloat16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
+    Tq, Hq, D = q.shape
+    Hkv = k.shape[1]
+    nseg = cu_q.numel() - 1
+    if out is None:
+        out = torch.empty((Tq, Hq, D), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device) if return_lse else None
+    rc = _lib.load().rga3_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(lse),
+                                          cu_q.data_ptr(), cu_k.data_ptr(), nseg, int(max_q), Tq, Hq, Hkv, D,
+                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                          out.stride(0), out.stride(1), float(scale), int(bool(causal)), impl, _stream())
+    _lib.check(rc, "attn_varlen_fwd")
+    return (out, lse) if return_lse else out
+
+
+def rmsnorm(x, weight, eps: float, add=None, return_residual=False):
+    """HF RMSNorm on [rows, dim] bf16; with add: normalises (x + add) and optionally returns that sum."""
+    _need_cuda(x, weight, add)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    rows, dim = x.shape
+    y = torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
+    res = None
+    if add is not None:
+        assert add.shape == x.shape and add.stride() == x.stride()
+        if return_residual:
+            res = torch.empty_strided(x.shape, x.stride(), dtype=torch.bfloat16, device=x.device)
+    if x.stride(0) != dim:
+        x = x.contiguous()
+        add = add.contiguous() if add is not None else None
+    rc = _lib.load().rga3_rmsnorm_fwd(x.data_ptr(), _ptr(add), weight.data_ptr(), y.data_ptr(), _ptr(res), rows, dim,
+                                      x.stride(0), float(eps), _stream())
+    _lib.check(rc, "rmsnorm_fwd")
+    return (y, res) if return_residual else y
+
+
+def layernorm(x, weight, bias, eps: float):
+    _need_cuda(x, weight, bias)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    rows, dim = x.shape
+    y = torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
+    rc = _lib.load().rga3_layernorm_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), rows, dim, x.stride(0),
+                                        dim, float(eps), _stream())
+    _lib.check(rc, "layernorm_fwd")
+    return y
+
+
+def rope_(x, cos, sin, h0: int, nh: int):
+    """In-place rotate heads [h0, h0+nh) of x [T, H, D]; cos/sin [T, D] fp32."""
+    _need_cuda(x, cos, sin)
+    assert x.dtype == torch.bfloat16 and x.dim() == 3 and x.stride(2) == 1
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (x.shape[0], x.shape[2])
+    rc = _lib.load().rga3_rope_inplace(x.data_ptr(), cos.data_ptr(), sin.data_ptr(), x.shape[0], h0, nh, x.shape[2],
+                                       x.stride(0), x.stride(1), _stream())
+    _lib.check(rc, "rope_inplace")
+    return x
+
+
+def gather_rows(table, idx, rows_per_idx: int = 1):
+    """out[i*r + j] = table[idx[i]*r + j]"""
+    _need_cuda(table, idx)
+    assert table.dtype == torch.bfloat16 and table.dim() == 2 and table.stride(1) == 1 and idx.dtype == torch.int64
+    n = idx.numel()
+    out = torch.empty((n * rows_per_idx, table.shape[1]), dtype=torch.bfloat16, device=table.device)
+    rc = _lib.load().rga3_gather_rows(table.data_ptr(), idx.data_ptr(), out.data_ptr(), n, rows_per_idx, table.shape[1],
+                                      table.stride(0), out.stride(0), _stream())
+    _lib.check(rc, "gather_rows")
+    return out
+
+
+def scatter_rows_(out, idx, src, rows_per_idx: int = 1):
+    """out[idx[i]*r + j] = src[i*r + j] (in place)."""
+    _need_cuda(out, idx, src)
+    assert out.dtype == src.dtype == torch.bfloat16 and idx.dtype == torch.int64
+    assert out.dim() == 2 and src.dim() == 2 and out.stride(1) == 1 and src.stride(1) == 1 and out.shape[1] == src.shape[1]
+    n = idx.numel()
+    if n == 0:
+        return out
+    rc = _lib.load().rga3_scatter_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), n, rows_per_idx, src.shape[1],
+                                       src.stride(0), out.stride(0), _stream())
+    _lib.check(rc, "scatter_rows")
+    return out
+
+
+def silu_mul(a, b):
+    _need_cuda(a, b)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().rga3_silu_mul(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "silu_mul")
+    return out
+
+
+def add(a, b):
+    _need_cuda(a, b)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().rga3_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add")
+    return out
+
+
+def cross_entropy_rows(logits, labels, want_grad=False, grad_scale: float = 1.0):
+    """Per-row CE with ignore_index=-100 (rows with negative labels give 0)."""
+    _need_cuda(logits, labels)
+    assert logits.dim() == 2 and logits.stride(1) == 1 and labels.dtype == torch.int64 and labels.numel() == logits.shape[0]
+    rows, V = logits.shape
+    loss = torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty((rows, V), dtype=torch.bfloat16, device=logits.device) if want_grad else None
+    dt = BF16 if logits.dtype == torch.bfloat16 else F32
+    ld = logits.stride(0)
+    if dl is not None and ld != V:
+        logits = logits.contiguous()
+        ld = V
+    rc = _lib.load().rga3_cross_entropy_rows(logits.data_ptr(), dt, labels.data_ptr(), loss.data_ptr(), _ptr(dl), rows, V,
+                                             ld, float(grad_scale), _stream())
+    _lib.check(rc, "cross_entropy_rows")
+    return (loss, dl) if want_grad else loss
