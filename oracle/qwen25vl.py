@@ -230,11 +230,18 @@ def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw
         q = q * cos + rotate_half(q) * sin  # HF:160-171
         k = k * cos + rotate_half(k) * sin
         att = torch.empty_like(q)
-        for s in range(len(cu) - 1):  # HF:266-287: independent segments
-            a, b = int(cu[s]), int(cu[s + 1])
-            qq, kk, vv = (z[a:b].transpose(0, 1) for z in (q, k, val))
-            pr = torch.softmax(qq @ kk.transpose(1, 2) * hd ** -0.5, dim=-1)
-            att[a:b] = (pr @ vv).transpose(0, 1)
+        lens = np.diff(cu)
+        if len(lens) > 1 and (lens == lens[0]).all():  # equal-length segments: one batched product (same arithmetic)
+            L = int(lens[0])
+            qq, kk, vv = (z.reshape(-1, L, v.num_heads, hd).transpose(1, 2) for z in (q, k, val))
+            pr = torch.softmax(qq @ kk.transpose(2, 3) * hd ** -0.5, dim=-1)
+            att = (pr @ vv).transpose(1, 2).reshape(N, v.num_heads, hd)
+        else:
+            for s in range(len(cu) - 1):  # HF:266-287: independent segments
+                a, b = int(cu[s]), int(cu[s + 1])
+                qq, kk, vv = (z[a:b].transpose(0, 1) for z in (q, k, val))
+                pr = torch.softmax(qq @ kk.transpose(1, 2) * hd ** -0.5, dim=-1)
+                att[a:b] = (pr @ vv).transpose(0, 1)
         x = x + _lin(att.reshape(N, -1), P, pre + "attn.proj")
         h = rms_norm(x, P[pre + "norm2.weight"], 1e-6)
         h = _lin(F.silu(_lin(h, P, pre + "mlp.gate_proj")) * _lin(h, P, pre + "mlp.up_proj"), P, pre + "mlp.down_proj")

@@ -48,6 +48,14 @@ def load():
         raise Rga3Error(
             f"{LIB_PATH} not found: the HIP extension is required (no fallback path). "
             "Run `make -C rga3-release_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # The library binds to whichever HIP runtime (SONAME libamdhip64.so.7) the process loaded first.  PyTorch ships
+    # its own copy; load torch's first so kernels, streams and events all live in ONE runtime (loading ours first
+    # would pull /opt/rocm's copy in and split the process across two runtimes).
+    import torch  # noqa: F401
+
+    _thip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(_thip):
+        C.CDLL(_thip, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
