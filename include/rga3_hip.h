@@ -40,13 +40,15 @@ int rga3_version(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
 int rga3_last_error(char* buf, size_t n);
 
-/* C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual).  bf16 in, f32 accumulate, bf16 or f32 out.
+/* C[M,N] = residual + colscale * act(A[M,K] . W[N,K]^T + bias)  (bias / residual / colscale optional).
+ * bf16 in, f32 accumulate, bf16 or f32 out.
  * Replaces nn.Linear / 1x1 conv / Conv3d-as-GEMM call sites: HF modeling_qwen2_5_vl.py:84-96 (MLP),
  * :99-122 (patch embed), :137-150 (merger), :211-291 (ViT qkv/proj), :602-757 (decoder projections),
  * :1383 (lm_head); reference model/qwen_2_5_vl_sam2.py:131-137 (text_hidden_fcs), model/sam2.py:986-1117
  * (Hiera qkv/proj/mlp), :857-889 (FPN 1x1), :1417-1481 (decoder attention projections).
- * K must be a multiple of 64, lda/ldw multiples of 8; tile = -1 lets the library choose. */
-int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N,
+ * colscale [N_out] is the ConvNeXt layer scale of reference model/sam2.py:690-703.
+ * K, lda, ldw must be multiples of 8 (16-byte rows); tile = -1 lets the library choose. */
+int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, int out_dtype, int tile,
                    void* stream);
 
@@ -71,9 +73,10 @@ int rga3_rmsnorm_fwd(const void* x, const void* add, const void* weight, void* y
                      int64_t dim, int64_t ldx, float eps, void* stream);
 
 /* LayerNorm over the last dim with affine, fp32 statistics (nn.LayerNorm; reference model/sam2.py:1050-1051,
- * :474-476).  x,y [rows, dim] bf16. */
+ * :474-476; on token-major maps this is also LayerNorm2d, :2334-2346).  x,y [rows, dim] bf16.
+ * act: 0 none, 1 exact GELU applied to the normalised output (MaskDownSampler / output_upscaling, :611-643, :1976-1986). */
 int rga3_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int64_t dim,
-                       int64_t ldx, int64_t ldy, float eps, void* stream);
+                       int64_t ldx, int64_t ldy, float eps, int act, void* stream);
 
 /* In-place rotary embedding on q and k heads living inside one [T, nheads_total, D] buffer (fused QKV output):
  * x = x*cos + rotate_half(x)*sin in fp32, cos/sin: [T, D] f32 tables (HF apply_rotary_pos_emb_vision
@@ -103,6 +106,37 @@ int rga3_add(const void* a, const void* b, void* out, int64_t n, void* stream);
  * (softmax - onehot) * grad_scale in bf16. */
 int rga3_cross_entropy_rows(const void* logits, int logits_dtype, const int64_t* labels, float* row_loss,
                             void* dlogits, int64_t rows, int64_t V, int64_t ld, float grad_scale, void* stream);
+
+/* ---- SAM2-side kernels (all feature maps token-major [pixels, C]) ------------------------------------------- */
+
+/* im2col for Conv2d(ks, stride, pad) on NCHW bf16 images -> [F*Ho*Wo, ld_out] rows, columns (c, kh, kw), zero tail;
+ * feeds the patch-embed GEMM (reference model/sam2.py:940-970: Conv2d 3->144 k7 s4 p3). */
+int rga3_im2col(const void* img, void* out, int64_t F, int C, int H, int W, int ks, int stride, int pad, int64_t ld_out,
+                void* stream);
+/* MaxPool2d(2,2) on window-major tokens (windows of w x w -> w/2 x w/2): Hiera q-pooling, model/sam2.py:972-983,1015-1018 */
+int rga3_maxpool2x2_win(const void* x, void* y, int64_t nwin, int w, int C, int64_t ldx, int64_t ldy, void* stream);
+/* out[f,y,x,:] = a[f,y,x,:] + b[f,y/2,x/2,:]: FPN nearest x2 top-down path, model/sam2.py:867-889 */
+int rga3_upsample2x_add(const void* a, const void* b, void* out, int64_t F, int H, int W, int C, void* stream);
+/* out[r,:] = a[r,:] + alpha * b[r % rows_b,:] (positional-encoding adds: model/sam2.py:571-572, 1390-1409, 355) */
+int rga3_add_bcast(const void* a, const void* b, void* out, int64_t rows, int64_t rows_b, int C, int64_t lda, int64_t ldb,
+                   int64_t ldo, float alpha, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=False) on planes [N,Hi,Wi] -> f32 [N,Ho,Wo]; plane_idx (optional, int32 [N])
+ * selects the source plane per output (argmax-IoU candidate): model/sam2.py:3388-3402, qwen_2_5_vl_sam2.py:248,272,387 */
+int rga3_bilinear(const void* in, int in_dtype, float* out, const int32_t* plane_idx, int64_t N, int Hi, int Wi, int Ho, int Wo,
+                  void* stream);
+/* Conv2d(k3,s2,p1) token-major; x_dtype F32 = single fp32 plane transformed by sigmoid(x)*sig_scale+sig_bias on load
+ * (model/sam2.py:3017-3022 + MaskDownSampler :611-643) */
+int rga3_conv3x3s2(const void* x, int x_dtype, const void* w, const void* bias, void* y, int64_t F, int H, int W, int Cin, int Cout,
+                   float sig_scale, float sig_bias, void* stream);
+/* depthwise Conv2d(k7,p3) token-major (CXBlock.dwconv, model/sam2.py:669-675) */
+int rga3_dwconv7x7(const void* x, const void* w, const void* bias, void* y, int64_t F, int H, int W, int C, void* stream);
+/* axial complex RoPE in place on [T, C] single-head tokens; rows t < n_rope use table row t % nq (model/sam2.py:1901-1923) */
+int rga3_rope_axial_inplace(void* x, const float* cos, const float* sin, int64_t n_rope, int nq, int C, int64_t ldx, void* stream);
+/* ConvTranspose2d(k2,s2) = GEMM to [pixels, 4*Co] + this shuffle (+bias, + optional high-res feature add, then
+ * act: 0 none / 1 GELU), model/sam2.py:2137-2140 */
+int rga3_pixel_shuffle2x(const void* g, const void* bias, const void* add, void* out, int64_t F, int H, int W, int Co, int act, void* stream);
+/* per-mask {sum BCE-with-logits, sum sigmoid*t, sum sigmoid, sum t} (model/qwen_2_5_vl_sam2.py:17-60); out4 f32 [n_masks,4] */
+int rga3_bce_dice_sums(const float* logits, const float* targets, float* out4, int64_t n_masks, int64_t hw, void* stream);
 
 #ifdef __cplusplus
 }

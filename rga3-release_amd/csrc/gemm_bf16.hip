@@ -29,10 +29,14 @@ struct GemmArgs {
     void* C;
     const unsigned short* bias;  // [N] (for SWIGLU: [N], interleaved like W) or null
     const unsigned short* res;   // [M, Nout] bf16 or null
+    const unsigned short* colscale;  // [Nout] bf16 or null: out = res + colscale[n] * act(acc + bias)  (ConvNeXt layer scale)
     int M, N, K;
     long lda, ldw, ldc, ldr;
     int ntm, ntn;
 };
+
+// 16 bytes of zeros in device memory: source for staging chunks that lie beyond K in the last K-tile
+__device__ const u32x4 g_zero16 = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -87,10 +91,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         bsrc[i] = p.W + (long)gr * p.ldw + ch * 8;
     }
 
-    auto stage_tile = [&](int s, int kt) {
+    const bool ktail = (p.K % BK) != 0;  // K is a multiple of 8: the last tile may be partial
+    auto stage_tile = [&](int s, int kt, bool last) {
         char* sa = smem + s * STAGE;
         char* sb = sa + BM * ROWB;
         const long koff = (long)kt * BK;
+        if (last && ktail) {
+            // chunks at or beyond K read 16 zero bytes instead (per-lane source address; LDS image unchanged)
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const int r = (wid + i * NW) * 8 + (lane >> 3);
+                const int ch = (lane & 7) ^ ((r >> 1) & 7);
+                const unsigned short* src = (kt * BK + ch * 8 < p.K) ? asrc[i] + koff : (const unsigned short*)&g_zero16;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sa + (wid + i * NW) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const int r = (wid + i * NW) * 8 + (lane >> 3);
+                const int ch = (lane & 7) ^ ((r >> 1) & 7);
+                const unsigned short* src = (kt * BK + ch * 8 < p.K) ? bsrc[i] + koff : (const unsigned short*)&g_zero16;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sb + (wid + i * NW) * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < APW; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[i] + koff), (lds_void*)(sa + (wid + i * NW) * 1024), 16, 0, 0);
@@ -110,13 +133,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    stage_tile(0, 0);
+    const int nk = (p.K + BK - 1) / BK;
+    stage_tile(0, 0, nk == 1);
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed (own loads: vmcnt(0); everyone's: barrier) and everyone is done reading
         // the other stage, so it can be refilled while this one is consumed.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage_tile((kt + 1) & 1, kt + 1);
+        if (kt + 1 < nk) stage_tile((kt + 1) & 1, kt + 1, kt + 2 == nk);
         const char* As = smem + (kt & 1) * STAGE + (wm * WTM) * ROWB;
         const char* Bs = smem + (kt & 1) * STAGE + BM * ROWB + (wn * WTN) * ROWB;
 #pragma unroll
@@ -165,6 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
                     gt = bf2f(f2bf(gt));
                     up = bf2f(f2bf(up));
                     v[r] = bf2f(f2bf(silu_f(gt))) * up;
+                    if (p.colscale) v[r] *= bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);
                 }
             } else {
 #pragma unroll
@@ -176,6 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
                     }
                     if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
                     if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
+                    if (p.colscale) x = bf2f(f2bf(x)) * bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);
                     v[r] = x;
                 }
             }
@@ -293,17 +319,17 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
 
 using namespace rga3;
 
-extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C,
+extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
                               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                               int act, int out_dtype, int tile, void* stream) {
     RGA3_CHECK_ARG(A && W && C, "gemm: null pointer");
     RGA3_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-    RGA3_CHECK_ARG(K % 64 == 0, "gemm: K=%ld must be a multiple of 64 (pad the operands)", (long)K);
+    RGA3_CHECK_ARG(K % 8 == 0, "gemm: K=%ld must be a multiple of 8 (16-byte staging chunks)", (long)K);
     RGA3_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
     RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0, "gemm: pointers must be 16-byte aligned");
     RGA3_CHECK_ARG(out_dtype == RGA3_BF16 || out_dtype == RGA3_F32, "gemm: out_dtype %d", out_dtype);
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
-    RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual)), "gemm: f32 output supports bias only");
+    RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
     RGA3_CHECK_ARG(tile >= -1 && tile <= 2, "gemm: tile %d", tile);
     GemmArgs a;
@@ -312,6 +338,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.C = C;
     a.bias = (const unsigned short*)bias;
     a.res = (const unsigned short*)residual;
+    a.colscale = (const unsigned short*)colscale;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     hipStream_t st = (hipStream_t)stream;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                                         const unsigned short* __restrict__ b, unsigned short* __restrict__ y,
-                                                        long rows, int dim, long ldx, long ldy, float eps) {
+                                                        long rows, int dim, long ldx, long ldy, float eps, int act) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -111,7 +111,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
             unpack8(*(const u32x4*)(w + ch * 8), fw);
             if (b) unpack8(*(const u32x4*)(b + ch * 8), fb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rinv * fw[e] + (b ? fb[e] : 0.f);
+            for (int e = 0; e < 8; ++e) {
+                f[e] = (f[e] - mean) * rinv * fw[e] + (b ? fb[e] : 0.f);
+                if (act == 1) { float t = bf2f(f2bf(f[e])); f[e] = 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); }
+            }
             *(u32x4*)(y + row * ldy + ch * 8) = pack8(f);
         }
     }
@@ -284,16 +287,16 @@ extern "C" int rga3_rmsnorm_fwd(const void* x, const void* add, const void* weig
 }
 
 extern "C" int rga3_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int64_t dim,
-                                  int64_t ldx, int64_t ldy, float eps, void* stream) {
+                                  int64_t ldx, int64_t ldy, float eps, int act, void* stream) {
     RGA3_CHECK_ARG(x && weight && y, "layernorm: null pointer");
     RGA3_CHECK_ARG(rows > 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && dim <= 8192, "layernorm: rows=%ld dim=%ld", (long)rows, (long)dim);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv(rows, 4));
     const unsigned short *xp = (const unsigned short*)x, *wp = (const unsigned short*)weight, *bp = (const unsigned short*)bias;
     unsigned short* yp = (unsigned short*)y;
-    if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps);
-    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps);
+    if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
     RGA3_CHECK_LAUNCH("layernorm_kernel");
     return 0;
 }

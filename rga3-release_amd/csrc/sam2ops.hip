@@ -1,0 +1,386 @@
+// HBM-bound kernels specific to the SAM2 half of the path (reference model/sam2.py): patch im2col, windowed max-pool,
+// FPN top-down add, broadcast adds, bilinear resampling (+ candidate select), small-channel strided conv, depthwise 7x7,
+// axial complex RoPE, mask -> memory-encoder affine sigmoid, ConvTranspose pixel shuffle, BCE/dice partial sums.
+// All feature maps are TOKEN-MAJOR ([pixels, C], i.e. NHWC): 1x1 convs / linears are plain GEMMs and every kernel
+// below is coalesced along C.
+#include "common.h"
+
+namespace rga3 {
+
+__device__ __forceinline__ void up8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pk8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// ---- im2col for Conv2d(k=KS, stride=ST, pad=PD) on NCHW bf16 images -> rows [F*Ho*Wo, ldo], cols (c, kh, kw), zero tail
+__global__ __launch_bounds__(256) void im2col_kernel(const unsigned short* __restrict__ img, unsigned short* __restrict__ out, int F, int C,
+                                                     int H, int W, int KS, int ST, int PD, int Ho, int Wo, int ldo) {
+    const long total = (long)F * Ho * Wo * ldo;
+    const int ncol = C * KS * KS;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % ldo);
+        const long row = i / ldo;
+        unsigned short v = 0;
+        if (col < ncol) {
+            const int kw = col % KS, kh = (col / KS) % KS, c = col / (KS * KS);
+            const int x = (int)(row % Wo), y = (int)((row / Wo) % Ho);
+            const long f = row / ((long)Wo * Ho);
+            const int sy = y * ST - PD + kh, sx = x * ST - PD + kw;
+            if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = img[((f * C + c) * H + sy) * (long)W + sx];
+        }
+        out[i] = v;
+    }
+}
+
+// ---- 2x2 max pool on window-major tokens: windows of w x w tokens -> (w/2) x (w/2), channels 8 at a time.
+__global__ __launch_bounds__(256) void maxpool_win_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, long nwin, int w,
+                                                          int C, long ldx, long ldy) {
+    const int wo = w / 2, nch = C / 8;
+    const long total = nwin * wo * wo * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        long t = i / nch;
+        const int c = (int)(t % wo), r = (int)((t / wo) % wo);
+        const long win = t / ((long)wo * wo);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const long tok = win * w * w + (2 * r + dy) * w + (2 * c + dx);
+                float f[8];
+                up8(*(const u32x4*)(x + tok * ldx + ch * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], f[e]);
+            }
+        *(u32x4*)(y + t * ldy + ch * 8) = pk8(m);
+    }
+}
+
+// ---- out[f, y, x, :] = a[f, y, x, :] + b[f, y/2, x/2, :]   (FPN nearest x2 top-down, reference sam2.py:867-889)
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                                                             unsigned short* __restrict__ o, long F, int H, int W, int C) {
+    const int nch = C / 8;
+    const long total = F * H * W * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long t = i / nch;
+        const int x = (int)(t % W), y = (int)((t / W) % H);
+        const long f = t / ((long)W * H);
+        const long tb = (f * (H / 2) + y / 2) * (W / 2) + x / 2;
+        float fa[8], fb[8];
+        up8(*(const u32x4*)(a + t * C + ch * 8), fa);
+        up8(*(const u32x4*)(b + tb * C + ch * 8), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+        *(u32x4*)(o + t * C + ch * 8) = pk8(fa);
+    }
+}
+
+// ---- out[r, :] = a[r, :] + alpha * b[r % rows_b, :]
+__global__ __launch_bounds__(256) void add_bcast_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
+                                                        unsigned short* __restrict__ o, long rows, long rows_b, int C, long lda, long ldb, long ldo,
+                                                        float alpha) {
+    const int nch = C / 8;
+    const long total = rows * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long r = i / nch;
+        float fa[8], fb[8];
+        up8(*(const u32x4*)(a + r * lda + ch * 8), fa);
+        up8(*(const u32x4*)(b + (r % rows_b) * ldb + ch * 8), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] += alpha * fb[e];
+        *(u32x4*)(o + r * ldo + ch * 8) = pk8(fa);
+    }
+}
+
+// ---- bilinear resize (align_corners=False, PyTorch area_pixel_compute_source_index), planes [N, Hi, Wi] -> [N, Ho, Wo] f32.
+//      plane_idx (optional): output plane n reads input plane plane_idx[n] (select-then-upsample of the argmax-IoU mask).
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void bilinear_kernel(const void* __restrict__ in, float* __restrict__ out, const int* __restrict__ plane_idx,
+                                                       long N, int Hi, int Wi, int Ho, int Wo) {
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    const long total = N * Ho * Wo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+        const long n = i / ((long)Wo * Ho);
+        const long pn = plane_idx ? plane_idx[n] : n;
+        float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        auto ld = [&](int yy, int xx) -> float {
+            const long o = (pn * Hi + yy) * (long)Wi + xx;
+            if (IN_BF16) return bf2f(((const unsigned short*)in)[o]);
+            return ((const float*)in)[o];
+        };
+        const float v = (1.f - ly) * ((1.f - lx) * ld(y0, x0) + lx * ld(y0, x1)) + ly * ((1.f - lx) * ld(y1, x0) + lx * ld(y1, x1));
+        out[i] = v;
+    }
+}
+
+// ---- Conv2d(k=3, s=2, p=1) on token-major maps: x [F, H, W, Cin] -> y [F, H/2, W/2, Cout]; w [Cout, Cin, 3, 3]; f32 accumulate.
+//      IN_F32: x is an fp32 single-channel plane (the mask), transformed on load by sigmoid(x)*ascale+abias if ascale != 0.
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void conv3x3s2_kernel(const void* __restrict__ x, const unsigned short* __restrict__ w, const unsigned short* __restrict__ bias,
+                                                        unsigned short* __restrict__ y, long F, int H, int W, int Cin, int Cout, float ascale, float abias) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = F * Ho * Wo * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        const long t = i / Cout;
+        const int ox = (int)(t % Wo), oy = (int)((t / Wo) % Ho);
+        const long f = t / ((long)Wo * Ho);
+        float acc = bias ? bf2f(bias[co]) : 0.f;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int sy = oy * 2 - 1 + kh;
+            if (sy < 0 || sy >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int sx = ox * 2 - 1 + kw;
+                if (sx < 0 || sx >= W) continue;
+                const long pix = (f * H + sy) * (long)W + sx;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    float xv;
+                    if (IN_F32) {
+                        xv = ((const float*)x)[pix * Cin + ci];
+                        if (ascale != 0.f) xv = bf2f(f2bf(ascale / (1.f + __expf(-xv)) + abias));
+                    } else {
+                        xv = bf2f(((const unsigned short*)x)[pix * Cin + ci]);
+                    }
+                    acc += xv * bf2f(w[((co * Cin + ci) * 3 + kh) * 3 + kw]);
+                }
+            }
+        }
+        y[i] = f2bf(acc);
+    }
+}
+
+// ---- depthwise Conv2d(k=7, p=3) on token-major maps [F, H, W, C]; w [C, 1, 7, 7]; 8 channels per thread.
+__global__ __launch_bounds__(256) void dwconv7_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                      const unsigned short* __restrict__ bias, unsigned short* __restrict__ y, long F, int H, int W, int C) {
+    const int nch = C / 8;
+    const long total = F * H * W * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long t = i / nch;
+        const int px = (int)(t % W), py = (int)((t / W) % H);
+        const long f = t / ((long)W * H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bf2f(bias[ch * 8 + e]) : 0.f;
+        for (int kh = 0; kh < 7; ++kh) {
+            const int sy = py - 3 + kh;
+            if (sy < 0 || sy >= H) continue;
+            for (int kw = 0; kw < 7; ++kw) {
+                const int sx = px - 3 + kw;
+                if (sx < 0 || sx >= W) continue;
+                float fx[8];
+                up8(*(const u32x4*)(x + ((f * H + sy) * (long)W + sx) * C + ch * 8), fx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += fx[e] * bf2f(w[(ch * 8 + e) * 49 + kh * 7 + kw]);
+            }
+        }
+        *(u32x4*)(y + t * C + ch * 8) = pk8(acc);
+    }
+}
+
+// ---- axial complex RoPE in place (reference sam2.py:1901-1923): consecutive (even, odd) pairs, token t < n_rope uses
+//      table row t % nq; cos/sin [nq, C/2] f32; x [T, C] bf16 with row stride ldx (single head).
+__global__ __launch_bounds__(256) void rope_axial_kernel(unsigned short* __restrict__ x, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                         long n_rope, int nq, int C, long ldx) {
+    const int nch = C / 8;
+    const long total = n_rope * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long t = i / nch;
+        const long tr = t % nq;
+        float f[8];
+        unsigned short* p = x + t * ldx + ch * 8;
+        up8(*(const u32x4*)p, f);
+        const float* c = cs + tr * (C / 2) + ch * 4;
+        const float* s = sn + tr * (C / 2) + ch * 4;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = f[2 * e] * c[e] - f[2 * e + 1] * s[e];
+            o[2 * e + 1] = f[2 * e] * s[e] + f[2 * e + 1] * c[e];
+        }
+        *(u32x4*)p = pk8(o);
+    }
+}
+
+// ---- ConvTranspose2d(k=2, s=2) second half: g [F*H*W, 4*Co] (GEMM output, column (dy*2+dx)*Co + co) -> token-major
+//      [F, 2H, 2W, Co] with bias and an optional added map (high-res feature), reference sam2.py:2137-2140.
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const unsigned short* __restrict__ g, const unsigned short* __restrict__ bias,
+                                                            const unsigned short* __restrict__ add, unsigned short* __restrict__ o, long F, int H, int W, int Co, int act) {
+    const int nch = Co / 8;
+    const long total = F * (2 * H) * (2 * W) * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long t = i / nch;
+        const int X = (int)(t % (2 * W)), Y = (int)((t / (2 * W)) % (2 * H));
+        const long f = t / ((long)4 * W * H);
+        const long src = (f * H + Y / 2) * (long)W + X / 2;
+        const int q = (Y & 1) * 2 + (X & 1);
+        float fg[8], fb[8];
+        up8(*(const u32x4*)(g + src * (4L * Co) + q * Co + ch * 8), fg);
+        if (bias) {
+            up8(*(const u32x4*)(bias + ch * 8), fb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fg[e] = bf2f(f2bf(fg[e] + fb[e]));
+        }
+        if (add) {
+            up8(*(const u32x4*)(add + t * Co + ch * 8), fb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fg[e] += fb[e];
+        }
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float tv = bf2f(f2bf(fg[e])); fg[e] = 0.5f * tv * (1.0f + erff(tv * 0.70710678118654752f)); }
+        }
+        *(u32x4*)(o + t * Co + ch * 8) = pk8(fg);
+    }
+}
+
+// ---- per-mask partial sums for BCE-with-logits and dice (reference qwen_2_5_vl_sam2.py:17-60):
+//      out[n] = { sum bce(x,t), sum sigmoid(x)*t, sum sigmoid(x), sum t }; one block per (mask, slice), atomics into out.
+__global__ __launch_bounds__(256) void bce_dice_kernel(const float* __restrict__ x, const float* __restrict__ tg, float* __restrict__ out, long hw) {
+    __shared__ float red[4][4];
+    const long n = blockIdx.y;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        const float v = x[n * hw + i], t = tg[n * hw + i];
+        s0 += fmaxf(v, 0.f) - v * t + log1pf(__expf(-fabsf(v)));  // stable BCE-with-logits
+        const float p = 1.f / (1.f + __expf(-v));
+        s1 += p * t;
+        s2 += p;
+        s3 += t;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = s0; red[wv][1] = s1; red[wv][2] = s2; red[wv][3] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(out + n * 4 + threadIdx.x, v);
+    }
+}
+
+static inline unsigned grid1(long total, long cap = 256L * 32) {
+    long b = cdiv(total, 256);
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace rga3
+
+using namespace rga3;
+typedef const unsigned short* cus;
+typedef unsigned short* us;
+
+extern "C" int rga3_im2col(const void* img, void* out, int64_t F, int C, int H, int W, int ks, int stride, int pad, int64_t ld_out,
+                           void* stream) {
+    RGA3_CHECK_ARG(img && out && F > 0 && C > 0 && H > 0 && W > 0 && ks > 0 && stride > 0, "im2col: bad args");
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    RGA3_CHECK_ARG(ld_out >= (int64_t)C * ks * ks, "im2col: ld_out too small");
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid1(F * Ho * Wo * ld_out)), dim3(256), 0, (hipStream_t)stream, (cus)img, (us)out, (int)F, C, H, W, ks,
+                       stride, pad, Ho, Wo, (int)ld_out);
+    RGA3_CHECK_LAUNCH("im2col");
+    return 0;
+}
+
+extern "C" int rga3_maxpool2x2_win(const void* x, void* y, int64_t nwin, int w, int C, int64_t ldx, int64_t ldy, void* stream) {
+    RGA3_CHECK_ARG(x && y && nwin > 0 && w >= 2 && w % 2 == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "maxpool2x2_win: bad args");
+    hipLaunchKernelGGL(maxpool_win_kernel, dim3(grid1(nwin * (w / 2) * (w / 2) * (C / 8))), dim3(256), 0, (hipStream_t)stream, (cus)x, (us)y,
+                       (long)nwin, w, C, (long)ldx, (long)ldy);
+    RGA3_CHECK_LAUNCH("maxpool2x2_win");
+    return 0;
+}
+
+extern "C" int rga3_upsample2x_add(const void* a, const void* b, void* out, int64_t F, int H, int W, int C, void* stream) {
+    RGA3_CHECK_ARG(a && b && out && F > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "upsample2x_add: bad args");
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid1(F * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, (cus)a, (cus)b, (us)out, (long)F, H, W, C);
+    RGA3_CHECK_LAUNCH("upsample2x_add");
+    return 0;
+}
+
+extern "C" int rga3_add_bcast(const void* a, const void* b, void* out, int64_t rows, int64_t rows_b, int C, int64_t lda, int64_t ldb,
+                              int64_t ldo, float alpha, void* stream) {
+    RGA3_CHECK_ARG(a && b && out && rows > 0 && rows_b > 0 && C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "add_bcast: bad args");
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(grid1(rows * (C / 8))), dim3(256), 0, (hipStream_t)stream, (cus)a, (cus)b, (us)out, (long)rows,
+                       (long)rows_b, C, (long)lda, (long)ldb, (long)ldo, alpha);
+    RGA3_CHECK_LAUNCH("add_bcast");
+    return 0;
+}
+
+extern "C" int rga3_bilinear(const void* in, int in_dtype, float* out, const int32_t* plane_idx, int64_t N, int Hi, int Wi, int Ho, int Wo,
+                             void* stream) {
+    RGA3_CHECK_ARG(in && out && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad args");
+    RGA3_CHECK_ARG(in_dtype == RGA3_BF16 || in_dtype == RGA3_F32, "bilinear: dtype");
+    dim3 g(grid1(N * Ho * Wo));
+    if (in_dtype == RGA3_BF16)
+        hipLaunchKernelGGL(bilinear_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, in, out, plane_idx, (long)N, Hi, Wi, Ho, Wo);
+    else
+        hipLaunchKernelGGL(bilinear_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, in, out, plane_idx, (long)N, Hi, Wi, Ho, Wo);
+    RGA3_CHECK_LAUNCH("bilinear");
+    return 0;
+}
+
+extern "C" int rga3_conv3x3s2(const void* x, int x_dtype, const void* w, const void* bias, void* y, int64_t F, int H, int W, int Cin, int Cout,
+                              float sig_scale, float sig_bias, void* stream) {
+    RGA3_CHECK_ARG(x && w && y && F > 0 && H % 2 == 0 && W % 2 == 0 && Cin > 0 && Cout > 0, "conv3x3s2: bad args");
+    dim3 g(grid1(F * (H / 2) * (W / 2) * Cout));
+    if (x_dtype == RGA3_F32)
+        hipLaunchKernelGGL(conv3x3s2_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, x, (cus)w, (cus)bias, (us)y, (long)F, H, W, Cin, Cout, sig_scale, sig_bias);
+    else
+        hipLaunchKernelGGL(conv3x3s2_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, x, (cus)w, (cus)bias, (us)y, (long)F, H, W, Cin, Cout, 0.f, 0.f);
+    RGA3_CHECK_LAUNCH("conv3x3s2");
+    return 0;
+}
+
+extern "C" int rga3_dwconv7x7(const void* x, const void* w, const void* bias, void* y, int64_t F, int H, int W, int C, void* stream) {
+    RGA3_CHECK_ARG(x && w && y && F > 0 && C % 8 == 0, "dwconv7x7: bad args");
+    hipLaunchKernelGGL(dwconv7_kernel, dim3(grid1(F * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, (cus)x, (cus)w, (cus)bias, (us)y, (long)F, H, W, C);
+    RGA3_CHECK_LAUNCH("dwconv7x7");
+    return 0;
+}
+
+extern "C" int rga3_rope_axial_inplace(void* x, const float* cos, const float* sin, int64_t n_rope, int nq, int C, int64_t ldx, void* stream) {
+    RGA3_CHECK_ARG(x && cos && sin && nq > 0 && C % 8 == 0 && ldx % 8 == 0, "rope_axial: bad args");
+    if (n_rope <= 0) return 0;
+    hipLaunchKernelGGL(rope_axial_kernel, dim3(grid1(n_rope * (C / 8))), dim3(256), 0, (hipStream_t)stream, (us)x, cos, sin, (long)n_rope, nq, C, (long)ldx);
+    RGA3_CHECK_LAUNCH("rope_axial");
+    return 0;
+}
+
+extern "C" int rga3_pixel_shuffle2x(const void* g, const void* bias, const void* add, void* out, int64_t F, int H, int W, int Co, int act, void* stream) {
+    RGA3_CHECK_ARG(g && out && F > 0 && Co % 8 == 0, "pixel_shuffle2x: bad args");
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid1(F * 4L * H * W * (Co / 8))), dim3(256), 0, (hipStream_t)stream, (cus)g, (cus)bias, (cus)add, (us)out,
+                       (long)F, H, W, Co, act);
+    RGA3_CHECK_LAUNCH("pixel_shuffle2x");
+    return 0;
+}
+
+extern "C" int rga3_bce_dice_sums(const float* logits, const float* targets, float* out4, int64_t n_masks, int64_t hw, void* stream) {
+    RGA3_CHECK_ARG(logits && targets && out4 && n_masks > 0 && hw > 0 && n_masks <= 65535, "bce_dice_sums: bad args");
+    hipError_t e = hipMemsetAsync(out4, 0, sizeof(float) * 4 * n_masks, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(-(int)e, "bce_dice_sums: memset: %s", hipGetErrorString(e));
+    unsigned gx = (unsigned)cdiv(hw, 256 * 8);
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(bce_dice_kernel, dim3(gx, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, logits, targets, out4, (long)hw);
+    RGA3_CHECK_LAUNCH("bce_dice_sums");
+    return 0;
+}

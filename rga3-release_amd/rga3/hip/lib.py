@@ -18,11 +18,11 @@ _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "rga3_version": [],
     "rga3_last_error": [C.c_char_p, _sz],
-    "rga3_gemm_bf16": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _p],
+    "rga3_gemm_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _p],
     "rga3_attn_varlen_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
                              _i64, _i64, _f, _i, _i, _p],
     "rga3_rmsnorm_fwd": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p],
-    "rga3_layernorm_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
+    "rga3_layernorm_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _i, _p],
     "rga3_rope_inplace": [_p, _p, _p, _i64, _i, _i, _i, _i64, _i64, _p],
     "rga3_gather_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "rga3_scatter_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
@@ -30,6 +30,16 @@ SIGNATURES = {
     "rga3_silu_mul": [_p, _p, _p, _i64, _p],
     "rga3_add": [_p, _p, _p, _i64, _p],
     "rga3_cross_entropy_rows": [_p, _i, _p, _p, _p, _i64, _i64, _i64, _f, _p],
+    "rga3_im2col": [_p, _p, _i64, _i, _i, _i, _i, _i, _i, _i64, _p],
+    "rga3_maxpool2x2_win": [_p, _p, _i64, _i, _i, _i64, _i64, _p],
+    "rga3_upsample2x_add": [_p, _p, _p, _i64, _i, _i, _i, _p],
+    "rga3_add_bcast": [_p, _p, _p, _i64, _i64, _i, _i64, _i64, _i64, _f, _p],
+    "rga3_bilinear": [_p, _i, _p, _p, _i64, _i, _i, _i, _i, _p],
+    "rga3_conv3x3s2": [_p, _i, _p, _p, _p, _i64, _i, _i, _i, _i, _f, _f, _p],
+    "rga3_dwconv7x7": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],
+    "rga3_rope_axial_inplace": [_p, _p, _p, _i64, _i, _i, _i64, _p],
+    "rga3_pixel_shuffle2x": [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _p],
+    "rga3_bce_dice_sums": [_p, _p, _p, _i64, _i64, _p],
 }
 
 _lib = None

@@ -40,16 +40,16 @@ def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = "none", out_dtype=torch.bfloat16,
-         out=None, tile: int = -1) -> torch.Tensor:
-    """out = act(a @ w.T + bias) (+ residual).  a [M,K], w [N,K] (nn.Linear layout), bf16."""
-    _need_cuda(a, w, bias, residual, out)
+         out=None, tile: int = -1, colscale=None) -> torch.Tensor:
+    """out = residual + colscale * act(a @ w.T + bias).  a [M,K], w [N,K] (nn.Linear layout), bf16."""
+    _need_cuda(a, w, bias, residual, out, colscale)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
     assert a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
-    if K % 64 != 0 or a.stride(0) % 8 != 0 or w.stride(0) % 8 != 0:
-        Kp = (K + 63) // 64 * 64
+    if K % 8 != 0 or a.stride(0) % 8 != 0 or w.stride(0) % 8 != 0:
+        Kp = (K + 7) // 8 * 8
         if a.stride(0) % 8 != 0:
             a = _repack_rows(a)
         if w.stride(0) % 8 != 0:
@@ -67,7 +67,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.shape == (M, n_out) and residual.stride(1) == 1
         ldr = residual.stride(0)
-    rc = _lib.load().rga3_gemm_bf16(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K,
+    if colscale is not None:
+        assert colscale.dtype == torch.bfloat16 and colscale.numel() == n_out and colscale.is_contiguous()
+    rc = _lib.load().rga3_gemm_bf16(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(colscale), out.data_ptr(), M, N, K,
                                     a.stride(0), w.stride(0), out.stride(0), ldr, ACT[act],
                                     BF16 if out_dtype == torch.bfloat16 else F32, tile, _stream())
     _lib.check(rc, "gemm_bf16")
@@ -127,13 +129,14 @@ def rmsnorm(x, weight, eps: float, add=None, return_residual=False):
     return (y, res) if return_residual else y
 
 
-def layernorm(x, weight, bias, eps: float):
+def layernorm(x, weight, bias, eps: float, act: str = "none", out=None):
+    """LayerNorm over the last dim of [rows, dim] (row stride free); act="gelu" fuses the exact GELU."""
     _need_cuda(x, weight, bias)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
     rows, dim = x.shape
-    y = torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
+    y = out if out is not None else torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
     rc = _lib.load().rga3_layernorm_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), rows, dim, x.stride(0),
-                                        dim, float(eps), _stream())
+                                        y.stride(0), float(eps), 1 if act == "gelu" else 0, _stream())
     _lib.check(rc, "layernorm_fwd")
     return y
 
@@ -207,3 +210,114 @@ def cross_entropy_rows(logits, labels, want_grad=False, grad_scale: float = 1.0)
                                              ld, float(grad_scale), _stream())
     _lib.check(rc, "cross_entropy_rows")
     return (loss, dl) if want_grad else loss
+
+
+# ------------------------------------------------------------------------------------------------ SAM2-side kernels
+def im2col(img, ks: int, stride: int, pad: int):
+    """NCHW bf16 images -> [F*Ho*Wo, ld] patch rows, columns (c, kh, kw), ld = C*ks*ks rounded up to 8."""
+    _need_cuda(img)
+    assert img.dtype == torch.bfloat16 and img.dim() == 4 and img.is_contiguous()
+    F, C, H, W = img.shape
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    ld = (C * ks * ks + 7) // 8 * 8
+    out = torch.empty((F * Ho * Wo, ld), dtype=torch.bfloat16, device=img.device)
+    _lib.check(_lib.load().rga3_im2col(img.data_ptr(), out.data_ptr(), F, C, H, W, ks, stride, pad, ld, _stream()), "im2col")
+    return out, (Ho, Wo)
+
+
+def maxpool2x2_win(x, nwin: int, w: int):
+    """x [nwin*w*w, C] window-major tokens (row stride free) -> [nwin*(w/2)^2, C]."""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] == nwin * w * w
+    C = x.shape[1]
+    y = torch.empty((nwin * (w // 2) ** 2, C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().rga3_maxpool2x2_win(x.data_ptr(), y.data_ptr(), nwin, w, C, x.stride(0), C, _stream()), "maxpool2x2_win")
+    return y
+
+
+def upsample2x_add(a, b, F: int, H: int, W: int):
+    """a [F*H*W, C] + nearest-x2(b [F*(H/2)*(W/2), C]) (raster token order)."""
+    _need_cuda(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype == torch.bfloat16
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().rga3_upsample2x_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), F, H, W, a.shape[1], _stream()), "upsample2x_add")
+    return out
+
+
+def add_bcast(a, b, alpha: float = 1.0):
+    """a [rows, C] + alpha * b[rows_b, C] with b broadcast (row r uses b[r % rows_b])."""
+    _need_cuda(a, b)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1]
+    assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] % b.shape[0] == 0
+    out = torch.empty((a.shape[0], a.shape[1]), dtype=torch.bfloat16, device=a.device)
+    rc = _lib.load().rga3_add_bcast(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], b.shape[0], a.shape[1], a.stride(0), b.stride(0),
+                                    out.stride(0), float(alpha), _stream())
+    _lib.check(rc, "add_bcast")
+    return out
+
+
+def bilinear(x, size, plane_idx=None):
+    """F.interpolate(bilinear, align_corners=False) on planes x [N, Hi, Wi] (f32 / bf16) -> f32 [N_out, Ho, Wo]."""
+    _need_cuda(x, plane_idx)
+    assert x.dim() == 3 and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+    n_out = x.shape[0] if plane_idx is None else plane_idx.numel()
+    if plane_idx is not None:
+        assert plane_idx.dtype == torch.int32
+    out = torch.empty((n_out, size[0], size[1]), dtype=torch.float32, device=x.device)
+    rc = _lib.load().rga3_bilinear(x.data_ptr(), BF16 if x.dtype == torch.bfloat16 else F32, out.data_ptr(), _ptr(plane_idx), n_out, x.shape[1],
+                                   x.shape[2], size[0], size[1], _stream())
+    _lib.check(rc, "bilinear")
+    return out
+
+
+def conv3x3s2(x, weight, bias, F: int, H: int, W: int, sig_scale: float = 0.0, sig_bias: float = 0.0):
+    """token-major x [F*H*W, Cin] (bf16, or f32 single plane with the sigmoid affine) -> [F*(H/2)*(W/2), Cout]."""
+    _need_cuda(x, weight, bias)
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    assert weight.dtype == torch.bfloat16 and weight.is_contiguous() and x.is_contiguous() and x.numel() == F * H * W * Cin
+    y = torch.empty((F * (H // 2) * (W // 2), Cout), dtype=torch.bfloat16, device=x.device)
+    rc = _lib.load().rga3_conv3x3s2(x.data_ptr(), F32 if x.dtype == torch.float32 else BF16, weight.data_ptr(), _ptr(bias), y.data_ptr(), F, H, W,
+                                    Cin, Cout, float(sig_scale), float(sig_bias), _stream())
+    _lib.check(rc, "conv3x3s2")
+    return y
+
+
+def dwconv7x7(x, weight, bias, F: int, H: int, W: int):
+    _need_cuda(x, weight, bias)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().rga3_dwconv7x7(x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), F, H, W, x.shape[1], _stream()), "dwconv7x7")
+    return y
+
+
+def rope_axial_(x, cos, sin, n_rope: int):
+    """In-place axial complex RoPE on x [T, C] (row stride free); rows t < n_rope use table row t % nq; cos/sin [nq, C/2] f32."""
+    _need_cuda(x, cos, sin)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+    assert cos.shape[1] * 2 == x.shape[1]
+    _lib.check(_lib.load().rga3_rope_axial_inplace(x.data_ptr(), cos.data_ptr(), sin.data_ptr(), int(n_rope), cos.shape[0], x.shape[1], x.stride(0),
+                                                  _stream()), "rope_axial")
+    return x
+
+
+def pixel_shuffle2x(g, bias, add, F: int, H: int, W: int, act: str = "none"):
+    """g [F*H*W, 4*Co] -> [F*2H*2W, Co] (+bias, +add, then optional GELU)."""
+    _need_cuda(g, bias, add)
+    Co = g.shape[1] // 4
+    assert g.dtype == torch.bfloat16 and g.is_contiguous()
+    out = torch.empty((F * 4 * H * W, Co), dtype=torch.bfloat16, device=g.device)
+    _lib.check(_lib.load().rga3_pixel_shuffle2x(g.data_ptr(), _ptr(bias), _ptr(add), out.data_ptr(), F, H, W, Co, 1 if act == "gelu" else 0, _stream()),
+               "pixel_shuffle2x")
+    return out
+
+
+def bce_dice_sums(logits, targets):
+    """logits/targets f32 [n, H, W] -> f32 [n, 4] = {sum bce, sum sig*t, sum sig, sum t}."""
+    _need_cuda(logits, targets)
+    assert logits.dtype == targets.dtype == torch.float32 and logits.is_contiguous() and targets.is_contiguous() and logits.shape == targets.shape
+    n = logits.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=logits.device)
+    if n == 0:
+        return out
+    _lib.check(_lib.load().rga3_bce_dice_sums(logits.data_ptr(), targets.data_ptr(), out.data_ptr(), n, logits[0].numel(), _stream()), "bce_dice_sums")
+    return out

@@ -1,0 +1,849 @@
+"""SAM2 (Hiera + FPN image encoder, prompt encoder, two-way mask decoder, memory encoder / attention, video session)
+on the rga3 HIP kernels — the build's own counterpart of reference model/sam2.py.
+
+Public surface kept from the reference wrapper (model/sam2.py:87-446): ``SAM2(ckpt_path)`` with
+``get_sam2_embeddings_train``, ``inject_language_embd_train``, ``get_sam2_embeddings``, ``language_embd_inference``
+and a ``sam2_model`` attribute whose parameter names equal the reference's state dict, so
+SAM2 checkpoints load and the trainer's substring selection (``sam_mask_decoder``, ``q_proj``, ``v_proj``) works.
+
+MI355X-first design differences (outputs proven equal on fixtures, tests/test_sam2_gpu.py):
+  * feature maps are token-major [pixels, C] end to end: every 1x1 conv / linear is the MFMA GEMM, LayerNorm2d is the
+    row LayerNorm kernel, no NCHW<->NHWC permutes;
+  * Hiera tokens live in window-major order for the stage's window size, so windowed attention is the varlen
+    attention kernel on contiguous segments (no window_partition / unpartition copies); q-pooling is a max-pool kernel
+    reading the Q slice of the fused QKV buffer through strides; layout changes (3 per image) are row gathers;
+  * the best-IoU candidate is selected BEFORE the x4 bilinear upsample (reference upsamples all 3: sam2.py:3388-3402);
+  * in the video session the image encoder runs once per frame (reference: twice, sam2.py:3539 one-entry cache).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..hip import ops
+from .qwen2_5_vl import Linear
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+class ConvParams(nn.Module):
+    """Holds a conv's weight/bias under the reference's names; the arithmetic runs in the HIP kernels."""
+
+    def __init__(self, cout, cin, kh, kw, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, kh, kw))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def as_linear(self):
+        return self.weight.reshape(self.weight.shape[0], -1)
+
+
+class NormParams(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+    def forward(self, x2d, act="none"):
+        return ops.layernorm(x2d, self.weight, self.bias, self.eps, act=act)
+
+
+class MLP(nn.Module):
+    """reference sam2.py:2305-2329"""
+
+    def __init__(self, i, h, o, n, sigmoid_output=False, act="relu"):
+        super().__init__()
+        hs = [h] * (n - 1)
+        self.layers = nn.ModuleList(Linear(a, b) for a, b in zip([i] + hs, hs + [o]))
+        self.num_layers, self.sigmoid_output, self.act = n, sigmoid_output, act
+
+    def forward(self, x, residual=None):
+        for i, l in enumerate(self.layers):
+            last = i == self.num_layers - 1
+            x = l(x, act="none" if last else self.act, residual=residual if last else None)
+        return torch.sigmoid(x.float()).to(x.dtype) if self.sigmoid_output else x
+
+
+# ------------------------------------------------------------------------------------------------ layouts
+_PERM_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _layout_order(H, W, w):
+    """raster index of each position of the window-major(w) layout (w == 0: raster)."""
+    if w == 0:
+        return np.arange(H * W)
+    idx = np.arange(H * W).reshape(H // w, w, W // w, w).transpose(0, 2, 1, 3).reshape(-1)
+    return idx
+
+
+def relayout(x, F, H, W, w_from, w_to):
+    """Reorder token rows of x [F*H*W, C] between window-major layouts (row gather with a cached permutation)."""
+    if w_from == w_to:
+        return x
+    key = (F, H, W, w_from, w_to, str(x.device))
+    if key not in _PERM_CACHE:
+        a, b = _layout_order(H, W, w_from), _layout_order(H, W, w_to)
+        inv_a = np.empty_like(a)
+        inv_a[a] = np.arange(a.size)
+        p = inv_a[b]
+        full = (p[None, :] + (np.arange(F) * H * W)[:, None]).reshape(-1)
+        _PERM_CACHE[key] = torch.from_numpy(full.astype(np.int64)).to(x.device)
+    return ops.gather_rows(x, _PERM_CACHE[key])
+
+
+_CU_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _cu(nseg, seglen, device):
+    key = (nseg, seglen, str(device))
+    if key not in _CU_CACHE:
+        _CU_CACHE[key] = (torch.arange(nseg + 1, dtype=torch.int64) * seglen).to(torch.int32).to(device)
+    return _CU_CACHE[key]
+
+
+# ------------------------------------------------------------------------------------------------ Hiera trunk
+class PatchEmbed(nn.Module):
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.proj = ConvParams(embed_dim, 3, 7, 7)
+
+
+class MultiScaleAttention(nn.Module):
+    def __init__(self, dim, dim_out, heads):
+        super().__init__()
+        self.qkv = Linear(dim, dim_out * 3)
+        self.proj = Linear(dim_out, dim_out)
+        self.num_heads = heads
+
+
+class MultiScaleBlock(nn.Module):
+    """reference sam2.py:1035-1117 on window-major tokens."""
+
+    def __init__(self, dim, dim_out, heads, window, pool):
+        super().__init__()
+        self.dim, self.dim_out, self.window, self.pool_q = dim, dim_out, window, pool
+        self.norm1 = NormParams(dim, 1e-6)
+        self.attn = MultiScaleAttention(dim, dim_out, heads)
+        self.norm2 = NormParams(dim_out, 1e-6)
+        self.mlp = MLP(dim_out, dim_out * 4, dim_out, 2, act="gelu")
+        if dim != dim_out:
+            self.proj = Linear(dim, dim_out)
+
+    def forward(self, x, Fn, H, W, layout_w):
+        """x [Fn*H*W, dim] in window-major(layout_w) order. Returns (x, H, W, layout_w)."""
+        ws = self.window
+        if ws > 0 and (H % ws or W % ws):
+            raise NotImplementedError("Hiera window padding (map not divisible by the window) is not on the RGA3 path (images are 1024x1024)")
+        if ws > 0:
+            x = relayout(x, Fn, H, W, layout_w, ws)
+            layout_w = ws
+        heads, do = self.attn.num_heads, self.dim_out
+        h = self.norm1(x)
+        T = H * W
+        nwin = Fn * (T // (ws * ws)) if ws > 0 else Fn
+        seg = ws * ws if ws > 0 else T
+        shortcut = x
+        if self.dim != self.dim_out:
+            shortcut = self.proj(h)
+        if self.pool_q:
+            if ws == 0:
+                raise NotImplementedError("q-pooling inside a global-attention block does not occur in Hiera configs used by SAM2")
+            if self.dim != self.dim_out:
+                shortcut = ops.maxpool2x2_win(shortcut, nwin, ws)
+        qkv = self.attn.qkv(h)                                  # [N, 3*do]
+        q = qkv[:, :do]
+        seg_q = seg
+        if self.pool_q:
+            q = ops.maxpool2x2_win(q, nwin, ws)                 # strided read of the Q slice
+            seg_q = seg // 4
+        hd = do // heads
+        qv = q.view(q.shape[0], heads, hd) if q.is_contiguous() else q.unflatten(1, (heads, hd))
+        kv = qkv.view(qkv.shape[0], 3 * heads, hd)
+        att = ops.attn_varlen(qv, kv[:, heads:2 * heads], kv[:, 2 * heads:], _cu(nwin, seg_q, x.device), _cu(nwin, seg, x.device), seg_q,
+                              hd ** -0.5, causal=False)
+        x = self.attn.proj(att.view(att.shape[0], do), residual=shortcut)
+        if self.pool_q:
+            H, W, layout_w = H // 2, W // 2, ws // 2
+        x = self.mlp(self.norm2(x), residual=x)
+        return x, H, W, layout_w
+
+
+class Hiera(nn.Module):
+    def __init__(self, embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8),
+                 window_pos_embed_bkg_spatial_size=(7, 7), q_pool=3):
+        super().__init__()
+        depth = sum(stages)
+        self.stage_ends = [sum(stages[:i]) - 1 for i in range(1, len(stages) + 1)]
+        self.q_pool_blocks = [x + 1 for x in self.stage_ends[:-1]][:q_pool]
+        self.patch_embed = PatchEmbed(embed_dim)
+        self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, *window_pos_embed_bkg_spatial_size))
+        self.pos_embed_window = nn.Parameter(torch.zeros(1, embed_dim, window_spec[0], window_spec[0]))
+        self.blocks = nn.ModuleList()
+        cur_stage, dim, heads = 1, embed_dim, num_heads
+        for i in range(depth):  # construction rule of reference sam2.py:1182-1210 (window lags the stage change by one block)
+            dim_out = dim
+            window = window_spec[cur_stage - 1]
+            if i in global_att_blocks:
+                window = 0
+            if i - 1 in self.stage_ends:
+                dim_out, heads = dim * 2, heads * 2
+                cur_stage += 1
+            self.blocks.append(MultiScaleBlock(dim, dim_out, heads, window, i in self.q_pool_blocks))
+            dim = dim_out
+        self.channel_list = [self.blocks[i].dim_out for i in self.stage_ends[::-1]]
+        self._pos_cache = {}
+
+    def pos_tokens(self, h, w):
+        """bicubic-interpolated background pos-embed + tiled window embed as raster tokens [h*w, C] (sam2.py:1218-1226)."""
+        key = (h, w, self.pos_embed._version, self.pos_embed.device)
+        if key not in self._pos_cache:
+            with torch.no_grad():
+                pe = F.interpolate(self.pos_embed.float(), size=(h, w), mode="bicubic")
+                we = self.pos_embed_window.float()
+                pe = pe + we.tile([a // b for a, b in zip(pe.shape, we.shape)])
+                self._pos_cache = {key: pe[0].permute(1, 2, 0).reshape(h * w, -1).to(self.pos_embed.dtype).contiguous()}
+        return self._pos_cache[key]
+
+    def forward(self, img):
+        """img [Fn, 3, S, S] bf16 -> list of (tokens [Fn*H*W, C] raster order, H, W) per stage (high-res first)."""
+        Fn = img.shape[0]
+        cols, (H, W) = ops.im2col(img.contiguous(), 7, 4, 3)
+        wp = self.patch_embed.proj.as_linear()
+        if wp.shape[1] != cols.shape[1]:
+            wp = ops.pad_cols(wp.contiguous(), cols.shape[1])
+        x = ops.gemm(cols, wp, self.patch_embed.proj.bias)
+        x = ops.add_bcast(x, self.pos_tokens(H, W))
+        layout = 0
+        outs = []
+        for i, blk in enumerate(self.blocks):
+            x, H, W, layout = blk(x, Fn, H, W, layout)
+            if i in self.stage_ends:
+                outs.append((x, H, W, layout))
+        return outs
+
+
+# ------------------------------------------------------------------------------------------------ position encodings
+def position_embedding_sine(num_pos_feats, h, w, device, temperature=10000.0):
+    """reference sam2.py:1781-1814 (normalize=True, scale=2*pi) -> raster tokens [h*w, num_pos_feats] f32 (host math, cached by callers)."""
+    npf = num_pos_feats // 2
+    y = torch.arange(1, h + 1, dtype=torch.float32).view(-1, 1).repeat(1, w)
+    x = torch.arange(1, w + 1, dtype=torch.float32).view(1, -1).repeat(h, 1)
+    y = y / (y[-1:, :] + 1e-6) * (2 * math.pi)
+    x = x / (x[:, -1:] + 1e-6) * (2 * math.pi)
+    dim_t = temperature ** (2 * (torch.arange(npf, dtype=torch.float32) // 2) / npf)
+    px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2).reshape(h * w, -1).to(device)
+
+
+class FpnNeck(nn.Module):
+    def __init__(self, d_model, backbone_channel_list, fpn_top_down_levels=(2, 3)):
+        super().__init__()
+        self.d_model = d_model
+        self.backbone_channel_list = list(backbone_channel_list)
+        self.convs = nn.ModuleList()
+        for c in backbone_channel_list:
+            seq = nn.Sequential()
+            seq.add_module("conv", ConvParams(d_model, c, 1, 1))
+            self.convs.append(seq)
+        self.fpn_top_down_levels = list(fpn_top_down_levels)
+        self._pos = {}
+
+    def pos(self, h, w, device, dtype):
+        key = (h, w, str(device), dtype)
+        if key not in self._pos:
+            self._pos[key] = position_embedding_sine(self.d_model, h, w, device).to(dtype)
+        return self._pos[key]
+
+    def forward(self, stages, Fn):
+        """stages: trunk outputs (high-res first). Returns raster-token maps per level [(tokens, H, W)], high-res first."""
+        n = len(self.convs) - 1
+        out = [None] * len(stages)
+        prev = None
+        for i in range(n, -1, -1):
+            x, H, W, layout = stages[i]
+            conv = self.convs[n - i].conv
+            lat = ops.gemm(x, conv.as_linear(), conv.bias)
+            lat = relayout(lat, Fn, H, W, layout, 0)
+            if i in self.fpn_top_down_levels and prev is not None:
+                prev = ops.upsample2x_add(lat, prev, Fn, H, W)
+            else:
+                prev = lat
+            out[i] = (prev, H, W)
+        return out
+
+
+class ImageEncoder(nn.Module):
+    def __init__(self, trunk, neck, scalp=1):
+        super().__init__()
+        self.trunk, self.neck, self.scalp = trunk, neck, scalp
+
+
+# ------------------------------------------------------------------------------------------------ SAM heads
+class Attention(nn.Module):
+    """reference sam2.py:1417-1481 (projections as GEMMs, softmax(QK^T)V as the varlen kernel, batch = segments)."""
+
+    def __init__(self, embedding_dim, num_heads, downsample_rate=1, kv_in_dim=None):
+        super().__init__()
+        self.internal_dim = embedding_dim // downsample_rate
+        self.num_heads = num_heads
+        kv = kv_in_dim if kv_in_dim is not None else embedding_dim
+        self.q_proj = Linear(embedding_dim, self.internal_dim)
+        self.k_proj = Linear(kv, self.internal_dim)
+        self.v_proj = Linear(kv, self.internal_dim)
+        self.out_proj = Linear(self.internal_dim, embedding_dim)
+
+    def forward(self, q, k, v, B, nq, nk, residual=None):
+        """q [B*nq, C], k/v [B*nk, Ckv] -> out_proj(attn) (+ residual) [B*nq, C]."""
+        H, hd = self.num_heads, self.internal_dim // self.num_heads
+        qp, kp, vp = self.q_proj(q), self.k_proj(k), self.v_proj(v)
+        o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5)
+        return self.out_proj(o.view(-1, self.internal_dim), residual=residual)
+
+
+class TwoWayAttentionBlock(nn.Module):
+    def __init__(self, dim, heads, mlp_dim, skip_first_layer_pe):
+        super().__init__()
+        self.self_attn = Attention(dim, heads)
+        self.norm1 = NormParams(dim, 1e-5)
+        self.cross_attn_token_to_image = Attention(dim, heads, downsample_rate=2)
+        self.norm2 = NormParams(dim, 1e-5)
+        self.mlp = MLP(dim, mlp_dim, dim, 2)
+        self.norm3 = NormParams(dim, 1e-5)
+        self.norm4 = NormParams(dim, 1e-5)
+        self.cross_attn_image_to_token = Attention(dim, heads, downsample_rate=2)
+        self.skip_first_layer_pe = skip_first_layer_pe
+
+    def forward(self, queries, keys, query_pe, key_pe, B, nq, nk):
+        if self.skip_first_layer_pe:
+            queries = self.self_attn(queries, queries, queries, B, nq, nq)
+        else:
+            q = ops.add(queries, query_pe)
+            queries = self.self_attn(q, q, queries, B, nq, nq, residual=queries)
+        queries = self.norm1(queries)
+        q = ops.add(queries, query_pe)
+        k = ops.add_bcast(keys, key_pe)
+        queries = self.norm2(self.cross_attn_token_to_image(q, k, keys, B, nq, nk, residual=queries))
+        queries = self.norm3(self.mlp(queries, residual=queries))
+        q = ops.add(queries, query_pe)
+        keys = self.norm4(self.cross_attn_image_to_token(k, q, queries, B, nk, nq, residual=keys))
+        return queries, keys
+
+
+class TwoWayTransformer(nn.Module):
+    def __init__(self, depth, dim, heads, mlp_dim):
+        super().__init__()
+        self.layers = nn.ModuleList(TwoWayAttentionBlock(dim, heads, mlp_dim, i == 0) for i in range(depth))
+        self.final_attn_token_to_image = Attention(dim, heads, downsample_rate=2)
+        self.norm_final_attn = NormParams(dim, 1e-5)
+
+    def forward(self, keys, key_pe, tokens, B, nq, nk):
+        queries, query_pe = tokens, tokens
+        for layer in self.layers:
+            queries, keys = layer(queries, keys, query_pe, key_pe, B, nq, nk)
+        q = ops.add(queries, query_pe)
+        k = ops.add_bcast(keys, key_pe)
+        queries = self.norm_final_attn(self.final_attn_token_to_image(q, k, keys, B, nq, nk, residual=queries))
+        return queries, keys
+
+
+class ConvTParams(nn.Module):
+    """ConvTranspose2d(k=2, s=2) parameters [Cin, Cout, 2, 2]; as_linear() gives the GEMM weight [(dy,dx,co), ci]."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cin, cout, 2, 2))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        self._pk = None
+
+    def as_linear(self):
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.dtype)
+        if self._pk is None or self._pk[0] != key:
+            self._pk = (key, self.weight.detach().permute(2, 3, 1, 0).reshape(-1, self.weight.shape[0]).contiguous())
+        return self._pk[1]
+
+
+class MaskDecoder(nn.Module):
+    """reference sam2.py:1926-2160 with pred_obj_scores(+mlp), high-res features, multimask tokens for the object pointer."""
+
+    def __init__(self, dim, depth=2, heads=8, mlp_dim=2048, iou_head_hidden_dim=256):
+        super().__init__()
+        self.transformer_dim = dim
+        self.transformer = TwoWayTransformer(depth, dim, heads, mlp_dim)
+        self.iou_token = nn.Embedding(1, dim)
+        self.num_mask_tokens = 4
+        self.mask_tokens = nn.Embedding(4, dim)
+        self.obj_score_token = nn.Embedding(1, dim)
+        self.output_upscaling = nn.Sequential(ConvTParams(dim, dim // 4), NormParams(dim // 4, 1e-6), nn.GELU(), ConvTParams(dim // 4, dim // 8), nn.GELU())
+        self.conv_s0 = ConvParams(dim // 8, dim, 1, 1)
+        self.conv_s1 = ConvParams(dim // 4, dim, 1, 1)
+        self.output_hypernetworks_mlps = nn.ModuleList(MLP(dim, dim, dim // 8, 3) for _ in range(4))
+        self.iou_prediction_head = MLP(dim, iou_head_hidden_dim, 4, 3, sigmoid_output=True)
+        self.pred_obj_score_head = MLP(dim, dim, 1, 3)
+
+    def forward(self, pix_tokens, pos_tokens, sparse, feat_s0, feat_s1, B, h, w):
+        """pix_tokens [B*h*w, C] (already + dense prompt), pos_tokens [h*w, C], sparse [B, n, C].
+        Returns masks f32 [B, 4, 4h, 4w], iou [B, 4], mask tokens [B, 4, C], object score logits [B, 1]."""
+        C = self.transformer_dim
+        out_tokens = torch.cat([self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight], dim=0)
+        tokens = torch.cat([out_tokens[None].expand(B, -1, -1), sparse.to(out_tokens.dtype)], dim=1).contiguous()
+        nq = tokens.shape[1]
+        hs, src = self.transformer(pix_tokens, pos_tokens, tokens.view(B * nq, C), B, nq, h * w)
+        hs = hs.view(B, nq, C)
+        iou_tok, mask_toks = hs[:, 1], hs[:, 2:6]
+        dc1, ln1, _, dc2, _ = self.output_upscaling
+        g1 = ops.gemm(src, dc1.as_linear())
+        up = ops.pixel_shuffle2x(g1, dc1.bias, feat_s1, B, h, w)
+        up = ln1(up, act="gelu")
+        g2 = ops.gemm(up, dc2.as_linear())
+        up = ops.pixel_shuffle2x(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w, act="gelu")          # [B*16hw, C/8]
+        hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)  # [B, 4, C/8]
+        npx = 16 * h * w
+        masks = torch.empty((B, 4, 4 * h, 4 * w), dtype=torch.float32, device=src.device)
+        for b in range(B):  # masks[b] = hyper[b] @ up[b]^T : planes come out row-major, f32
+            ops.gemm(hyper[b].contiguous(), up[b * npx:(b + 1) * npx], out_dtype=torch.float32, out=masks[b].view(4, npx))
+        iou = self.iou_prediction_head(iou_tok.contiguous())
+        obj = self.pred_obj_score_head(hs[:, 0].contiguous())
+        return masks, iou, mask_toks, obj
+
+
+class PositionEmbeddingRandom(nn.Module):
+    def __init__(self, num_pos_feats):
+        super().__init__()
+        self.register_buffer("positional_encoding_gaussian_matrix", torch.randn(2, num_pos_feats))
+
+    def dense_tokens(self, h, w):
+        """reference sam2.py:1832-1856 -> raster tokens [h*w, 2F] f32"""
+        G = self.positional_encoding_gaussian_matrix.float()
+        grid = torch.ones((h, w), dtype=torch.float32, device=G.device)
+        y, x = (grid.cumsum(0) - 0.5) / h, (grid.cumsum(1) - 0.5) / w
+        c = 2 * math.pi * ((2 * torch.stack([x, y], dim=-1) - 1) @ G)
+        return torch.cat([torch.sin(c), torch.cos(c)], dim=-1).reshape(h * w, -1)
+
+
+class PromptEncoder(nn.Module):
+    def __init__(self, embed_dim, image_embedding_size, input_image_size, mask_in_chans=16):
+        super().__init__()
+        self.embed_dim, self.image_embedding_size, self.input_image_size = embed_dim, image_embedding_size, input_image_size
+        self.pe_layer = PositionEmbeddingRandom(embed_dim // 2)
+        self.point_embeddings = nn.ModuleList(nn.Embedding(1, embed_dim) for _ in range(4))
+        self.not_a_point_embed = nn.Embedding(1, embed_dim)
+        self.mask_downscaling = nn.Sequential(ConvParams(mask_in_chans // 4, 1, 2, 2), NormParams(mask_in_chans // 4, 1e-6), nn.GELU(),
+                                              ConvParams(mask_in_chans, mask_in_chans // 4, 2, 2), NormParams(mask_in_chans, 1e-6), nn.GELU(),
+                                              ConvParams(embed_dim, mask_in_chans, 1, 1))
+        self.no_mask_embed = nn.Embedding(1, embed_dim)
+        self._pe = None
+
+    def dense_pe_tokens(self, dtype):
+        key = (self.pe_layer.positional_encoding_gaussian_matrix.data_ptr(), dtype)
+        if self._pe is None or self._pe[0] != key:
+            self._pe = (key, self.pe_layer.dense_tokens(*self.image_embedding_size).to(dtype).contiguous())
+        return self._pe[1]
+
+
+# ------------------------------------------------------------------------------------------------ memory
+class RoPEAttention(Attention):
+    """reference sam2.py:1484-1548: 1 head, axial complex RoPE on q and the first (Nk - exclude) keys (table tiled)."""
+
+    def __init__(self, *a, rope_theta=10000.0, rope_k_repeat=False, feat_sizes=(32, 32), **k):
+        super().__init__(*a, **k)
+        self.rope_theta, self.rope_k_repeat = rope_theta, rope_k_repeat
+        self._tab = {}
+
+    def table(self, nq, device):
+        key = (nq, str(device))
+        if key not in self._tab:
+            dim = self.internal_dim // self.num_heads
+            side = int(math.sqrt(nq))
+            fr = 1.0 / (self.rope_theta ** (torch.arange(0, dim, 4)[: dim // 4].float() / dim))
+            t = torch.arange(side * side, dtype=torch.float32)
+            ang = torch.cat([torch.outer(t % side, fr), torch.outer(torch.div(t, side, rounding_mode="floor"), fr)], dim=-1)
+            self._tab[key] = (ang.cos().contiguous().to(device), ang.sin().contiguous().to(device))
+        return self._tab[key]
+
+    def forward(self, q, k, v, nq, nk, num_k_exclude_rope=0, residual=None):
+        """single sequence: q [nq, C], k/v [nk, Ckv]."""
+        assert self.num_heads == 1
+        qp, kp, vp = self.q_proj(q), self.k_proj(k), self.v_proj(v)
+        cos, sin = self.table(nq, q.device)
+        ops.rope_axial_(qp, cos, sin, nq)
+        ops.rope_axial_(kp, cos, sin, nk - num_k_exclude_rope)
+        D = self.internal_dim
+        o = ops.attn_varlen(qp.view(nq, 1, D), kp.view(nk, 1, D), vp.view(nk, 1, D), _cu(1, nq, q.device), _cu(1, nk, q.device), nq, D ** -0.5)
+        return self.out_proj(o.view(nq, D), residual=residual)
+
+
+class MemoryAttentionLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward, kv_in_dim):
+        super().__init__()
+        self.self_attn = RoPEAttention(d_model, 1)
+        self.cross_attn_image = RoPEAttention(d_model, 1, rope_k_repeat=True, kv_in_dim=kv_in_dim)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = NormParams(d_model, 1e-5), NormParams(d_model, 1e-5), NormParams(d_model, 1e-5)
+
+    def forward(self, x, mem_k, mem_v, nq, nk, n_excl):
+        t = self.norm1(x)
+        x = self.self_attn(t, t, t, nq, nq, residual=x)
+        t = self.norm2(x)
+        x = self.cross_attn_image(t, mem_k, mem_v, nq, nk, num_k_exclude_rope=n_excl, residual=x)
+        t = self.norm3(x)
+        return self.linear2(self.linear1(t, act="relu"), residual=x)
+
+
+class MemoryAttention(nn.Module):
+    """reference sam2.py:533-600 (single object / single sequence per call; dropout inactive in eval)."""
+
+    def __init__(self, d_model, num_layers, dim_feedforward, kv_in_dim):
+        super().__init__()
+        self.d_model = d_model
+        self.layers = nn.ModuleList(MemoryAttentionLayer(d_model, dim_feedforward, kv_in_dim) for _ in range(num_layers))
+        self.norm = NormParams(d_model, 1e-5)
+
+    def forward(self, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens):
+        nq, nk = curr.shape[0], memory.shape[0]
+        x = ops.add_bcast(curr, curr_pos, alpha=0.1)
+        mem_k = ops.add(memory, memory_pos)
+        for layer in self.layers:
+            x = layer(x, mem_k, memory, nq, nk, num_obj_ptr_tokens)
+        return self.norm(x)
+
+
+class CXBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dwconv = ConvParams(dim, 1, 7, 7)
+        self.norm = NormParams(dim, 1e-6)
+        self.pwconv1 = Linear(dim, 4 * dim)
+        self.pwconv2 = Linear(4 * dim, dim)
+        self.g_weight = nn.Parameter(1e-6 * torch.ones(dim))
+
+    def forward(self, x, Fn, H, W):
+        z = ops.dwconv7x7(x, self.dwconv.weight, self.dwconv.bias, Fn, H, W)
+        z = self.norm(z)
+        z = self.pwconv1(z, act="gelu")
+        return ops.gemm(z, self.pwconv2.weight, self.pwconv2.bias, residual=x, colscale=self.g_weight)
+
+
+class Fuser(nn.Module):
+    def __init__(self, dim, num_layers):
+        super().__init__()
+        self.proj = nn.Identity()
+        self.layers = nn.ModuleList(CXBlock(dim) for _ in range(num_layers))
+
+
+class MaskDownSampler(nn.Module):
+    def __init__(self, embed_dim, total_stride=16):
+        super().__init__()
+        n = int(math.log2(total_stride))
+        self.encoder = nn.Sequential()
+        cin = 1
+        for _ in range(n):
+            cout = cin * 4
+            self.encoder.append(ConvParams(cout, cin, 3, 3))
+            self.encoder.append(NormParams(cout, 1e-6))
+            self.encoder.append(nn.GELU())
+            cin = cout
+        self.encoder.append(ConvParams(embed_dim, cin, 1, 1))
+        self.n_down = n
+
+
+class MemoryEncoder(nn.Module):
+    """reference sam2.py:724-767"""
+
+    def __init__(self, out_dim, in_dim, fuser_layers=2, total_stride=16):
+        super().__init__()
+        self.mask_downsampler = MaskDownSampler(in_dim, total_stride)
+        self.pix_feat_proj = ConvParams(in_dim, in_dim, 1, 1)
+        self.fuser = Fuser(in_dim, fuser_layers)
+        self.out_proj = ConvParams(out_dim, in_dim, 1, 1)
+        self.out_dim = out_dim
+        self._pos = {}
+
+    def forward(self, pix_tokens, mask_f32, Fn, S, sig_scale, sig_bias):
+        """pix_tokens [Fn*h*w, C] raster; mask_f32 [Fn, S, S] raw high-res logits (sigmoid*scale+bias fused into the first conv)."""
+        enc = self.mask_downsampler.encoder
+        x, H = mask_f32.contiguous(), S
+        for i in range(self.mask_downsampler.n_down):
+            conv, norm = enc[3 * i], enc[3 * i + 1]
+            if i == 0:
+                x = ops.conv3x3s2(x, conv.weight, conv.bias, Fn, H, H, sig_scale, sig_bias)
+            else:
+                x = ops.conv3x3s2(x, conv.weight, conv.bias, Fn, H, H)
+            H //= 2
+            if x.shape[1] % 8 == 0:
+                x = norm(x, act="gelu")
+            else:  # 4-channel stage: LayerNorm2d + GELU over 4 values per pixel (row kernel needs dim % 8 == 0)
+                xf = x.float()
+                u = xf.mean(1, keepdim=True)
+                s = (xf - u).pow(2).mean(1, keepdim=True)
+                xf = (xf - u) / torch.sqrt(s + norm.eps) * norm.weight.float() + norm.bias.float()
+                x = F.gelu(xf.to(x.dtype).float()).to(x.dtype)
+        last = enc[3 * self.mask_downsampler.n_down]
+        m = ops.gemm(x, last.as_linear(), last.bias)
+        y = ops.gemm(pix_tokens, self.pix_feat_proj.as_linear(), self.pix_feat_proj.bias, residual=m)
+        for layer in self.fuser.layers:
+            y = layer(y, Fn, H, H)
+        y = ops.gemm(y, self.out_proj.as_linear(), self.out_proj.bias)
+        key = (H, str(y.device))
+        if key not in self._pos:
+            self._pos[key] = position_embedding_sine(self.out_dim, H, H, y.device).to(y.dtype)
+        return y, self._pos[key]
+
+
+# ------------------------------------------------------------------------------------------------ the model
+class SAM2VideoPredictor(nn.Module):
+    """Parameter container + frame-level arithmetic of reference SAM2Base / SAM2VideoPredictor (sam2.py:2348-4132)
+    with the hyper-parameters the RGA3 wrapper hard-codes (sam2.py:97-136)."""
+
+    def __init__(self, image_size=1024, embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43),
+                 window_spec=(8, 4, 16, 8), pos_bkg=(7, 7), d_model=256, mem_dim=64, num_maskmem=7, memattn_layers=4, memattn_ff=2048,
+                 max_obj_ptrs_in_encoder=16, backbone_stride=16, dec_mlp_dim=2048, iou_head_hidden_dim=256):
+        super().__init__()
+        self.image_size, self.hidden_dim, self.mem_dim, self.num_maskmem = image_size, d_model, mem_dim, num_maskmem
+        self.backbone_stride, self.max_obj_ptrs_in_encoder = backbone_stride, max_obj_ptrs_in_encoder
+        self.sigmoid_scale_for_mem_enc, self.sigmoid_bias_for_mem_enc = 20.0, -10.0
+        trunk = Hiera(embed_dim, num_heads, stages, global_att_blocks, window_spec, pos_bkg)
+        self.image_encoder = ImageEncoder(trunk, FpnNeck(d_model, trunk.channel_list), scalp=1)
+        self.mask_downsample = ConvParams(1, 1, 4, 4)  # present in checkpoints (sam2.py:2434); unused on the language path
+        self.memory_attention = MemoryAttention(d_model, memattn_layers, memattn_ff, mem_dim)
+        self.memory_encoder = MemoryEncoder(mem_dim, d_model)
+        self.maskmem_tpos_enc = nn.Parameter(torch.zeros(num_maskmem, 1, 1, mem_dim))
+        self.no_mem_embed = nn.Parameter(torch.zeros(1, 1, d_model))
+        self.no_mem_pos_enc = nn.Parameter(torch.zeros(1, 1, d_model))
+        self.no_obj_ptr = nn.Parameter(torch.zeros(1, d_model))
+        for p in (self.maskmem_tpos_enc, self.no_mem_embed, self.no_mem_pos_enc, self.no_obj_ptr):
+            nn.init.trunc_normal_(p, std=0.02)
+        s = image_size // backbone_stride
+        self.sam_image_embedding_size = s
+        self.sam_prompt_encoder = PromptEncoder(d_model, (s, s), (image_size, image_size))
+        self.sam_mask_decoder = MaskDecoder(d_model, 2, 8, dec_mlp_dim, iou_head_hidden_dim)
+        self.obj_ptr_proj = MLP(d_model, d_model, d_model, 3)
+
+    @property
+    def device(self):
+        return self.no_mem_embed.device
+
+    @property
+    def dtype(self):
+        return self.no_mem_embed.dtype
+
+    # -- image encoder --------------------------------------------------------------------------------------
+    def forward_image(self, img):
+        """reference sam2.py:2790-2802 (+ FPN, scalp). Returns dict of raster token maps."""
+        Fn = img.shape[0]
+        stages = self.image_encoder.trunk(img.to(self.dtype))
+        lv = self.image_encoder.neck(stages, Fn)[: len(stages) - self.image_encoder.scalp]
+        (f0, H0, W0), (f1, H1, W1), (f2, H2, W2) = lv
+        dec = self.sam_mask_decoder
+        return {"feat_s0": ops.gemm(f0, dec.conv_s0.as_linear(), dec.conv_s0.bias), "feat_s1": ops.gemm(f1, dec.conv_s1.as_linear(), dec.conv_s1.bias),
+                "feat": f2, "hw": (H2, W2), "n": Fn, "pos": self.image_encoder.neck.pos(H2, W2, f2.device, f2.dtype)}
+
+    # -- SAM heads (language path: no clicks, no mask prompt) ---------------------------------------------
+    def forward_sam_heads(self, pix_tokens, feats, language_embd, frame_slice=None):
+        """reference sam2.py:3262-3431. pix_tokens [B*h*w, C] (memory-conditioned or + no_mem_embed)."""
+        h, w = feats["hw"]
+        B = pix_tokens.shape[0] // (h * w)
+        pe = self.sam_prompt_encoder
+        sparse = pe.not_a_point_embed.weight.expand(2, -1)[None].expand(B, -1, -1)
+        if language_embd is not None:
+            sparse = torch.cat([sparse, language_embd.to(sparse.dtype)], dim=1)
+        src = ops.add_bcast(pix_tokens, pe.no_mask_embed.weight)  # dense prompt = no_mask_embed everywhere
+        s0, s1 = feats["feat_s0"], feats["feat_s1"]
+        if frame_slice is not None:
+            a, b = frame_slice
+            s0, s1 = s0[a * 16 * h * w: b * 16 * h * w], s1[a * 4 * h * w: b * 4 * h * w]
+        masks, iou, toks, obj = self.sam_mask_decoder(src, pe.dense_pe_tokens(src.dtype), sparse, s0, s1, B, h, w)
+        ious = iou[:, 1:].float()
+        best = torch.argmax(ious, dim=-1)
+        bi = torch.arange(B, device=best.device)
+        sel = (bi * 4 + 1 + best).to(torch.int32)
+        low = masks.view(B * 4, 4 * h, 4 * w)[sel.long()].unsqueeze(1)                                  # chosen candidate, f32
+        high = ops.bilinear(masks.view(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
+        tok = toks[:, 1:][bi, best]
+        obj_ptr = self.obj_ptr_proj(tok.contiguous())
+        lam = (obj > 0).to(obj_ptr.dtype)
+        obj_ptr = lam * obj_ptr + (1 - lam) * self.no_obj_ptr
+        return {"low_res_multimasks": masks[:, 1:], "ious": ious, "low_res_masks": low, "high_res_masks": high, "obj_ptr": obj_ptr,
+                "object_score_logits": obj, "best_iou_inds": best}
+
+    # -- memory ----------------------------------------------------------------------------------------------
+    def encode_new_memory(self, feats, frame, high_res_masks):
+        """reference sam2.py:2991-3029 for one frame: (maskmem tokens [h*w, mem_dim], pos tokens)."""
+        h, w = feats["hw"]
+        pix = feats["feat"][frame * h * w:(frame + 1) * h * w]
+        return self.memory_encoder(pix, high_res_masks.reshape(1, self.image_size, self.image_size).float(), 1, self.image_size,
+                                   self.sigmoid_scale_for_mem_enc, self.sigmoid_bias_for_mem_enc)
+
+
+class SAM2(nn.Module):
+    """Drop-in for the reference wrapper (model/sam2.py:87-446)."""
+
+    def __init__(self, ckpt_path: str = None, **tiny_overrides):
+        super().__init__()
+        self.sam2_model = SAM2VideoPredictor(**tiny_overrides)
+        self.hidden_dim = self.sam2_model.hidden_dim
+        self.img_mean, self.img_std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+        if ckpt_path is not None:
+            load_sam2_checkpoint(self.sam2_model, ckpt_path)
+
+    # ---- training path: frames independent (reference :412-433, :343-375)
+    def get_sam2_embeddings_train(self, images, expand_size=1):
+        assert expand_size == 1, "num_objs == 1 on the RGA3 path (model/qwen_2_5_vl_sam2.py:263)"
+        return self.sam2_model.forward_image(images)
+
+    def inject_language_embd_train(self, sam_states, language_embd, nf_nobj=None):
+        m = self.sam2_model
+        pix = ops.add_bcast(sam_states["feat"], m.no_mem_embed.view(1, -1))
+        o = m.forward_sam_heads(pix, sam_states, language_embd)
+        return o["low_res_masks"], o["high_res_masks"]
+
+    # ---- inference path (reference :406-410, :378-404)
+    def get_sam2_embeddings(self, images):
+        return VideoSession(self.sam2_model, images)
+
+    get_sam2_embeddings_inference = get_sam2_embeddings
+
+    def language_embd_inference(self, session, language_embd):
+        """Prompt on every frame, then propagate: every frame is an initial conditioning frame, so the masks are the
+        consolidated low-res predictions upsampled to image_size (reference :378-404, :3749-3769). [T, n_obj, S, S] f32."""
+        T = len(language_embd)
+        n_obj = len(language_embd[0])
+        outs = []
+        for o in range(n_obj):
+            sess = session if o == 0 else VideoSession(self.sam2_model, session.images, feats=session.feats)
+            for t in range(T):
+                sess.add_language_embd(t, language_embd[t][o].reshape(1, 1, -1))
+            outs.append(torch.cat([mk for _, mk in sess.propagate()], dim=0))
+        return torch.cat(outs, dim=1)
+
+    def forward(self, batch):
+        raise NotImplementedError
+
+
+class VideoSession:
+    """Single-object video state (reference SAM2VideoPredictor.init_state / add_language_embd / propagate_in_video,
+    sam2.py:3771-4132).  Image features are computed once per frame and kept; the memory encoder runs only for frames
+    whose memory can be read by a later frame."""
+
+    def __init__(self, model: SAM2VideoPredictor, images, feats=None, chunk=8):
+        self.m, self.images = model, images
+        self.num_frames = images.shape[0]
+        self.cond: Dict[int, dict] = {}
+        self.non_cond: Dict[int, dict] = {}
+        self.temp_cond: Dict[int, dict] = {}
+        self.counts = {"enc": 0, "memattn": 0, "memenc": 0, "dec": 0}
+        self.feats = feats
+        self.chunk = chunk
+
+    def _ensure_feats(self):
+        if self.feats is None:
+            parts = []
+            with torch.no_grad():
+                for a in range(0, self.num_frames, self.chunk):
+                    parts.append(self.m.forward_image(self.images[a:a + self.chunk]))
+                    self.counts["enc"] += min(self.chunk, self.num_frames - a)
+            self.feats = {k: torch.cat([p[k] for p in parts]) for k in ("feat_s0", "feat_s1", "feat")}
+            self.feats.update(hw=parts[0]["hw"], n=self.num_frames, pos=parts[0]["pos"])
+        return self.feats
+
+    def _frame_tokens(self, t):
+        f = self._ensure_feats()
+        h, w = f["hw"]
+        return f["feat"][t * h * w:(t + 1) * h * w]
+
+    def add_language_embd(self, frame_idx, language_embd):
+        f = self._ensure_feats()
+        pix = ops.add_bcast(self._frame_tokens(frame_idx), self.m.no_mem_embed.view(1, -1))
+        o = self.m.forward_sam_heads(pix, f, language_embd, frame_slice=(frame_idx, frame_idx + 1))
+        self.counts["dec"] += 1
+        self.temp_cond[frame_idx] = {"pred_masks": o["low_res_masks"], "obj_ptr": o["obj_ptr"], "best_iou_inds": o["best_iou_inds"]}
+        return o["low_res_masks"]
+
+    def _memory_for(self, t, low_res_masks):
+        S = self.m.image_size
+        high = ops.bilinear(low_res_masks.reshape(1, *low_res_masks.shape[-2:]).float().contiguous(), (S, S))
+        mf, mp = self.m.encode_new_memory(self._ensure_feats(), t, high)
+        self.counts["memenc"] += 1
+        return mf, mp
+
+    def _preflight(self, need_memory):
+        for t, cur in sorted(self.temp_cond.items()):
+            out = dict(cur)
+            if need_memory:
+                out["maskmem_features"], out["maskmem_pos_enc"] = self._memory_for(t, cur["pred_masks"])
+            self.cond[t] = out
+        self.temp_cond = {}
+
+    def _conditioned_features(self, t):
+        """reference sam2.py:2820-2989 (forward order, r = 1, only past pointers, no temporal enc on pointers)."""
+        m = self.m
+        h, w = self._ensure_feats()["hw"]
+        to_cat, to_cat_pos = [], []
+        prevs = [(0, o) for o in self.cond.values()]
+        for t_pos in range(1, m.num_maskmem):
+            prevs.append((t_pos, self.non_cond.get(t - (m.num_maskmem - t_pos), None)))
+        for t_pos, prev in prevs:
+            if prev is None:
+                continue
+            to_cat.append(prev["maskmem_features"])
+            to_cat_pos.append(ops.add_bcast(prev["maskmem_pos_enc"], m.maskmem_tpos_enc[m.num_maskmem - t_pos - 1].view(1, -1)))
+        ptrs = [o["obj_ptr"] for tt, o in self.cond.items() if tt <= t]
+        for t_diff in range(1, min(self.num_frames, m.max_obj_ptrs_in_encoder)):
+            tt = t - t_diff
+            if tt < 0:
+                break
+            o = self.non_cond.get(tt, None)
+            if o is not None:
+                ptrs.append(o["obj_ptr"])
+        n_ptr = 0
+        if ptrs:
+            op = torch.cat(ptrs, dim=0).reshape(-1, m.mem_dim)  # each 1 x C pointer -> C/mem_dim tokens (sam2.py:2952-2958)
+            to_cat.append(op)
+            to_cat_pos.append(torch.zeros_like(op))
+            n_ptr = op.shape[0]
+        memory, mpos = torch.cat(to_cat, dim=0).contiguous(), torch.cat(to_cat_pos, dim=0).contiguous()
+        self.counts["memattn"] += 1
+        return m.memory_attention(self._frame_tokens(t), self._ensure_feats()["pos"], memory, mpos, n_ptr)
+
+    def propagate(self):
+        """Yields (frame_idx, masks [1, 1, S, S] f32) for every frame from the first conditioning frame on."""
+        S = self.m.image_size
+        all_cond = set(self.temp_cond) | set(self.cond)
+        start = min(all_cond)
+        need_memory = any(t not in all_cond for t in range(start, self.num_frames))
+        self._preflight(need_memory)
+        res = []
+        for t in range(start, self.num_frames):
+            if t in self.cond:
+                pm = self.cond[t]["pred_masks"]
+            else:
+                pix = self._conditioned_features(t)
+                o = self.m.forward_sam_heads(pix, self._ensure_feats(), None, frame_slice=(t, t + 1))
+                self.counts["dec"] += 1
+                cur = {"pred_masks": o["low_res_masks"], "obj_ptr": o["obj_ptr"], "best_iou_inds": o["best_iou_inds"]}
+                if any(tt not in self.cond for tt in range(t + 1, self.num_frames)):  # memory is dead after the last tracked frame
+                    self.counts["memenc"] += 1
+                    cur["maskmem_features"], cur["maskmem_pos_enc"] = self.m.encode_new_memory(self._ensure_feats(), t, o["high_res_masks"])
+                self.non_cond[t] = cur
+                pm = cur["pred_masks"]
+            res.append((t, ops.bilinear(pm.reshape(1, *pm.shape[-2:]).float().contiguous(), (S, S)).unsqueeze(0)))
+        return res
+
+
+def load_sam2_checkpoint(model: SAM2VideoPredictor, path: str):
+    """reference sam2.py:30-85: accept {'model': sd} / {'state_dict': sd} / sd, rename '.gamma' -> '.g_weight', strict."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    sd = ck.get("model", ck.get("state_dict", ck)) if isinstance(ck, dict) else ck
+    sd = {k.replace("gamma", "g_weight"): v for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if missing or unexpected:
+        raise RuntimeError(f"SAM2 checkpoint mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")

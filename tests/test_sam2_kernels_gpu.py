@@ -1,0 +1,132 @@
+"""GPU parity of the SAM2-side HIP kernels (through the C ABI) against torch fp32 references of the ops the reference calls
+(F.conv2d / F.max_pool2d / F.interpolate / conv_transpose2d / complex RoPE / BCE+dice sums)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sam2 as S
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def test_gemm_ktail_and_colscale(dev):
+    from rga3.hip import ops
+
+    for K in (8, 24, 144, 152, 200):
+        a, w = rnd((70, K), dev, seed=K), rnd((40, K), dev, 0.1, seed=K + 1)
+        assert rel(ops.gemm(a, w), a.float().cpu() @ w.float().cpu().t()) < 6e-3, K
+    a, w, b = rnd((65, 64), dev, seed=1), rnd((48, 64), dev, 0.1, seed=2), rnd((48,), dev, 0.1, seed=3)
+    g, r = rnd((48,), dev, 1.0, seed=4), rnd((65, 48), dev, seed=5)
+    ref = r.float().cpu() + g.float().cpu() * (a.float().cpu() @ w.float().cpu().t() + b.float().cpu())
+    assert rel(ops.gemm(a, w, b, residual=r, colscale=g), ref) < 8e-3
+
+
+def test_patch_embed_im2col(dev):
+    from rga3.hip import ops
+
+    img = rnd((2, 3, 64, 64), dev, seed=1)
+    w, b = rnd((16, 3, 7, 7), dev, 0.1, seed=2), rnd((16,), dev, 0.1, seed=3)
+    cols, (Ho, Wo) = ops.im2col(img, 7, 4, 3)
+    wl = ops.pad_cols(w.reshape(16, -1).contiguous(), cols.shape[1])
+    out = ops.gemm(cols, wl, b).view(2, Ho, Wo, 16)
+    ref = F.conv2d(img.float().cpu(), w.float().cpu(), b.float().cpu(), stride=4, padding=3).permute(0, 2, 3, 1)
+    assert rel(out, ref) < 6e-3
+
+
+def test_maxpool_win_and_upsample_add(dev):
+    from rga3.hip import ops
+    from rga3.model.sam2 import relayout
+
+    Fn, H, W, C, w = 2, 16, 16, 24, 8
+    x = rnd((Fn * H * W, 3 * C), dev, seed=1)
+    xw = relayout(x, Fn, H, W, 0, w)
+    y = ops.maxpool2x2_win(xw[:, C:2 * C], Fn * (H // w) * (W // w), w)          # strided slice read
+    y = relayout(y, Fn, H // 2, W // 2, w // 2, 0)
+    ref = F.max_pool2d(x[:, C:2 * C].float().cpu().view(Fn, H, W, C).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(-1, C)
+    assert torch.equal(y.float().cpu(), ref)
+    a, b = rnd((Fn * H * W, C), dev, seed=2), rnd((Fn * H * W // 4, C), dev, seed=3)
+    up = F.interpolate(b.float().cpu().view(Fn, H // 2, W // 2, C).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1).reshape(-1, C)
+    assert rel(ops.upsample2x_add(a, b, Fn, H, W), a.float().cpu() + up) < 4e-3
+    pe = rnd((H * W, C), dev, seed=4)
+    assert rel(ops.add_bcast(a, pe, 0.1), a.float().cpu() + 0.1 * pe.float().cpu().repeat(Fn, 1)) < 4e-3
+
+
+@pytest.mark.parametrize("size", [(128, 128), (37, 53), (9, 200)])
+def test_bilinear(dev, size):
+    from rga3.hip import ops
+
+    x = torch.randn(5, 32, 32)
+    ref = F.interpolate(x[None], size=size, mode="bilinear", align_corners=False)[0]
+    assert (ops.bilinear(x.to(dev), size).cpu() - ref).abs().max().item() < 1e-5
+    idx = torch.tensor([3, 0, 3], dtype=torch.int32)
+    out = ops.bilinear(x.to(dev), size, idx.to(dev)).cpu()
+    assert (out - ref[idx.long()]).abs().max().item() < 1e-5
+    xb = x.to(torch.bfloat16)
+    assert (ops.bilinear(xb.to(dev), size).cpu() - F.interpolate(xb.float()[None], size=size, mode="bilinear", align_corners=False)[0]).abs().max().item() < 1e-5
+
+
+def test_conv3x3s2_dwconv_pixel_shuffle(dev):
+    from rga3.hip import ops
+
+    Fn, H, W = 2, 16, 16
+    for cin in (1, 4, 16):
+        x = rnd((Fn * H * W, cin), dev, seed=cin)
+        w, b = rnd((cin * 4, cin, 3, 3), dev, 0.2, seed=cin + 1), rnd((cin * 4,), dev, 0.1, seed=cin + 2)
+        ref = F.conv2d(x.float().cpu().view(Fn, H, W, cin).permute(0, 3, 1, 2), w.float().cpu(), b.float().cpu(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, cin * 4)
+        assert rel(ops.conv3x3s2(x, w, b, Fn, H, W), ref) < 6e-3, cin
+    m = torch.randn(Fn, H, W) * 4
+    w, b = rnd((4, 1, 3, 3), dev, 0.2, seed=9), rnd((4,), dev, 0.1, seed=10)
+    mm = (torch.sigmoid(m) * 20 - 10).to(torch.bfloat16).float()
+    ref = F.conv2d(mm[:, None], w.float().cpu(), b.float().cpu(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, 4)
+    assert rel(ops.conv3x3s2(m.to(dev), w, b, Fn, H, W, 20.0, -10.0), ref) < 6e-3
+    C = 32
+    x, w, b = rnd((Fn * H * W, C), dev, seed=11), rnd((C, 1, 7, 7), dev, 0.1, seed=12), rnd((C,), dev, 0.1, seed=13)
+    ref = F.conv2d(x.float().cpu().view(Fn, H, W, C).permute(0, 3, 1, 2), w.float().cpu(), b.float().cpu(), padding=3, groups=C).permute(0, 2, 3, 1).reshape(-1, C)
+    assert rel(ops.dwconv7x7(x, w, b, Fn, H, W), ref) < 6e-3
+    cin, co = 32, 16
+    x, wt, b = rnd((Fn * H * W, cin), dev, seed=14), rnd((cin, co, 2, 2), dev, 0.1, seed=15), rnd((co,), dev, 0.1, seed=16)
+    add = rnd((Fn * 4 * H * W, co), dev, seed=17)
+    g = ops.gemm(x, wt.permute(2, 3, 1, 0).reshape(-1, cin).contiguous())
+    out = ops.pixel_shuffle2x(g, b, add, Fn, H, W)
+    ref = F.conv_transpose2d(x.float().cpu().view(Fn, H, W, cin).permute(0, 3, 1, 2), wt.float().cpu(), b.float().cpu(), stride=2).permute(0, 2, 3, 1).reshape(-1, co) + add.float().cpu()
+    assert rel(out, ref) < 8e-3
+    assert rel(ops.pixel_shuffle2x(g, b, add, Fn, H, W, act="gelu"), F.gelu(ref)) < 1e-2
+
+
+def test_rope_axial_and_layernorm_gelu(dev):
+    from rga3.hip import ops
+
+    nq, nk, C = 16, 40, 64
+    cos, sin = S.compute_axial_cis(C, 4, 4)
+    q, k = rnd((nq, C), dev, seed=1), rnd((nk, C), dev, seed=2)
+    rq, rk = S.apply_rotary_enc(q.float().cpu()[None, None], k.float().cpu()[None, None][:, :, :32], cos, sin, repeat_freqs_k=True)
+    ops.rope_axial_(q, cos.contiguous().to(dev), sin.contiguous().to(dev), nq)
+    k_ref = torch.cat([rk[0, 0], k.float().cpu()[32:]], 0)
+    ops.rope_axial_(k, cos.contiguous().to(dev), sin.contiguous().to(dev), 32)
+    assert rel(q, rq[0, 0]) < 4e-3 and rel(k, k_ref) < 4e-3
+    x, w, b = rnd((33, 64), dev, 2.0, seed=3), rnd((64,), dev, seed=4), rnd((64,), dev, seed=5)
+    ref = F.gelu(F.layer_norm(x.float().cpu(), (64,), w.float().cpu(), b.float().cpu(), 1e-6))
+    assert rel(ops.layernorm(x, w, b, 1e-6, act="gelu"), ref) < 8e-3
+
+
+def test_bce_dice_sums(dev):
+    from rga3.hip import ops
+
+    x, t = torch.randn(3, 40, 50) * 3, (torch.randn(3, 40, 50) > 0.2).float()
+    out = ops.bce_dice_sums(x.to(dev), t.to(dev)).cpu()
+    bce = F.binary_cross_entropy_with_logits(x, t, reduction="none").flatten(1).sum(1)
+    p = torch.sigmoid(x)
+    ref = torch.stack([bce, (p * t).flatten(1).sum(1), p.flatten(1).sum(1), t.flatten(1).sum(1)], 1)
+    assert ((out - ref).abs() / ref.abs().clamp_min(1)).max().item() < 1e-4
