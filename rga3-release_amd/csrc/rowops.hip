@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void pad_cols_kernel(const unsigned short* __r
         const int ch = (int)(i % nch);
         const long r = i / nch;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (ch * 8 + 8 <= cols) {
+        if (ch * 8 + 8 <= cols && (ld_src & 7) == 0) {
             v = *(const u32x4*)(src + r * ld_src + ch * 8);
         } else if (ch * 8 < cols) {
             unsigned short tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -336,7 +336,7 @@ extern "C" int rga3_scatter_rows(const void* src, const int64_t* idx, void* out,
 
 extern "C" int rga3_pad_cols(const void* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, void* stream) {
     RGA3_CHECK_ARG(src && dst, "pad_cols: null pointer");
-    RGA3_CHECK_ARG(rows > 0 && cols > 0 && ld_dst >= cols && ld_dst % 8 == 0 && ld_src % 8 == 0, "pad_cols: bad shape");
+    RGA3_CHECK_ARG(rows > 0 && cols > 0 && ld_dst >= cols && ld_dst % 8 == 0, "pad_cols: bad shape");
     hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(rows * (ld_dst / 8))), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src,
                        (unsigned short*)dst, (long)rows, (int)cols, (long)ld_src, (long)ld_dst);
     RGA3_CHECK_LAUNCH("pad_cols");

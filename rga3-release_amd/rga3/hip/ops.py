@@ -32,8 +32,6 @@ def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:
     _need_cuda(x)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
     rows, cols = x.shape
-    if x.stride(0) % 8 != 0:
-        raise _lib.Rga3Error("pad_cols: source row stride must be a multiple of 8 elements")
     out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
     _lib.check(_lib.load().rga3_pad_cols(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), ld, _stream()), "pad_cols")
     return out
@@ -50,12 +48,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     N = w.shape[0]
     if K % 8 != 0 or a.stride(0) % 8 != 0 or w.stride(0) % 8 != 0:
         Kp = (K + 7) // 8 * 8
-        if a.stride(0) % 8 != 0:
-            a = _repack_rows(a)
-        if w.stride(0) % 8 != 0:
-            w = _repack_rows(w)
-        a = pad_cols(a, Kp) if a.shape[1] != Kp else a
-        w = pad_cols(w, Kp) if w.shape[1] != Kp else w
+        if a.shape[1] != Kp or a.stride(0) % 8 != 0:
+            a = pad_cols(a, Kp)
+        if w.shape[1] != Kp or w.stride(0) % 8 != 0:
+            w = pad_cols(w, Kp)
         K = Kp
     n_out = N // 2 if act == "swiglu" else N
     if out is None:
@@ -74,15 +70,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
                                     BF16 if out_dtype == torch.bfloat16 else F32, tile, _stream())
     _lib.check(rc, "gemm_bf16")
     return out
-
-
-def _repack_rows(x):
-    """Row stride not 16-byte aligned (e.g. K=3420): copy into an 8-element-aligned buffer (device-side copy)."""
-    rows, cols = x.shape
-    ld = (cols + 7) // 8 * 8
-    buf = torch.zeros((rows, ld), dtype=x.dtype, device=x.device)
-    buf[:, :cols].copy_(x)
-    return buf[:, :cols] if ld == cols else buf.as_strided((rows, cols), (ld, 1))
 
 
 def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = False, out=None, return_lse=False,

@@ -1,0 +1,67 @@
+"""Synthetic batch construction and the label-masking rule of the reference's collate_fn.
+
+No tokenizer / processor / dataset exists offline, so batches are built from token-id arrays directly; the masking rule is
+the pure function of reference utils/dataset.py:88-105.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+IGNORE_INDEX = -100
+
+
+def mask_labels(input_ids: np.ndarray, im_start_id: int, im_end_id: int, user_id: int, assistant_id: int, pad_token_id=None) -> np.ndarray:
+    """labels = input_ids with everything except assistant spans set to -100.
+
+    For every <|im_start|> ... <|im_end|> pair after the first (the system turn is skipped), an assistant turn keeps
+    positions [start+3, end] (content tokens plus the closing <|im_end|>); user turns keep nothing; pad -> -100."""
+    ids = np.asarray(input_ids)
+    labels = ids.copy()
+    keep = np.zeros(ids.shape, dtype=bool)
+    for b in range(ids.shape[0]):
+        starts = np.flatnonzero(ids[b] == im_start_id)
+        ends = np.flatnonzero(ids[b] == im_end_id)
+        for s, e in zip(starts[1:], ends[1:]):
+            if s + 1 < ids.shape[1] and ids[b, s + 1] == assistant_id:
+                keep[b, s + 3: e + 1] = True
+    labels[~keep] = IGNORE_INDEX
+    if pad_token_id is not None:
+        labels[labels == pad_token_id] = IGNORE_INDEX
+    return labels
+
+
+def make_batch(cfg, device, batch=1, frames_mllm=16, frames_sam=16, side=448, sam_side=1024, n_text=64, seed=0, seg=True, label_hw=(480, 640),
+               dtype=torch.bfloat16):
+    """Synthetic UniGRModel kwargs of the shape the reference's collate_fn produces:
+    frames_mllm frames side x side -> video_grid_thw [[frames/2, side/14, side/14]], n_text non-video tokens incl. the
+    answer "Sure, [SEG]." (6 supervised tokens), random rectangle GT masks."""
+    g = torch.Generator().manual_seed(seed)
+    gt, gh = frames_mllm // 2, side // 14
+    n_vid = gt * (gh // 2) * (gh // 2)
+    ids, labels = [], []
+    for b in range(batch):
+        text = torch.randint(1000, 100000, (n_text,), generator=g)
+        seq = torch.cat([text[:10], torch.tensor([cfg.vision_start_token_id]), torch.full((n_vid,), cfg.video_token_id),
+                         torch.tensor([cfg.vision_end_token_id]), text[12:]])
+        lab = torch.full_like(seq, IGNORE_INDEX)
+        if seg:
+            seq[-3] = cfg.seg_token_idx
+        lab[-6:] = seq[-6:]
+        ids.append(seq)
+        labels.append(lab)
+    input_ids, labels = torch.stack(ids), torch.stack(labels)
+    px = torch.randn(batch * gt * gh * gh, 1176, generator=g).clamp_(-1.8, 2.2).to(dtype)
+    images_sam = torch.randn(batch, frames_sam, 3, sam_side, sam_side, generator=g).to(dtype)
+    masks = []
+    for b in range(batch):
+        m = torch.zeros(frames_sam if seg else 0, *label_hw)
+        for t in range(m.shape[0]):
+            y0, x0 = int(torch.randint(0, label_hw[0] // 2, (1,), generator=g)), int(torch.randint(0, label_hw[1] // 2, (1,), generator=g))
+            m[t, y0:y0 + label_hw[0] // 3, x0:x0 + label_hw[1] // 3] = 1
+        masks.append(m)
+    to = lambda t: t.to(device)
+    return dict(input_ids=to(input_ids), attention_mask=to(torch.ones_like(input_ids)), labels=to(labels), pixel_values_videos=to(px),
+                video_grid_thw=torch.tensor([[gt, gh, gh]] * batch), second_per_grid_ts=torch.ones(batch), images_sam=to(images_sam),
+                offset=torch.arange(batch + 1), masks_list=[to(m) for m in masks], label_list=[torch.zeros(label_hw) for _ in range(batch)],
+                resize_list=[(sam_side, sam_side)] * batch, inference=False)

@@ -38,11 +38,13 @@ import model.sam2 as RS  # noqa: E402  (the reference)
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 TINY = dict(image_size=128, embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4),
-            pos_bkg=(7, 7), d_model=128, mem_dim=16, memattn_layers=2, memattn_ff=64)
+            pos_bkg=(7, 7), d_model=256, mem_dim=64, memattn_layers=2, memattn_ff=64)
 
 
-def build_tiny_predictor():
-    t = TINY
+def build_tiny_predictor(image_size=None):
+    t = dict(TINY)
+    if image_size is not None:
+        t["image_size"] = image_size
     trunk = RS.Hiera(embed_dim=t["embed_dim"], num_heads=t["num_heads"], stages=t["stages"], global_att_blocks=t["global_att_blocks"],
                      window_pos_embed_bkg_spatial_size=t["pos_bkg"], window_spec=t["window_spec"])
     neck = RS.FpnNeck(d_model=t["d_model"], position_encoding=RS.PositionEmbeddingSine(num_pos_feats=t["d_model"], normalize=True, scale=None, temperature=10000),
@@ -137,7 +139,7 @@ def main():
     out["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
     T = 5
     imgs = det_tensor("sam_images", (T, 3, 128, 128), 1.0, seed=3)
-    emb = det_tensor("lang_embd", (T, 1, 128), 1.0, seed=4)
+    emb = det_tensor("lang_embd", (T, 1, 256), 1.0, seed=4)
 
     with torch.no_grad():
         # G2: image encoder levels
@@ -154,7 +156,7 @@ def main():
         # internals of the same call for decoder-level pinning
         feats = st
         hr = [x.permute(1, 2, 0).view(x.size(1), x.size(2), *s) for x, s in zip(feats["current_vision_feats"][:-1], feats["feat_sizes"][:-1])]
-        pix = (feats["current_vision_feats"][-1] + pred.no_mem_embed).permute(1, 2, 0).view(3, 128, 8, 8)
+        pix = (feats["current_vision_feats"][-1] + pred.no_mem_embed).permute(1, 2, 0).view(3, 256, 8, 8)
         lm, hm, ious, lr, hrm, optr, osl = pred._forward_sam_heads(backbone_features=pix, high_res_features=hr, multimask_output=True, language_embd=emb[:3])
         out["g3_heads_ious"], out["g3_heads_best"] = ious.numpy(), torch.argmax(ious, -1).numpy()
         out["g3_heads_low_multi"], out["g3_heads_obj_ptr"], out["g3_heads_obj_logits"] = lm.numpy(), optr.numpy(), osl.numpy()
@@ -162,7 +164,7 @@ def main():
         mf, mp = pred._encode_new_memory(feats["current_vision_feats"], feats["feat_sizes"], hrm, False)
         out["g2_memenc_feat"], out["g2_memenc_pos"] = mf.numpy(), mp[0].numpy()
         # G2: memory attention on synthetic memory (two 8x8 frames of mem + 4 pointer tokens)
-        mem = det_tensor("g2_mem", (2 * 64 + 8, 1, 16)); mem_pos = det_tensor("g2_mem_pos", (2 * 64 + 8, 1, 16))
+        mem = det_tensor("g2_mem", (2 * 64 + 8, 1, 64)); mem_pos = det_tensor("g2_mem_pos", (2 * 64 + 8, 1, 64))
         cur = feats["current_vision_feats"][-1][:, :1]; cur_pos = feats["current_vision_pos_embeds"][-1][:, :1]
         ma = pred.memory_attention(curr=[cur], curr_pos=[cur_pos], memory=mem, memory_pos=mem_pos, num_obj_ptr_tokens=8)
         out["g2_memattn"] = ma.numpy()

@@ -16,7 +16,7 @@ def gold():
 
 def tiny_cfg():
     return S.Sam2Cfg(image_size=128, embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4),
-                     pos_bkg=(7, 7), d_model=128, mem_dim=16, memattn_layers=2)
+                     pos_bkg=(7, 7), d_model=256, mem_dim=64, memattn_layers=2)
 
 
 def det_params(g, bf16_round=False):
@@ -32,4 +32,4 @@ def images(T=5):
 
 
 def lang(T=5):
-    return det_tensor("lang_embd", (5, 1, 128), 1.0, seed=4)[:T]
+    return det_tensor("lang_embd", (5, 1, 256), 1.0, seed=4)[:T]

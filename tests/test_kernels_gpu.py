@@ -187,6 +187,9 @@ def test_gather_scatter_pad(dev):
     assert torch.equal(p[:, :40].cpu(), table[:, :40].cpu()) and p[:, 40:].abs().sum().item() == 0
     q = ops.pad_cols(_rand((5, 24), dev)[:, :20], 32)
     assert q[:, 20:].abs().sum().item() == 0
+    u = _rand((7, 147), dev, seed=52)  # rows not 16-byte aligned
+    pu = ops.pad_cols(u, 152)
+    assert torch.equal(pu[:, :147].cpu(), u.cpu()) and pu[:, 147:].abs().sum().item() == 0
 
 
 def test_elementwise(dev):

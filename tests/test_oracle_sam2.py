@@ -76,7 +76,7 @@ def test_g3_train_path_and_heads(G, P):
         assert close(low, G["g3_train_low"]) and close(high, G["g3_train_high"])
         mf, mp = S.encode_new_memory(P, feats[0], feats[2], o["high_res_masks"], cfg)
         assert close(mf, G["g2_memenc_feat"]) and close(mp, G["g2_memenc_pos"], 1e-5)
-        mem, mpos = det_tensor("g2_mem", (136, 1, 16)), det_tensor("g2_mem_pos", (136, 1, 16))
+        mem, mpos = det_tensor("g2_mem", (136, 1, 64)), det_tensor("g2_mem_pos", (136, 1, 64))
         ma = S.memory_attention(P, feats[0][-1][:, :1], feats[1][-1][:, :1], mem, mpos, 8, cfg)
         assert close(ma, G["g2_memattn"])
 

@@ -12,7 +12,7 @@ from tests.sam2_tiny import det_params, gold, images, lang, tiny_cfg
 pytestmark = pytest.mark.gpu
 
 TINY = dict(image_size=128, embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4), pos_bkg=(7, 7),
-            d_model=128, mem_dim=16, memattn_layers=2, memattn_ff=64)
+            d_model=256, mem_dim=64, memattn_layers=2, memattn_ff=64)
 
 
 def rel(a, b):

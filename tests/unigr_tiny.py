@@ -1,0 +1,64 @@
+"""Shared tiny-UniGR helpers: identical batch construction to tests/golden/make_unigr_fixtures.py."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import sam2 as S
+from oracle.detweights import det_state_dict, det_tensor
+from tests.qwen_tiny import oracle_cfg, product_cfg_kwargs
+
+SEG, T_SAM, SAM_SIDE = 300, 2, 1024
+GOLD_PATH = os.path.join(os.path.dirname(__file__), "golden", "unigr_tiny.npz")
+SAM_TINY = dict(image_size=SAM_SIDE, embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4), pos_bkg=(7, 7),
+                d_model=256, mem_dim=64, memattn_layers=2, memattn_ff=64)
+
+
+def gold():
+    return np.load(GOLD_PATH, allow_pickle=False)
+
+
+def sam_cfg():
+    return S.Sam2Cfg(image_size=SAM_SIDE, embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4), pos_bkg=(7, 7),
+                     d_model=256, mem_dim=64, memattn_layers=2)
+
+
+def params(g, bf16_round=False):
+    shapes = {str(n): eval(str(s)) for n, s in zip(g["param_names"], g["param_shapes"])}
+    sam_shapes = {str(n): eval(str(s)) for n, s in zip(g["sam_param_names"], g["sam_param_shapes"])}
+    P, PS = det_state_dict(shapes, seed=1), det_state_dict(sam_shapes, seed=2)
+    if bf16_round:
+        P = {k: v.to(torch.bfloat16).float() for k, v in P.items()}
+        PS = {k: v.to(torch.bfloat16).float() for k, v in PS.items()}
+    return P, PS
+
+
+def make_batch(seg_flags, seed):
+    g = np.random.default_rng(seed)
+    grid = [[2, 8, 12]]
+    nv = 2 * 4 * 6
+    ids, labs = [], []
+    for b, has in enumerate(seg_flags):
+        pre = g.integers(0, 290, 6)
+        ans = g.integers(0, 290, 7)
+        if has:
+            ans[3] = SEG
+        seq = np.concatenate([pre, [303], np.full(nv, 302), g.integers(0, 290, 4), ans]).astype(np.int64)
+        lab = np.full_like(seq, -100)
+        lab[-7:] = seq[-7:]
+        ids.append(seq); labs.append(lab)
+    ids, labs = np.stack(ids), np.stack(labs)
+    B = len(seg_flags)
+    px = torch.cat([det_tensor(f"unigr_px_{seed}_{b}", (2 * 8 * 12, 1176), 1.0, seed=5) for b in range(B)], 0)
+    imgs = torch.stack([det_tensor(f"unigr_img_{seed}_{b}", (T_SAM, 3, SAM_SIDE, SAM_SIDE), 1.0, seed=6) for b in range(B)], 0)
+    h, w = 20, 28
+    masks = []
+    for b, has in enumerate(seg_flags):
+        m = (det_tensor(f"unigr_gt_{seed}_{b}", (T_SAM, h, w), 1.0, seed=7) > 0.3).float()
+        masks.append(m if has else m[0:0])
+    return dict(input_ids=torch.from_numpy(ids), labels=torch.from_numpy(labs), attention_mask=torch.ones(B, ids.shape[1], dtype=torch.long),
+                pixel_values_videos=px, video_grid_thw=torch.tensor(grid * B), second_per_grid_ts=torch.tensor([1.0] * B), images_sam=imgs,
+                offset=torch.arange(B + 1), masks_list=masks, label_list=[torch.zeros(h, w) for _ in range(B)], resize_list=[(SAM_SIDE, SAM_SIDE)] * B)
+
+
+CASES = {"11": (True, True), "10": (True, False), "00": (False, False)}
