@@ -84,7 +84,7 @@ def evaluate(P, PS, qcfg, scfg, batch, seg_token_idx, original_size_list):
     pred = seg_embeddings(P, r["hidden"], mask)
     counts = mask.int().sum(-1)
     off = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(-1)])
-    out = []
+    out, logits = [], []
     imgs = batch["images_sam"][0].float()
     for i in range(len(off) - 1):
         e = pred[int(off[i]):int(off[i + 1])]
@@ -92,4 +92,5 @@ def evaluate(P, PS, qcfg, scfg, batch, seg_token_idx, original_size_list):
         h, w = original_size_list[i]
         m = F.interpolate(masks, size=(h, w), mode="bilinear", align_corners=False)[:, 0]
         out.append(m.sigmoid() > 0.5)
-    return r, out, off
+        logits.append(m)
+    return r, out, off, logits

@@ -48,6 +48,6 @@ def test_evaluate_bool_masks(G):
     b = make_batch((True,), seed=9)
     assert np.array_equal(b["input_ids"].numpy(), G["eval_input_ids"])
     with torch.no_grad():
-        _, masks, off = U.evaluate(P, PS, oracle_cfg(), sam_cfg(), b, SEG, [(20, 28)])
+        _, masks, off, _ = U.evaluate(P, PS, oracle_cfg(), sam_cfg(), b, SEG, [(20, 28)])
     assert len(masks) == int(G["eval_n_masks"]) and off.tolist() == [0, 1]
     assert np.array_equal(masks[0].numpy(), G["eval_masks"])

@@ -94,7 +94,11 @@ def test_inference_prompt_every_frame(model, dev, P, G):
     assert sess.counts["enc"] == 5 and sess.counts["memattn"] == 0 and sess.counts["memenc"] == 0   # reference: enc=10, memenc=5 (dead work)
     same = [int(sess.cond[t]["best_iou_inds"]) == int(rs.out["cond_frame_outputs"][t]["best_iou_inds"]) if "best_iou_inds" in rs.out["cond_frame_outputs"][t] else True for t in range(5)]
     ious = [iou(masks[t] > 0, rmasks[t] > 0) for t in range(5)]
-    assert np.mean(ious) >= 0.99, ious
+    # random-weight masks are speckle (logits hover around 0): exact agreement is required outside the bf16 noise band
+    margin = rmasks.abs() > 0.05 * rmasks.abs().max()
+    assert margin.float().mean() > 0.5
+    assert torch.equal((masks.cpu() > 0)[margin], (rmasks > 0)[margin])
+    assert np.mean(ious) >= 0.97, ious
 
 
 def test_frame0_prompt_propagation(model, dev, P, G):

@@ -41,7 +41,7 @@ def bench_gemm(out):
     for name, M, N, K in shapes:
         a, w = rnd(M, K), rnd(N, K, scale=0.02)
         c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-        for tile in (0, 1, 2):
+        for tile in (0, 1, 2, 10, 11, 12):
             ms = timeit(lambda: ops.gemm(a, w, out=c, tile=tile), iters=10 if M * N * K > 4e11 else 20)
             tf = 2.0 * M * N * K / ms / 1e9
             rec = {"op": "gemm", "name": name, "M": M, "N": N, "K": K, "tile": tile, "ms": round(ms, 4), "tflops": round(tf, 1)}
