@@ -214,7 +214,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     constexpr int OUT_NT = (ACT == ACT_SWIGLU) ? NTL / 2 : NTL;  // output n-tiles per wave
     constexpr int OW = OUT_NT * 16;                               // output columns per wave
     constexpr int ESZ = OUT_F32 ? 4 : 2;
-    constexpr int EROW = OW * ESZ;  // bytes per staged row
+    constexpr int EDAT = OW * ESZ;  // payload bytes per staged row
+    constexpr int EROW = EDAT + 16; // +16 B pad: rows no longer alias on the 128-B ds_write bank period (was 16-way conflicts)
     char* est = smem + wid * (16 * EROW);
     const int g = lane >> 4, c = lane & 15;
     const int ncol0 = (ACT == ACT_SWIGLU) ? (n0 / 2 + wn * OW) : (n0 + wn * OW);  // first output column of this wave
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // read back row-major: 16 rows x EROW bytes, 16 B per lane
-        constexpr int CPR = EROW / 16;       // 16-byte chunks per row
+        constexpr int CPR = EDAT / 16;       // 16-byte chunks per row
         constexpr int TOTAL = 16 * CPR;      // chunks in the staged block
         constexpr int EPC = 16 / ESZ;        // elements per chunk
 #pragma unroll

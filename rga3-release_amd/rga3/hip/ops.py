@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from . import lib as _lib
+from . import tuner as _tuner
 
 BF16, F32 = 0, 1
 ACT = {"none": 0, "gelu": 1, "swiglu": 2, "relu": 3}
@@ -65,10 +66,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
         ldr = residual.stride(0)
     if colscale is not None:
         assert colscale.dtype == torch.bfloat16 and colscale.numel() == n_out and colscale.is_contiguous()
-    rc = _lib.load().rga3_gemm_bf16(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(colscale), out.data_ptr(), M, N, K,
-                                    a.stride(0), w.stride(0), out.stride(0), ldr, ACT[act],
-                                    BF16 if out_dtype == torch.bfloat16 else F32, tile, _stream())
-    _lib.check(rc, "gemm_bf16")
+    fn = _lib.load().rga3_gemm_bf16
+    odt = BF16 if out_dtype == torch.bfloat16 else F32
+
+    def run(t):
+        _lib.check(fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(colscale), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
+                      out.stride(0), ldr, ACT[act], odt, t, _stream()), "gemm_bf16")
+
+    if tile == -1 and M * N * K >= (1 << 24) and not (residual is not None and residual.data_ptr() == out.data_ptr()):
+        tile = _tuner.pick(_tuner.key_of(M, N, K, act, odt, bias is not None, residual is not None), run)
+    run(tile)
     return out
 
 

@@ -1,0 +1,46 @@
+"""Per-shape tile selection for the bf16 GEMM, measured on the device it runs on (MI355X boards differ by >10 % on the same
+binary: MI355X_MICROARCH.md 'DVFS give-back' item 5).  First call of a (M-bucket, N, K, epilogue) shape times the candidate
+tilings with HIP events on the launch stream and caches the winner for the process; RGA3_GEMM_TUNE=0 falls back to the
+library's static heuristic (tile = -1)."""
+from __future__ import annotations
+
+import os
+
+import torch
+
+CANDIDATES = (10, 11, 12, 1)   # 256x256, 256x128, 128x128 (single-phase loop) and 256x128 register-pipelined
+_cache = {}
+_enabled = os.environ.get("RGA3_GEMM_TUNE", "1") != "0"
+
+
+def key_of(M, N, K, act, out_f32, has_bias, has_res):
+    return ((M + 255) // 256, N, K, act, out_f32, has_bias, has_res)
+
+
+def pick(key, run):
+    """run(tile) launches the GEMM once with that tiling.  Returns the cached / measured best tile id."""
+    if not _enabled:
+        return -1
+    t = _cache.get(key)
+    if t is not None:
+        return t
+    if torch.cuda.is_current_stream_capturing():
+        return -1
+    best, best_ms = -1, float("inf")
+    for tile in CANDIDATES:
+        run(tile)  # warm (also sets the func attribute for large dynamic LDS)
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(3):
+            run(tile)
+        en.record()
+        en.synchronize()
+        ms = st.elapsed_time(en)
+        if ms < best_ms:
+            best, best_ms = tile, ms
+    _cache[key] = best
+    return best
+
+
+def table():
+    return dict(_cache)
