@@ -138,6 +138,33 @@ int rga3_pixel_shuffle2x(const void* g, const void* bias, const void* add, void*
 /* per-mask {sum BCE-with-logits, sum sigmoid*t, sum sigmoid, sum t} (model/qwen_2_5_vl_sam2.py:17-60); out4 f32 [n_masks,4] */
 int rga3_bce_dice_sums(const float* logits, const float* targets, float* out4, int64_t n_masks, int64_t hw, void* stream);
 
+/* ---- training step (backward + optimiser) ---------------------------------------------------------------- */
+
+/* Flash-style attention backward (recompute from q,k,v,dO and the forward's lse): dq, dk, dv in bf16, no atomics.
+ * strides16 = HOST array {q_st,q_sh,k_st,k_sh,v_st,v_sh,o_st,o_sh,do_st,do_sh,dq_st,dq_sh,dk_st,dk_sh,dv_st,dv_sh} (elements);
+ * delta_ws: f32 workspace [Hq*total_q].  Replaces the autograd of flash-attn / SDPA under train_joint.py:534. D <= 128. */
+int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                         void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
+                         int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale, int causal,
+                         void* stream);
+/* dx = d rmsnorm(x; weight)/dx . dy (+ add): backward of HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:74-79) w.r.t. x */
+int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim, float eps,
+                     void* stream);
+/* backward of silu(gate)*up on the interleaved [T, 2I] pre-activation layout of RGA3_ACT_SWIGLU: dgu from da [T, I] */
+int rga3_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t T, int64_t I, void* stream);
+/* out[c, r] = in[r, c] (16-bit): operand layout for dW = dY^T X through the NT GEMM */
+int rga3_transpose16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, void* stream);
+/* out[u,:] = sum_{j in [offsets[u], offsets[u+1])} x[rows[j],:]: embedding-table gradient rows (HF embed_tokens, trainable per
+ * train_joint.py:242-243) without atomics */
+int rga3_segment_sum_rows(const void* x, const int64_t* rows, const int64_t* offsets, void* out, int64_t n_out, int64_t dim, int64_t ldx,
+                          void* stream);
+/* fused AdamW (decoupled decay, bias correction) on bf16 params with fp32 master/moments; grad is scaled by grad_scale first
+ * (loss scaling / clipping factor). Optimiser of train_joint.py:300-324 (DeepSpeed AdamW lr 4e-5, betas (0.9,0.95), wd 0). */
+int rga3_adamw_step(void* param, float* master, const void* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* *out += sum(g^2) (fp32 atomic): global gradient norm for clipping (train_joint.py:300 gradient_clipping 1.0) */
+int rga3_sumsq_accum(const void* g, float* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,7 +193,12 @@ def rotate_half(x):
 
 
 def _lin(x, P, name):
-    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+    """nn.Linear, plus the PEFT-style LoRA update when P carries <name>.lora_A/B.default.weight (scaling in P['lora_scaling'])."""
+    y = F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+    a = P.get(name + ".lora_A.default.weight")
+    if a is not None:
+        y = y + P["lora_scaling"] * F.linear(F.linear(x, a), P[name + ".lora_B.default.weight"])
+    return y
 
 
 def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw, cfg: QwenCfg, return_pre_merge=False):

@@ -1,0 +1,414 @@
+// Variable-length fused attention BACKWARD for CDNA4 — companion of attn_fwd.hip (same MFMA layouts, same LDS images).
+//
+// Flash-style recomputation from Q, K, V, dO and the forward's LSE (never materialises the score matrix).  Two kernels,
+// no atomics, bitwise reproducible:
+//   * dq kernel   — one workgroup per (q block, q head): recomputes S^T = K.Q^T and dP^T = V.dO^T per KV tile with the
+//                   QUERY on the lane (so lse[q], delta[q] are lane scalars), forms dS^T and accumulates
+//                   dQ^T += K^T . dS^T  (K^T through ds_read_b64_tr_b16 of the row-major K image).
+//   * dkv kernel  — one workgroup per (key block, kv head), looping over the q heads of the GQA group and over Q tiles:
+//                   roles swapped (K/V fragments live in registers, Q / dO tiles are staged in LDS), KEY on the lane;
+//                   dV^T += dO^T . P  and  dK^T += Q^T . dS  with transposed LDS reads of the dO / Q images.
+// delta[q] = rowsum(dO * O) comes from a small pre-pass kernel.
+// Call sites replaced: the autograd of flash_attn_varlen_func / SDPA under train_joint.py:534 (model.backward).
+#include "common.h"
+
+namespace rga3 {
+
+struct AttnBwdArgs {
+    const unsigned short *q, *k, *v, *o, *dout;
+    unsigned short *dq, *dk, *dv;
+    const float* lse;   // [Hq, total_q] natural log
+    float* delta;       // [Hq, total_q]
+    const int *cu_q, *cu_k;
+    long q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh, do_st, do_sh, dq_st, dq_sh, dk_st, dk_sh, dv_st, dv_sh;
+    int Hq, Hkv, D;
+    long total_q;
+    float scale, scale_log2;
+    int causal;
+};
+
+constexpr int BT = 64;  // tile of the streamed (LDS-staged) dimension
+
+// ---------------------------------------------------------------------------------------------- delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdArgs p) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (token, head) pairs, one wave each
+    const int lane = threadIdx.x & 63;
+    const long total = p.total_q * p.Hq;
+    if (row >= total) return;
+    const long t = row / p.Hq;
+    const int h = (int)(row % p.Hq);
+    float s = 0.f;
+    for (int d = lane * 8; d < p.D; d += 512) {
+        u32x4 a = *(const u32x4*)(p.o + t * p.o_st + (long)h * p.o_sh + d);
+        u32x4 b = *(const u32x4*)(p.dout + t * p.do_st + (long)h * p.do_sh + d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s += __uint_as_float(a[i] << 16) * __uint_as_float(b[i] << 16);
+            s += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(b[i] & 0xffff0000u);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) p.delta[(long)h * p.total_q + t] = s;
+}
+
+// ---------------------------------------------------------------------------------------------- dQ
+template <int DP, int QT, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+    constexpr int NT = 64 * NWAVE;
+    constexpr int BLOCK_M = NWAVE * QT * 16;
+    constexpr int CH = DP / 8;
+    constexpr int STRIDE = DP * 2 + 32;
+    constexpr int DS = DP / 32, DT = DP / 16;
+    constexpr int LOADS = (BT * CH) / NT;
+    static_assert((BT * CH) % NT == 0, "tile chunks must divide evenly over threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + BT * STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int seg = blockIdx.z, hq = blockIdx.y;
+    const int hk = hq / (p.Hq / p.Hkv);
+    const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
+    const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
+    const int qb0 = blockIdx.x * BLOCK_M;
+    if (qb0 >= Lq) return;
+    const int shift = Lk - Lq;
+    const int qw0 = qb0 + wid * (QT * 16);
+
+    // Q and dO fragments ("B" operands): lane (c, g) holds row q = c, d = 32*ds + 8g .. +7
+    bf16x8 qf[QT][DS], dof[QT][DS];
+    float lse2[QT], dl[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = qw0 + t * 16 + c;
+        const bool ok = qi < Lq;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+            const int d = ds * 32 + g * 8;
+            u32x4 z = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u};
+            if (ok && d < p.D) {
+                z = *(const u32x4*)(p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh + d);
+                y = *(const u32x4*)(p.dout + (long)(qs + qi) * p.do_st + (long)hq * p.do_sh + d);
+            }
+            qf[t][ds] = __builtin_bit_cast(bf16x8, z);
+            dof[t][ds] = __builtin_bit_cast(bf16x8, y);
+        }
+        lse2[t] = ok ? p.lse[(long)hq * p.total_q + qs + qi] * 1.4426950408889634f : 0.f;
+        dl[t] = ok ? p.delta[(long)hq * p.total_q + qs + qi] : 0.f;
+    }
+
+    f32x4 dqacc[QT][DT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) dqacc[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int kv_end = Lk;
+    if (p.causal) kv_end = min(Lk, qb0 + BLOCK_M + shift);
+    if (kv_end < 0) kv_end = 0;
+    const int ntiles = (kv_end + BT - 1) / BT;
+
+    u32x4 kreg[LOADS], vreg[LOADS];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / CH, ch = idx % CH;
+            const int key = kt * BT + r;
+            u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+            if (key < Lk && ch * 8 < p.D) {
+                zk = *(const u32x4*)(p.k + (long)(ks + key) * p.k_st + (long)hk * p.k_sh + ch * 8);
+                zv = *(const u32x4*)(p.v + (long)(ks + key) * p.v_st + (long)hk * p.v_sh + ch * 8);
+            }
+            kreg[i] = zk;
+            vreg[i] = zv;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / CH, ch = idx % CH;
+            *(u32x4*)(Ks + r * STRIDE + ch * 16) = kreg[i];
+            *(u32x4*)(Vs + r * STRIDE + ch * 16) = vreg[i];
+        }
+    };
+
+    if (ntiles > 0) load_tile(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < ntiles) load_tile(kt + 1);
+        const int k0 = kt * BT;
+        const bool need_mask = (k0 + BT > Lk) || (p.causal && (k0 + BT - 1 > qb0 + shift));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int qi = qw0 + t * 16 + c;
+            // S^T and dP^T for the 64 keys of this tile x query c
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    bf16x8 kf = *(const bf16x8*)(Ks + (j * 16 + c) * STRIDE + ds * 64 + g * 16);
+                    bf16x8 vf = *(const bf16x8*)(Vs + (j * 16 + c) * STRIDE + ds * 64 + g * 16);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ds], s[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[t][ds], dp[j], 0, 0, 0);
+                }
+            // dS^T = P^T * (dP^T - delta) * scale, packed as the "B" operand of the dQ product
+            bf16x8 dsf[2];
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                float e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = 2 * ss + (u >> 2), r = u & 3;
+                    float pr = exp2f(s[j][r] * p.scale_log2 - lse2[t]);
+                    if (need_mask) {
+                        const int key = k0 + j * 16 + 4 * g + r;
+                        const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
+                        pr = ok ? pr : 0.f;
+                    }
+                    if (qi >= Lq) pr = 0.f;
+                    e[u] = pr * (dp[j][r] - dl[t]) * p.scale;
+                }
+                u32x4 pk;
+                pk[0] = pack_bf2(e[0], e[1]); pk[1] = pack_bf2(e[2], e[3]); pk[2] = pack_bf2(e[4], e[5]); pk[3] = pack_bf2(e[6], e[7]);
+                dsf[ss] = __builtin_bit_cast(bf16x8, pk);
+            }
+            // dQ^T += K^T . dS^T
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const char* a0 = Ks + (ss * 32 + 4 * g + (c >> 2)) * STRIDE + (d * 16 + 4 * (c & 3)) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * STRIDE));
+                    bf16x8 kt8;
+                    kt8[0] = lo[0]; kt8[1] = lo[1]; kt8[2] = lo[2]; kt8[3] = lo[3];
+                    kt8[4] = hi[0]; kt8[5] = hi[1]; kt8[6] = hi[2]; kt8[7] = hi[3];
+                    dqacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt8, dsf[ss], dqacc[t][d], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = qw0 + t * 16 + c;
+        if (qi < Lq) {
+            unsigned short* row = p.dq + (long)(qs + qi) * p.dq_st + (long)hq * p.dq_sh;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int dd = d * 16 + 4 * g;
+                if (dd < p.D) {
+                    u32x2 pk;
+                    pk[0] = pack_bf2(dqacc[t][d][0], dqacc[t][d][1]);
+                    pk[1] = pack_bf2(dqacc[t][d][2], dqacc[t][d][3]);
+                    *(u32x2*)(row + dd) = pk;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV
+template <int DP, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    constexpr int NT = 64 * NWAVE;
+    constexpr int BLOCK_N = NWAVE * 16;  // keys per workgroup (one 16-key tile per wave)
+    constexpr int CH = DP / 8;
+    constexpr int STRIDE = DP * 2 + 32;
+    constexpr int DS = DP / 32, DT = DP / 16;
+    constexpr int LOADS = (BT * CH) / NT;
+    static_assert((BT * CH) % NT == 0, "tile chunks must divide evenly over threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                       // [BT][STRIDE] row-major Q tile
+    char* Os = smem + BT * STRIDE;         // [BT][STRIDE] row-major dO tile
+    float* Ls = (float*)(smem + 2 * BT * STRIDE);  // lse2[BT], delta[BT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int seg = blockIdx.z, hk = blockIdx.y;
+    const int group = p.Hq / p.Hkv;
+    const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
+    const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
+    const int kb0 = blockIdx.x * BLOCK_N;
+    if (kb0 >= Lk) return;
+    const int shift = Lk - Lq;
+    const int key = kb0 + wid * 16 + c;  // this lane's key
+
+    // K and V fragments ("B" operands): lane holds key row `key`, d = 32*ds + 8g .. +7
+    bf16x8 kf[DS], vf[DS];
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+        const int d = ds * 32 + g * 8;
+        u32x4 z = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u};
+        if (key < Lk && d < p.D) {
+            z = *(const u32x4*)(p.k + (long)(ks + key) * p.k_st + (long)hk * p.k_sh + d);
+            y = *(const u32x4*)(p.v + (long)(ks + key) * p.v_st + (long)hk * p.v_sh + d);
+        }
+        kf[ds] = __builtin_bit_cast(bf16x8, z);
+        vf[ds] = __builtin_bit_cast(bf16x8, y);
+    }
+    f32x4 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { dkacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // first query that can see any key of this block (causal): q >= key - shift
+    int q_begin = 0;
+    if (p.causal) q_begin = max(0, kb0 - shift);
+    const int t0 = q_begin / BT;
+    const int ntq = (Lq + BT - 1) / BT;
+
+    for (int hh = 0; hh < group; ++hh) {
+        const int hq = hk * group + hh;
+        for (int qt = t0; qt < ntq; ++qt) {
+            __syncthreads();  // previous tile fully consumed
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int idx = tid + i * NT;
+                const int r = idx / CH, ch = idx % CH;
+                const int qi = qt * BT + r;
+                u32x4 zq = {0u, 0u, 0u, 0u}, zo = {0u, 0u, 0u, 0u};
+                if (qi < Lq && ch * 8 < p.D) {
+                    zq = *(const u32x4*)(p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh + ch * 8);
+                    zo = *(const u32x4*)(p.dout + (long)(qs + qi) * p.do_st + (long)hq * p.do_sh + ch * 8);
+                }
+                *(u32x4*)(Qs + r * STRIDE + ch * 16) = zq;
+                *(u32x4*)(Os + r * STRIDE + ch * 16) = zo;
+            }
+            if (tid < BT) {
+                const int qi = qt * BT + tid;
+                Ls[tid] = (qi < Lq) ? p.lse[(long)hq * p.total_q + qs + qi] * 1.4426950408889634f : 0.f;
+                Ls[BT + tid] = (qi < Lq) ? p.delta[(long)hq * p.total_q + qs + qi] : 0.f;
+            }
+            __syncthreads();
+            const int q0 = qt * BT;
+            // S[q][key], dP[q][key]: "A" = Q / dO rows from LDS, "B" = K / V registers; lane = key, regs = 4 queries (4g + r) per 16-q tile j
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    bf16x8 qa = *(const bf16x8*)(Qs + (j * 16 + c) * STRIDE + ds * 64 + g * 16);
+                    bf16x8 oa = *(const bf16x8*)(Os + (j * 16 + c) * STRIDE + ds * 64 + g * 16);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ds], s[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, vf[ds], dp[j], 0, 0, 0);
+                }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                float e[8], f[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = 2 * ss + (u >> 2), r = u & 3;
+                    const int ql = j * 16 + 4 * g + r;   // query index inside the tile
+                    const int qi = q0 + ql;
+                    float pr = exp2f(s[j][r] * p.scale_log2 - Ls[ql]);
+                    const bool ok = (qi < Lq) && (key < Lk) && (!p.causal || key <= qi + shift);
+                    pr = ok ? pr : 0.f;
+                    e[u] = pr;
+                    f[u] = pr * (dp[j][r] - Ls[BT + ql]) * p.scale;
+                }
+                u32x4 a, b;
+                a[0] = pack_bf2(e[0], e[1]); a[1] = pack_bf2(e[2], e[3]); a[2] = pack_bf2(e[4], e[5]); a[3] = pack_bf2(e[6], e[7]);
+                b[0] = pack_bf2(f[0], f[1]); b[1] = pack_bf2(f[2], f[3]); b[2] = pack_bf2(f[4], f[5]); b[3] = pack_bf2(f[6], f[7]);
+                pf[ss] = __builtin_bit_cast(bf16x8, a);
+                dsf[ss] = __builtin_bit_cast(bf16x8, b);
+            }
+            // dV^T += dO^T . P ; dK^T += Q^T . dS   (k = queries, permuted exactly like the forward's P.V step)
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int roff = (ss * 32 + 4 * g + (c >> 2)) * STRIDE + (d * 16 + 4 * (c & 3)) * 2;
+                    bf16x4 ol = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(Os + roff));
+                    bf16x4 oh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(Os + roff + 16 * STRIDE));
+                    bf16x4 ql_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(Qs + roff));
+                    bf16x4 qh_ = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(Qs + roff + 16 * STRIDE));
+                    bf16x8 ot, qt8;
+                    ot[0] = ol[0]; ot[1] = ol[1]; ot[2] = ol[2]; ot[3] = ol[3]; ot[4] = oh[0]; ot[5] = oh[1]; ot[6] = oh[2]; ot[7] = oh[3];
+                    qt8[0] = ql_[0]; qt8[1] = ql_[1]; qt8[2] = ql_[2]; qt8[3] = ql_[3]; qt8[4] = qh_[0]; qt8[5] = qh_[1]; qt8[6] = qh_[2]; qt8[7] = qh_[3];
+                    dvacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pf[ss], dvacc[d], 0, 0, 0);
+                    dkacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt8, dsf[ss], dkacc[d], 0, 0, 0);
+                }
+        }
+    }
+    if (key < Lk) {
+        unsigned short* rk = p.dk + (long)(ks + key) * p.dk_st + (long)hk * p.dk_sh;
+        unsigned short* rv = p.dv + (long)(ks + key) * p.dv_st + (long)hk * p.dv_sh;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const int dd = d * 16 + 4 * g;
+            if (dd < p.D) {
+                u32x2 a, b;
+                a[0] = pack_bf2(dkacc[d][0], dkacc[d][1]); a[1] = pack_bf2(dkacc[d][2], dkacc[d][3]);
+                b[0] = pack_bf2(dvacc[d][0], dvacc[d][1]); b[1] = pack_bf2(dvacc[d][2], dvacc[d][3]);
+                *(u32x2*)(rk + dd) = a;
+                *(u32x2*)(rv + dd) = b;
+            }
+        }
+    }
+}
+
+template <int DP>
+static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipStream_t st) {
+    constexpr int QT = (DP >= 128) ? 1 : 2;
+    constexpr int BLOCK_M = 4 * QT * 16;
+    constexpr int LDS_DQ = 2 * BT * (DP * 2 + 32);
+    constexpr int LDS_DKV = 2 * BT * (DP * 2 + 32) + 2 * BT * 4;
+    auto kq = attn_bwd_dq_kernel<DP, QT, 4>;
+    auto kk = attn_bwd_dkv_kernel<DP, 4>;
+    static bool attr_done = false;
+    if (!attr_done && LDS_DKV > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+        if (e != hipSuccess) return fail(-(int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(a.total_q * a.Hq, 4)), dim3(256), 0, st, a);
+    RGA3_CHECK_LAUNCH("attn_delta_kernel");
+    hipLaunchKernelGGL(kq, dim3((unsigned)cdiv(max_q, BLOCK_M), (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DQ, st, a);
+    RGA3_CHECK_LAUNCH("attn_bwd_dq_kernel");
+    hipLaunchKernelGGL(kk, dim3((unsigned)cdiv(max_k, 64), (unsigned)a.Hkv, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+    RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel");
+    return 0;
+}
+
+}  // namespace rga3
+
+using namespace rga3;
+
+extern "C" int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                    void* dq, void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg,
+                                    int max_q, int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale,
+                                    int causal, void* stream) {
+    RGA3_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta_ws && cu_q && cu_k && strides16, "attn_bwd: null pointer");
+    RGA3_CHECK_ARG(nseg > 0 && max_q > 0 && max_k > 0 && total_q > 0, "attn_bwd: sizes");
+    RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attn_bwd: Hq=%d Hkv=%d", Hq, Hkv);
+    RGA3_CHECK_ARG(D >= 8 && D <= 128 && D % 8 == 0, "attn_bwd: head dim %d unsupported (multiple of 8, <= 128)", D);
+    for (int i = 0; i < 16; ++i) RGA3_CHECK_ARG(strides16[i] % 4 == 0, "attn_bwd: stride %d must be a multiple of 4 elements", i);
+    for (int i = 0; i < 10; ++i) RGA3_CHECK_ARG(strides16[i] % 8 == 0, "attn_bwd: input stride %d must be a multiple of 8 elements", i);
+    AttnBwdArgs a;
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v; a.o = (const unsigned short*)o;
+    a.dout = (const unsigned short*)dout; a.dq = (unsigned short*)dq; a.dk = (unsigned short*)dk; a.dv = (unsigned short*)dv;
+    a.lse = lse; a.delta = delta_ws; a.cu_q = cu_q; a.cu_k = cu_k;
+    a.q_st = strides16[0]; a.q_sh = strides16[1]; a.k_st = strides16[2]; a.k_sh = strides16[3]; a.v_st = strides16[4]; a.v_sh = strides16[5];
+    a.o_st = strides16[6]; a.o_sh = strides16[7]; a.do_st = strides16[8]; a.do_sh = strides16[9]; a.dq_st = strides16[10]; a.dq_sh = strides16[11];
+    a.dk_st = strides16[12]; a.dk_sh = strides16[13]; a.dv_st = strides16[14]; a.dv_sh = strides16[15];
+    a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.total_q = total_q; a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f; a.causal = causal;
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 32) return launch_bwd<32>(a, nseg, max_q, max_k, st);
+    if (D <= 64) return launch_bwd<64>(a, nseg, max_q, max_k, st);
+    if (D <= 96) return launch_bwd<96>(a, nseg, max_q, max_k, st);
+    return launch_bwd<128>(a, nseg, max_q, max_k, st);
+}

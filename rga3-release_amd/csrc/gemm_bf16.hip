@@ -363,6 +363,7 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 0: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 1>(a, st);
         case 1: return launch_cfg<256, 128, 2, 4, ACT, OUT_F32, 1>(a, st);
         case 2: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 1>(a, st);
+        case 3: return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 10: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 11: return launch_cfg<256, 128, 2, 4, ACT, OUT_F32, 0>(a, st);
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);

@@ -1,0 +1,224 @@
+// Backward / optimiser kernels of the training step (HBM-bound, 16 B per lane, fp32 math):
+// RMSNorm backward, SwiGLU backward on the interleaved gate/up layout, bf16 transpose (for dW = dY^T X through the NT
+// GEMM), CSR row-segment sums (embedding gradient), fused AdamW.
+#include "common.h"
+
+namespace rga3 {
+
+__device__ __forceinline__ void un8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pk8_(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// dx = r * g - x * r^3 * mean(g * x) (+ add), g = dy * w, r = rsqrt(mean(x^2) + eps); one wave per row.
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                          const unsigned short* __restrict__ dy, const unsigned short* __restrict__ add,
+                                                          unsigned short* __restrict__ dx, long rows, int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = dim / 8;
+    u32x4 xb[MAXC], gb[MAXC];
+    float ss = 0.f, sg = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            float fx[8], fd[8], fw[8];
+            xb[i] = *(const u32x4*)(x + row * dim + ch * 8);
+            un8(xb[i], fx);
+            un8(*(const u32x4*)(dy + row * dim + ch * 8), fd);
+            un8(*(const u32x4*)(w + ch * 8), fw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                fd[e] *= fw[e];
+                ss += fx[e] * fx[e];
+                sg += fd[e] * fx[e];
+            }
+            gb[i] = pk8_(fd);
+        }
+    }
+    ss = wave_sum(ss);
+    sg = wave_sum(sg);
+    const float r = rsqrtf(ss / (float)dim + eps);
+    const float coef = r * r * r * sg / (float)dim;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            float fx[8], fg[8], fa[8];
+            un8(xb[i], fx);
+            un8(gb[i], fg);
+            if (add) un8(*(const u32x4*)(add + row * dim + ch * 8), fa);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fg[e] = r * fg[e] - fx[e] * coef + (add ? fa[e] : 0.f);
+            *(u32x4*)(dx + row * dim + ch * 8) = pk8_(fg);
+        }
+    }
+}
+
+// gu [T, 2I] pre-activations in 16-column blocks (gate | up), da [T, I]  ->  dgu [T, 2I] (same interleave)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const unsigned short* __restrict__ gu, const unsigned short* __restrict__ da,
+                                                         unsigned short* __restrict__ dgu, long T, long I) {
+    const long nch = I / 8;  // 8 outputs per thread (half of a 16-block)
+    const long total = T * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long ch = i % nch, t = i / nch;
+        const long blk = ch / 2, half = ch % 2;
+        const long goff = t * 2 * I + blk * 32 + half * 8;
+        float g[8], u[8], d[8], dg[8], du[8];
+        un8(*(const u32x4*)(gu + goff), g);
+        un8(*(const u32x4*)(gu + goff + 16), u);
+        un8(*(const u32x4*)(da + t * I + ch * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.f / (1.f + __expf(-g[e]));
+            const float silu = g[e] * sg;
+            du[e] = d[e] * silu;
+            dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
+        }
+        *(u32x4*)(dgu + goff) = pk8_(dg);
+        *(u32x4*)(dgu + goff + 16) = pk8_(du);
+    }
+}
+
+// out[c, r] = in[r, c] for 16-bit elements, 64x64 tiles through LDS (padded rows)
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, long R, long C,
+                                                          long ldi, long ldo) {
+    __shared__ unsigned short tile[64][66];
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const long r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[r * ldi + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const long c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[c * ldo + r] = tile[tx][i];
+    }
+}
+
+// out[u, :] = sum_{j in [off[u], off[u+1])} x[rows[j], :]   (fp32 accumulate, bf16 out); one block per output row
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const unsigned short* __restrict__ x, const long* __restrict__ rows,
+                                                               const long* __restrict__ off, unsigned short* __restrict__ out, int dim, long ldx) {
+    const long u = blockIdx.x;
+    const long a = off[u], b = off[u + 1];
+    for (int ch = threadIdx.x; ch < dim / 8; ch += 256) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long j = a; j < b; ++j) {
+            float f[8];
+            un8(*(const u32x4*)(x + rows[j] * ldx + ch * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+        *(u32x4*)(out + u * dim + ch * 8) = pk8_(acc);
+    }
+}
+
+// AdamW on bf16 parameters with fp32 moments and an fp32 master copy (decoupled weight decay, bias-corrected)
+__global__ __launch_bounds__(256) void adamw_kernel(unsigned short* __restrict__ p, float* __restrict__ master, const unsigned short* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, float gscale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gr = bf2f(g[i]) * gscale;
+        float w = master[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gr;
+        const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mi;
+        v[i] = vi;
+        w = w * (1.f - lr * wd) - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        master[i] = w;
+        p[i] = f2bf(w);
+    }
+}
+
+// sum of squares of a bf16 tensor into *out (fp32 atomic) — global grad-norm for clipping
+__global__ __launch_bounds__(256) void sumsq_kernel(const unsigned short* __restrict__ g, float* __restrict__ out, long n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = bf2f(g[i]);
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+static inline unsigned g1(long total, long cap = 256L * 32) {
+    long b = cdiv(total, 256);
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace rga3
+
+using namespace rga3;
+typedef const unsigned short* cus;
+typedef unsigned short* us;
+
+extern "C" int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim,
+                                float eps, void* stream) {
+    RGA3_CHECK_ARG(x && weight && dy && dx && rows > 0 && dim > 0 && dim % 8 == 0 && dim <= 8192, "rmsnorm_bwd: bad args");
+    dim3 grid((unsigned)cdiv(rows, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (dim <= 2048) hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, grid, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (cus)add, (us)dx, (long)rows, (int)dim, eps);
+    else if (dim <= 4096) hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (cus)add, (us)dx, (long)rows, (int)dim, eps);
+    else hipLaunchKernelGGL(rmsnorm_bwd_kernel<16>, grid, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (cus)add, (us)dx, (long)rows, (int)dim, eps);
+    RGA3_CHECK_LAUNCH("rmsnorm_bwd");
+    return 0;
+}
+
+extern "C" int rga3_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t T, int64_t I, void* stream) {
+    RGA3_CHECK_ARG(gu && da && dgu && T > 0 && I > 0 && I % 16 == 0, "swiglu_bwd: bad args");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(g1(T * (I / 8))), dim3(256), 0, (hipStream_t)stream, (cus)gu, (cus)da, (us)dgu, (long)T, (long)I);
+    RGA3_CHECK_LAUNCH("swiglu_bwd");
+    return 0;
+}
+
+extern "C" int rga3_transpose16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, void* stream) {
+    RGA3_CHECK_ARG(in && out && R > 0 && C > 0 && ld_in >= C && ld_out >= R, "transpose16: bad args");
+    RGA3_CHECK_ARG(cdiv(R, 64) <= 65535, "transpose16: too many rows");
+    hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, (cus)in, (us)out, (long)R,
+                       (long)C, (long)ld_in, (long)ld_out);
+    RGA3_CHECK_LAUNCH("transpose16");
+    return 0;
+}
+
+extern "C" int rga3_segment_sum_rows(const void* x, const int64_t* rows, const int64_t* offsets, void* out, int64_t n_out, int64_t dim,
+                                     int64_t ldx, void* stream) {
+    RGA3_CHECK_ARG(x && rows && offsets && out && n_out > 0 && dim % 8 == 0 && ldx % 8 == 0, "segment_sum_rows: bad args");
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((unsigned)n_out), dim3(256), 0, (hipStream_t)stream, (cus)x, (const long*)rows, (const long*)offsets,
+                       (us)out, (int)dim, (long)ldx);
+    RGA3_CHECK_LAUNCH("segment_sum_rows");
+    return 0;
+}
+
+extern "C" int rga3_adamw_step(void* param, float* master, const void* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    RGA3_CHECK_ARG(param && master && grad && m && v && n > 0 && step >= 1, "adamw_step: bad args");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, (us)param, master, (cus)grad, m, v, (long)n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2, grad_scale);
+    RGA3_CHECK_LAUNCH("adamw_step");
+    return 0;
+}
+
+extern "C" int rga3_sumsq_accum(const void* g, float* out, int64_t n, void* stream) {
+    RGA3_CHECK_ARG(g && out && n > 0, "sumsq_accum: bad args");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(g1(n, 2048)), dim3(256), 0, (hipStream_t)stream, (cus)g, out, (long)n);
+    RGA3_CHECK_LAUNCH("sumsq_accum");
+    return 0;
+}

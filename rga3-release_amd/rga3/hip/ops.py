@@ -315,3 +315,77 @@ def bce_dice_sums(logits, targets):
         return out
     _lib.check(_lib.load().rga3_bce_dice_sums(logits.data_ptr(), targets.data_ptr(), out.data_ptr(), n, logits[0].numel(), _stream()), "bce_dice_sums")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ training-step kernels
+def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, max_q: int, max_k: int, scale: float, causal: bool, dq=None, dk=None, dv=None):
+    """Gradients of attn_varlen w.r.t. q, k, v (bf16, same [T, H, D] shapes; outputs may be strided views)."""
+    import ctypes
+    _need_cuda(q, k, v, o, dout, lse)
+    Tq, Hq, D = q.shape
+    Hkv = k.shape[1]
+    dq = torch.empty_like(q) if dq is None else dq
+    dk = torch.empty((k.shape[0], Hkv, D), dtype=torch.bfloat16, device=q.device) if dk is None else dk
+    dv = torch.empty((k.shape[0], Hkv, D), dtype=torch.bfloat16, device=q.device) if dv is None else dv
+    for t in (q, k, v, o, dout, dq, dk, dv):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1
+    delta = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)
+    st = (ctypes.c_int64 * 16)(q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
+                               dout.stride(0), dout.stride(1), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1))
+    rc = _lib.load().rga3_attn_varlen_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dq.data_ptr(),
+                                          dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), cu_q.numel() - 1, int(max_q),
+                                          int(max_k), Tq, Hq, Hkv, D, ctypes.cast(st, ctypes.c_void_p), float(scale), int(bool(causal)), _stream())
+    _lib.check(rc, "attn_varlen_bwd")
+    return dq, dk, dv
+
+
+def rmsnorm_bwd(x, weight, dy, eps: float, add=None):
+    _need_cuda(x, weight, dy, add)
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype == torch.bfloat16 and (add is None or add.is_contiguous())
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().rga3_rmsnorm_bwd(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), _ptr(add), dx.data_ptr(), x.shape[0], x.shape[1], float(eps),
+                                            _stream()), "rmsnorm_bwd")
+    return dx
+
+
+def swiglu_bwd(gu, da):
+    _need_cuda(gu, da)
+    assert gu.is_contiguous() and da.is_contiguous() and gu.shape[1] == 2 * da.shape[1]
+    dgu = torch.empty_like(gu)
+    _lib.check(_lib.load().rga3_swiglu_bwd(gu.data_ptr(), da.data_ptr(), dgu.data_ptr(), gu.shape[0], da.shape[1], _stream()), "swiglu_bwd")
+    return dgu
+
+
+def transpose(x):
+    """[R, C] bf16 (row stride free) -> contiguous [C, R]."""
+    _need_cuda(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.element_size() == 2
+    R, C = x.shape
+    out = torch.empty((C, R), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().rga3_transpose16(x.data_ptr(), out.data_ptr(), R, C, x.stride(0), R, _stream()), "transpose16")
+    return out
+
+
+def segment_sum_rows(x, rows, offsets):
+    _need_cuda(x, rows, offsets)
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1 and rows.dtype == torch.int64 and offsets.dtype == torch.int64
+    n = offsets.numel() - 1
+    out = torch.empty((n, x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    if n > 0:
+        _lib.check(_lib.load().rga3_segment_sum_rows(x.data_ptr(), rows.data_ptr(), offsets.data_ptr(), out.data_ptr(), n, x.shape[1], x.stride(0), _stream()),
+                   "segment_sum_rows")
+    return out
+
+
+def adamw_step_(param, master, grad, m, v, lr, beta1, beta2, eps, weight_decay, step: int, grad_scale: float = 1.0):
+    _need_cuda(param, master, grad, m, v)
+    assert param.dtype == grad.dtype == torch.bfloat16 and master.dtype == m.dtype == v.dtype == torch.float32
+    assert param.is_contiguous() and grad.is_contiguous() and master.is_contiguous()
+    _lib.check(_lib.load().rga3_adamw_step(param.data_ptr(), master.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(), float(lr),
+                                           float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()), "adamw_step")
+
+
+def sumsq_accum_(g, out):
+    _need_cuda(g, out)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous() and out.dtype == torch.float32
+    _lib.check(_lib.load().rga3_sumsq_accum(g.data_ptr(), out.data_ptr(), g.numel(), _stream()), "sumsq_accum")

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-CANDIDATES = (10, 11, 12, 1)   # 256x256, 256x128, 128x128 (single-phase loop) and 256x128 register-pipelined
+CANDIDATES = (10, 11, 12, 3, 1)   # 256x256, 256x128, 128x128, 128x256 (single-phase loop) and 256x128 register-pipelined
 _cache = {}
 _enabled = os.environ.get("RGA3_GEMM_TUNE", "1") != "0"
 

@@ -368,7 +368,10 @@ class DecoderAttention(nn.Module):
         if _is_plain(self.q_proj, self.k_proj, self.v_proj):
             w, b = self._packed()
             qkv = ops.gemm(h, w, b).view(T, Hq + 2 * Hk, D)
-        else:  # wrapped projections (e.g. PEFT LoRA): honour the wrappers, then assemble the fused buffer
+        elif all(type(m).__name__ in ("Linear", "LoRALinear") and type(m).__module__.startswith("rga3.") for m in (self.q_proj, self.k_proj, self.v_proj)):
+            from .qwen_train import qkv_with_lora  # native LoRA: fused projection + in-place low-rank updates
+            qkv = qkv_with_lora(self, h)[0].view(T, Hq + 2 * Hk, D)
+        else:  # foreign wrappers (e.g. PEFT): honour them, then assemble the fused buffer
             qkv = torch.cat([self.q_proj(h), self.k_proj(h), self.v_proj(h)], dim=-1).view(T, Hq + 2 * Hk, D)
         ops.rope_(qkv, cos, sin, 0, Hq + Hk)
         q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
@@ -527,8 +530,14 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
 
     # -- multimodal embedding assembly ---------------------------------------------------------------------
     def _embed(self, ids_packed_np, ids_packed_dev, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw):
-        x = ops.gather_rows(self.model.embed_tokens.weight, ids_packed_dev)
+        w = self.model.embed_tokens.weight
         c = self.config
+        if torch.is_grad_enabled() and w.requires_grad:
+            from .qwen_train import EmbedFn
+            text_rows = np.flatnonzero((ids_packed_np != c.image_token_id) & (ids_packed_np != c.video_token_id))
+            x = EmbedFn.apply(w, ids_packed_dev, ids_packed_np, text_rows)
+        else:
+            x = ops.gather_rows(w, ids_packed_dev)
         for px, grid, tok in ((pixel_values, image_grid_thw, c.image_token_id), (pixel_values_videos, video_grid_thw, c.video_token_id)):
             if px is None:
                 continue
@@ -582,6 +591,12 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
         x = self._embed(ids_packed_np, ids_packed, pixel_values if past_len == 0 else None, image_grid_thw,
                         pixel_values_videos if past_len == 0 else None, video_grid_thw)
+        trainable = torch.is_grad_enabled() and labels is not None and cache is None and any(p.requires_grad for p in self.parameters())
+        if trainable:
+            from .qwen_train import lm_train_forward
+            loss, hn = lm_train_forward(self, x, pos3, cu, int(lens.max()), labels.detach().cpu().numpy(), am_cur, flat_keep, lens)
+            full = hn if flat_keep.size == B * S else ops.scatter_rows_(torch.zeros((B * S, hn.shape[-1]), dtype=hn.dtype, device=hn.device), keep_dev, hn)
+            return CausalLMOutput(loss=loss, logits=None, past_key_values=None, hidden_states=(full.view(B, S, -1),), rope_deltas=self.rope_deltas)
         if cache is not None:
             cache.begin(lens.tolist())
         h, hs = self.model(x, pos3, cu, int(lens.max()), cache, collect_hidden=bool(output_hidden_states))

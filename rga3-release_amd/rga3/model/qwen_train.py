@@ -1,0 +1,267 @@
+"""Training-step autograd for the Qwen2.5 decoder on HIP kernels (LoRA fine-tuning as in reference train_joint.py).
+
+What is trainable on the LLM side of the reference recipe (train_joint.py:193-251, run_torchrun.sh:30-31): LoRA r=128 / alpha=256
+on q_proj and v_proj of every decoder layer, embed_tokens, lm_head (plus text_hidden_fcs and the SAM2 mask decoder on the mask
+path).  Base projections, norms and the whole ViT are frozen.
+
+Design: ONE autograd node per decoder layer (DecoderLayerFn).  Its forward runs the fused inference kernels under no_grad and
+keeps only the layer input (activation checkpointing == reference's gradient_checkpointing_enable, train_joint.py:188); its
+backward recomputes the layer and back-propagates by hand with the same kernel library: dX GEMMs against cached transposed
+packs of the frozen weights, flash-style attention backward, fused RMSNorm / SwiGLU backward, inverse RoPE, and the small
+LoRA dA/dB products.  The LM head only evaluates the rows that carry a label.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..hip import ops
+from .qwen2_5_vl import GatedMLP, Linear, _versions
+
+
+# ------------------------------------------------------------------------------------------------ LoRA
+class LoRALinear(Linear):
+    """nn.Linear + low-rank update, parameter names as PEFT writes them (<name>.lora_A.default.weight, ...)."""
+
+    def __init__(self, base: Linear, r: int, alpha: float, dropout: float = 0.0):
+        super().__init__(base.in_features, base.out_features, bias=base.bias is not None, device=base.weight.device, dtype=base.weight.dtype)
+        self.weight, self.bias = base.weight, base.bias
+        self.weight.requires_grad_(False)
+        if self.bias is not None:
+            self.bias.requires_grad_(False)
+        mk = lambda i, o: Linear(i, o, bias=False, device=base.weight.device, dtype=base.weight.dtype)
+        self.lora_A = nn.ModuleDict({"default": mk(base.in_features, r)})
+        self.lora_B = nn.ModuleDict({"default": mk(r, base.out_features)})
+        nn.init.kaiming_uniform_(self.lora_A["default"].weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_B["default"].weight)
+        self.scaling = alpha / r
+        self.r = r
+        if dropout != 0.0:
+            raise NotImplementedError("LoRA dropout > 0 is not implemented on the HIP training path yet (reference uses 0.05)")
+
+    def forward(self, x, residual=None, act="none"):
+        y = super().forward(x, residual=residual, act=act)
+        t = self.lora_A["default"](x.reshape(-1, x.shape[-1]))
+        bs = (self.lora_B["default"].weight.detach() * self.scaling).to(t.dtype)
+        y2 = y.view(-1, y.shape[-1])
+        ops.gemm(t, bs, residual=y2, out=y2)
+        return y
+
+
+def add_lora(model: nn.Module, r=128, alpha=256, dropout=0.0, targets=("q_proj", "v_proj"),
+             exclude=("sam_model", "grounding_encodervisual", "text_hidden_fcs")):
+    """Replace matching Linear modules by LoRALinear, with the name filter of reference train_joint.py:199-212 (including its
+    missing comma, which makes SAM2's q_proj / v_proj LoRA targets too)."""
+    hits = []
+    for name, mod in list(model.named_modules()):
+        if isinstance(mod, nn.Linear) and not isinstance(mod, LoRALinear) and all(x not in name for x in exclude) and any(x in name for x in targets):
+            parent = model
+            parts = name.split(".")
+            for p in parts[:-1]:
+                parent = getattr(parent, p)
+            setattr(parent, parts[-1], LoRALinear(mod, r, alpha, dropout))
+            hits.append(name)
+    return hits
+
+
+# ------------------------------------------------------------------------------------------------ transposed weight packs
+def _wt(owner, key, *srcs, build):
+    """Cached derived tensor keyed by the versions of its sources (frozen weights never change -> built once)."""
+    cache = owner.__dict__.setdefault("_wt_cache", {})
+    ver = _versions(*srcs)
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        with torch.no_grad():
+            cache[key] = (ver, build())
+    return cache[key][1]
+
+
+def _lora_parts(lin):
+    if isinstance(lin, LoRALinear):
+        return lin.lora_A["default"].weight, lin.lora_B["default"].weight, lin.scaling
+    return None
+
+
+def qkv_with_lora(at, h1):
+    """Fused q/k/v projection (+ LoRA updates on q and v accumulated in place); returns (qkv2 [T, (Hq+2Hk)D], tq, tv)."""
+    Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
+    wqkv, bqkv = at._packed()
+    qkv2 = ops.gemm(h1, wqkv, bqkv)
+    lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
+    tq = tv = None
+    if lq is not None:
+        tq = ops.gemm(h1, lq[0])
+        oq = qkv2[:, : Hq * D]
+        ops.gemm(tq, (lq[1].detach() * lq[2]).to(tq.dtype), residual=oq, out=oq)
+    if lv is not None:
+        tv = ops.gemm(h1, lv[0])
+        ov = qkv2[:, (Hq + Hk) * D:]
+        ops.gemm(tv, (lv[1].detach() * lv[2]).to(tv.dtype), residual=ov, out=ov)
+    return qkv2, tq, tv
+
+
+class DecoderLayerFn(torch.autograd.Function):
+    """y = DecoderLayer(x); saves x only, recomputes in backward."""
+
+    @staticmethod
+    def forward(ctx, x, aq, bq, av, bv, layer, cos, sin, cu, max_len):
+        with torch.no_grad():
+            y = layer(x, cos, sin, cu, max_len, None)
+        ctx.layer, ctx.cos, ctx.sin, ctx.cu, ctx.max_len = layer, cos, sin, cu, max_len
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        layer, cos, sin, cu, max_len = ctx.layer, ctx.cos, ctx.sin, ctx.cu, ctx.max_len
+        at, mlp = layer.self_attn, layer.mlp
+        Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
+        T = x.shape[0]
+        dy = dy.contiguous()
+        with torch.no_grad():
+            # ---- recompute forward pieces the backward needs
+            w1, w2 = layer.input_layernorm, layer.post_attention_layernorm
+            h1 = ops.rmsnorm(x, w1.weight, w1.variance_epsilon)
+            wqkv, bqkv = at._packed()
+            lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
+            qkv2, tq, tv = qkv_with_lora(at, h1)
+            qkv = qkv2.view(T, Hq + 2 * Hk, D)
+            ops.rope_(qkv, cos, sin, 0, Hq + Hk)
+            q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
+            att, lse = ops.attn_varlen(q, k, v, cu, cu, max_len, D ** -0.5, causal=True, return_lse=True)
+            x1 = ops.gemm(att.view(T, Hq * D), at.o_proj.weight, residual=x)
+            h2 = ops.rmsnorm(x1, w2.weight, w2.variance_epsilon)
+            wgu, bgu, wd = mlp._packed()
+            gu = ops.gemm(h2, wgu, bgu)                                   # pre-activations, interleaved [T, 2*Ip]
+            # ---- MLP backward
+            wd_t = _wt(mlp, "wd_t", mlp.down_proj.weight, build=lambda: ops.transpose(wd))            # [Ip, H]
+            wgu_t = _wt(mlp, "wgu_t", mlp.gate_proj.weight, mlp.up_proj.weight, build=lambda: ops.transpose(wgu))  # [H, 2Ip]
+            da = ops.gemm(dy, wd_t)
+            dgu = ops.swiglu_bwd(gu, da)
+            del gu, da
+            dh2 = ops.gemm(dgu, wgu_t)
+            del dgu
+            dx1 = ops.rmsnorm_bwd(x1, w2.weight, dh2, w2.variance_epsilon, add=dy)
+            # ---- attention backward
+            wo_t = _wt(at, "wo_t", at.o_proj.weight, build=lambda: ops.transpose(at.o_proj.weight.detach()))   # [HqD, H]
+            datt = ops.gemm(dx1, wo_t).view(T, Hq, D)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_varlen_bwd(q, k, v, att, datt, lse, cu, cu, max_len, max_len, D ** -0.5, True, dq=dqkv[:, :Hq], dk=dqkv[:, Hq:Hq + Hk],
+                                dv=dqkv[:, Hq + Hk:])
+            ops.rope_(dqkv, cos, (-sin).contiguous(), 0, Hq + Hk)   # inverse rotation (cos/sin tables are symmetric in the two halves)
+            dqkv2 = dqkv.view(T, (Hq + 2 * Hk) * D)
+            wqkv_t = _wt(at, "wqkv_t", at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, build=lambda: ops.transpose(wqkv))   # [H, (Hq+2Hk)D]
+            dh1 = ops.gemm(dqkv2, wqkv_t)
+            grads = [None, None, None, None]
+            if lq is not None or lv is not None:
+                h1_t = ops.transpose(h1)                                                # [H, T]
+                for slot, lp, t_, cols in ((0, lq, tq, (0, Hq * D)), (2, lv, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D))):
+                    if lp is None:
+                        continue
+                    A, B, s = lp
+                    dsl = dqkv2[:, cols[0]:cols[1]]                                    # [T, out]
+                    Tp = (T + 7) // 8 * 8
+                    dsl_t = ops.transpose(dsl)                                          # [out, T]
+                    t_t = ops.transpose(t_)                                             # [r, T]
+                    if Tp != T:
+                        dsl_t, t_t = ops.pad_cols(dsl_t, Tp), ops.pad_cols(t_t, Tp)
+                    dB = ops.gemm(dsl_t, t_t)                                           # [out, r] = dsl^T t
+                    dB = (dB.float() * s).to(B.dtype)
+                    dt = ops.gemm(dsl, (ops.transpose(B.detach()) * s).to(B.dtype))     # [T, r] = s * dsl B
+                    dt_t = ops.transpose(dt)
+                    h1_tp = h1_t
+                    if Tp != T:
+                        dt_t, h1_tp = ops.pad_cols(dt_t, Tp), ops.pad_cols(h1_t, Tp)
+                    dA = ops.gemm(dt_t, h1_tp)                                          # [r, H] = dt^T h1
+                    ops.gemm(dt, ops.transpose(A.detach()), residual=dh1, out=dh1)      # dh1 += dt A
+                    grads[slot], grads[slot + 1] = dA, dB
+            dx = ops.rmsnorm_bwd(x, w1.weight, dh1, w1.variance_epsilon, add=dx1)
+        return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None)
+
+
+class EmbedFn(torch.autograd.Function):
+    """x = embed_tokens[ids]; backward builds the dense table gradient from CSR segment sums over duplicate ids."""
+
+    @staticmethod
+    def forward(ctx, weight, ids_dev, ids_np, grad_rows_np):
+        ctx.ids_np, ctx.grad_rows_np, ctx.shape = ids_np, grad_rows_np, weight.shape
+        return ops.gather_rows(weight, ids_dev)
+
+    @staticmethod
+    def backward(ctx, dx):
+        rows = ctx.grad_rows_np                      # packed positions whose embedding came from the table (not vision placeholders)
+        ids = ctx.ids_np[rows]
+        order = np.argsort(ids, kind="stable")
+        uniq, counts = np.unique(ids[order], return_counts=True)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        dev = dx.device
+        seg = ops.segment_sum_rows(dx.contiguous(), torch.from_numpy(rows[order].astype(np.int64)).to(dev), torch.from_numpy(off).to(dev))
+        dW = torch.zeros(ctx.shape, dtype=dx.dtype, device=dev)
+        ops.scatter_rows_(dW, torch.from_numpy(uniq.astype(np.int64)).to(dev), seg)
+        return dW, None, None, None
+
+
+class NormHeadCEFn(torch.autograd.Function):
+    """loss = mean CE(lm_head(norm(h))[valid rows], labels): evaluates only rows with a label (value-identical to the reference's
+    full-logits CE, HF ForCausalLMLoss).  Also returns the post-norm hidden states (no grad path through them yet)."""
+
+    @staticmethod
+    def forward(ctx, h, lm_w, norm_w, eps, valid_rows_dev, targets_dev, n_valid):
+        hn = ops.rmsnorm(h, norm_w, eps)
+        if n_valid == 0:
+            ctx.n = 0
+            ctx.hshape = h.shape
+            ctx.mark_non_differentiable(hn)
+            return torch.zeros((), device=h.device, dtype=torch.float32), hn
+        hv = ops.gather_rows(hn, valid_rows_dev)
+        logits = ops.gemm(hv, lm_w)
+        row_loss, dlogits = ops.cross_entropy_rows(logits, targets_dev, want_grad=True, grad_scale=1.0 / n_valid)
+        ctx.save_for_backward(h, lm_w, norm_w, hv, dlogits, valid_rows_dev)
+        ctx.eps, ctx.n = eps, n_valid
+        ctx.mark_non_differentiable(hn)
+        return row_loss.sum() / n_valid, hn
+
+    @staticmethod
+    def backward(ctx, gloss, ghn):
+        if ctx.n == 0:
+            return torch.zeros(ctx.hshape, dtype=torch.bfloat16, device=gloss.device), None, None, None, None, None, None
+        h, lm_w, norm_w, hv, dlogits, rows = ctx.saved_tensors
+        n = ctx.n
+        with torch.no_grad():
+            if float(gloss) != 1.0:
+                dlogits = (dlogits.float() * float(gloss)).to(dlogits.dtype)
+            npad = (n + 7) // 8 * 8
+            dl_t = ops.transpose(dlogits)                       # [V, n]
+            hv_t = ops.transpose(hv)                            # [H, n]
+            if npad != n:
+                dl_t, hv_t = ops.pad_cols(dl_t, npad), ops.pad_cols(hv_t, npad)
+            dW = ops.gemm(dl_t, hv_t) if lm_w.requires_grad else None      # [V, H]
+            dhv = ops.gemm(dlogits, ops.transpose(lm_w.detach()))            # [n, H]
+            dhn = torch.zeros_like(h)
+            ops.scatter_rows_(dhn, rows, dhv)
+            dh = ops.rmsnorm_bwd(h, norm_w, dhn, ctx.eps)
+        return dh, dW, None, None, None, None, None
+
+
+def lm_train_forward(model, x, pos3, cu, max_len, labels_np, am_cur, flat_keep, lens):
+    """Decoder + LM head + CE with autograd nodes; x [T, H] packed embeddings (requires_grad if embed_tokens is trainable)."""
+    tm = model.model
+    cos, sin = tm.mrope_tables(pos3)
+    for layer in tm.layers:
+        at = layer.self_attn
+        lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
+        x = DecoderLayerFn.apply(x, lq[0] if lq else None, lq[1] if lq else None, lv[0] if lv else None, lv[1] if lv else None, layer, cos, sin,
+                                 cu, max_len)
+    B, S = labels_np.shape
+    nxt = np.full((B, S), -100, dtype=np.int64)
+    nxt[:, :-1] = labels_np[:, 1:]
+    tgt = nxt.reshape(-1)[flat_keep]
+    valid = np.flatnonzero(tgt != -100)
+    dev = x.device
+    loss, hn = NormHeadCEFn.apply(x, model.lm_head.weight, tm.norm.weight, tm.norm.variance_epsilon, torch.from_numpy(valid.astype(np.int64)).to(dev),
+                                  torch.from_numpy(tgt[valid]).to(dev), int(valid.size))
+    return loss, hn

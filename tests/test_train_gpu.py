@@ -1,0 +1,132 @@
+"""GPU parity of the training-step kernels and of the LLM fwd+bwd path (LoRA + lm_head + embed_tokens gradients) against
+torch-autograd fp32 references / the fp32 oracle.  bf16 pipeline vs fp32: gradient rel-L2 <= 3e-2, loss <= 1e-2 relative."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import kernels_ref as R
+from oracle import qwen25vl as Q
+from oracle.detweights import det_tensor
+from tests.qwen_tiny import det_params, gold, oracle_cfg, product_cfg_kwargs, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+BWD_CASES = [([300, 77, 1], None, 4, 2, 128, True), ([128], None, 7, 1, 128, True), ([9, 9], [64, 64], 8, 8, 16, False),
+             ([64, 64], [9, 9], 8, 8, 16, False), ([70], [70], 2, 2, 32, False), ([5], [133], 2, 2, 64, True), ([200], None, 2, 2, 80, False)]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_attention_backward(dev, case):
+    from rga3.hip import ops
+
+    lq, lk, Hq, Hkv, D, causal = case
+    lk = lk or lq
+    cu_q = torch.tensor([0] + list(torch.tensor(lq).cumsum(0)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(torch.tensor(lk).cumsum(0)), dtype=torch.int32)
+    Tq, Tk = int(cu_q[-1]), int(cu_k[-1])
+    q, k, v = rnd((Tq, Hq, D), dev, seed=1), rnd((Tk, Hkv, D), dev, seed=2), rnd((Tk, Hkv, D), dev, seed=3)
+    do = rnd((Tq, Hq, D), dev, seed=4)
+    scale = D ** -0.5
+    o, lse = ops.attn_varlen(q, k, v, cu_q.to(dev), cu_k.to(dev), max(lq), scale, causal, return_lse=True)
+    dq, dk, dv = ops.attn_varlen_bwd(q, k, v, o, do, lse, cu_q.to(dev), cu_k.to(dev), max(lq), max(lk), scale, causal)
+    qf, kf, vf = (t.float().cpu().requires_grad_(True) for t in (q, k, v))
+    ref, _ = R.attn_varlen_ref(qf, kf, vf, cu_q, cu_k, scale, causal)
+    ref.backward(do.float().cpu())
+    assert rel_l2(dq, qf.grad) < 2e-2 and rel_l2(dk, kf.grad) < 2e-2 and rel_l2(dv, vf.grad) < 2e-2, case
+
+
+def test_rmsnorm_swiglu_backward_and_transpose(dev):
+    from rga3.hip import ops
+
+    x, w, dy, add = rnd((37, 256), dev, 2.0, 1), (1 + 0.1 * torch.randn(256)).to(torch.bfloat16).to(dev), rnd((37, 256), dev, seed=2), rnd((37, 256), dev, seed=3)
+    xf = x.float().cpu().requires_grad_(True)
+    R.rmsnorm_ref(xf, w.cpu(), 1e-6).backward(dy.float().cpu())
+    assert rel_l2(ops.rmsnorm_bwd(x, w, dy, 1e-6, add=add), xf.grad + add.float().cpu()) < 1e-2
+    T, I = 19, 64
+    gu, da = rnd((T, 2 * I), dev, seed=4), rnd((T, I), dev, seed=5)
+    gf = gu.float().cpu().requires_grad_(True)
+    gb = gf.view(T, I // 16, 2, 16)
+    (F.silu(gb[:, :, 0]) * gb[:, :, 1]).reshape(T, I).backward(da.float().cpu())
+    assert rel_l2(ops.swiglu_bwd(gu, da), gf.grad) < 1e-2
+    m = rnd((130, 77), dev, seed=6)
+    assert torch.equal(ops.transpose(m).cpu(), m.cpu().t().contiguous())
+    assert torch.equal(ops.transpose(m[:, :40]).cpu(), m[:, :40].cpu().t().contiguous())
+
+
+def test_segment_sum_and_adamw(dev):
+    from rga3.hip import ops
+
+    x = rnd((20, 64), dev, seed=1)
+    rows = torch.tensor([3, 5, 5, 0, 19, 7, 7, 7])
+    off = torch.tensor([0, 1, 3, 5, 8])
+    out = ops.segment_sum_rows(x, rows.to(dev), off.to(dev)).float().cpu()
+    ref = torch.stack([x.float().cpu()[rows[off[i]:off[i + 1]]].sum(0) for i in range(4)])
+    assert rel_l2(out, ref) < 5e-3
+    p = torch.randn(1000)
+    g = torch.randn(1000)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    pb, master = p.to(torch.bfloat16).to(dev), p.clone().to(dev)
+    m, v = torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for step in range(1, 4):
+        gb = g.to(torch.bfloat16)
+        pr.grad = gb.float()
+        opt.step()
+        ops.adamw_step_(pb, master, gb.to(dev), m, v, 1e-2, 0.9, 0.95, 1e-8, 0.1, step)
+    assert (master.cpu() - pr.data).abs().max().item() < 1e-5
+    acc = torch.zeros(1, device=dev)
+    ops.sumsq_accum_(g.to(torch.bfloat16).to(dev), acc)
+    assert abs(acc.item() - g.to(torch.bfloat16).float().pow(2).sum().item()) / acc.item() < 1e-4
+
+
+def _build_lora_model(dev, G):
+    from rga3.model.qwen2_5_vl import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    from rga3.model.qwen_train import add_lora
+
+    m = Qwen2_5_VLForConditionalGeneration(Qwen2_5_VLConfig(**product_cfg_kwargs()))
+    m.load_state_dict(det_params(G, bf16_round=False), strict=True)
+    hits = add_lora(m, r=8, alpha=16)
+    assert len(hits) == 4
+    lora = {}
+    for n, p in m.named_parameters():
+        if "lora_" in n:
+            p.data = det_tensor(n, tuple(p.shape), 0.2, seed=11)
+            lora[n] = p.data.clone()
+    m = m.to(torch.bfloat16).to(dev)
+    for n, p in m.named_parameters():
+        p.requires_grad_(("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight"))
+    return m, lora
+
+
+def test_llm_training_step_gradients(dev):
+    G = gold()
+    model, lora = _build_lora_model(dev, G)
+    px = torch.cat([det_tensor("pixel_values_full0", (192, 1176), 1.0, seed=5), det_tensor("pixel_values_full1", (192, 1176), 1.0, seed=6)], 0).to(torch.bfloat16)
+    ids, am, labels = (torch.from_numpy(G[k]) for k in ("full_input_ids", "full_attention_mask", "full_labels"))
+    out = model(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev), pixel_values_videos=px.to(dev),
+                video_grid_thw=torch.from_numpy(G["full_grid"]), second_per_grid_ts=torch.tensor([1.0, 1.0]), output_hidden_states=True)
+    out.loss.backward()
+    # oracle: same weights rounded to bf16, fp32 autograd
+    P = det_params(G)
+    P.update({k: v.to(torch.bfloat16).float() for k, v in lora.items()})
+    P["lora_scaling"] = 2.0
+    train_keys = [k for k in P if isinstance(P[k], torch.Tensor) and ("lora_" in k or k in ("lm_head.weight", "model.embed_tokens.weight"))]
+    for k in train_keys:
+        P[k].requires_grad_(True)
+    ref = Q.forward(P, oracle_cfg(), ids, am, labels=labels, pixel_values_videos=px.float(), video_grid_thw=G["full_grid"], second_per_grid_ts=np.array([1.0, 1.0]))
+    ref["loss"].backward()
+    assert abs(out.loss.item() - ref["loss"].item()) / ref["loss"].item() < 1e-2
+    got = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
+    assert all(g is not None for g in got.values())
+    for k in train_keys:
+        tol = 5e-2 if "lora_" in k else 3e-2
+        assert rel_l2(got[k], P[k].grad) < tol, (k, rel_l2(got[k], P[k].grad))
+    m = am.bool()
+    assert rel_l2(out.hidden_states[-1][m], ref["hidden"][m].detach()) < 2e-2
