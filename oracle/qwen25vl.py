@@ -292,6 +292,10 @@ def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, pa
         am = attention_mask.bool()
         assert am.shape[1] == S + Sp
         mask = mask.masked_fill(~am[:, None, None, :], float("-inf"))
+        # padded QUERY rows would be fully masked (NaN softmax / NaN gradients); let them see themselves — their outputs are
+        # never read by valid rows (keys masked) nor by the loss (labels -100), so nothing observable changes
+        eye = (j == i)[None, None]
+        mask = torch.where(eye & ~am[:, None, -S:, None], torch.zeros_like(mask), mask)
     x = inputs_embeds.float()
     new_kv = []
     for li in range(t.num_hidden_layers):
