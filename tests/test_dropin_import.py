@@ -1,0 +1,38 @@
+"""CPU: the reference's import line resolves to this build when rga3-release_amd/dropin leads sys.path, and the public surface
+(class / method names, config fields, output dict keys in the source) is the reference's."""
+import inspect
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_import_line_and_surface():
+    code = ("import sys; sys.path.insert(0, %r); "
+            "from model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel; from model.sam2 import SAM2; from model.STOM import STOM; "
+            "c = UniGRConfig(train_mask_decoder=True, out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=7, sam_pretrained=None, hidden_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, intermediate_size=64, vocab_size=32, vision_config=dict(depth=1, hidden_size=32, num_heads=2, intermediate_size=32, out_hidden_size=64)); "
+            "assert (c.train_mask_decoder, c.out_dim, c.seg_token_idx, c.hidden_size) == (True, 256, 7, 64); "
+            "m = UniGRModel(c); "
+            "assert not hasattr(m, 'grounding_encoder'); "
+            "names = [n for n, _ in m.named_parameters()]; "
+            "assert 'model.embed_tokens.weight' in names and 'lm_head.weight' in names and any('self_attn.q_proj' in n for n in names) and any(n.startswith('visual.blocks.0.attn.qkv') for n in names); "
+            "print('ok')") % os.path.join(ROOT, "rga3-release_amd", "dropin")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_method_signatures_match_reference_contract():
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRModel
+
+    ev = list(inspect.signature(UniGRModel.evaluate).parameters)
+    assert ev == ["self", "input_ids", "attention_mask", "pixel_values", "pixel_values_videos", "image_grid_thw", "video_grid_thw",
+                  "second_per_grid_ts", "images_sam", "resize_list", "original_size_list"]
+    mf = inspect.signature(UniGRModel.model_forward).parameters
+    for k in ("input_ids", "attention_mask", "position_ids", "labels", "pixel_values_videos", "video_grid_thw", "second_per_grid_ts", "images_sam",
+              "offset", "masks_list", "label_list", "resize_list", "inference", "kwargs"):
+        assert k in mf, k
+    src = inspect.getsource(UniGRModel.model_forward)
+    for key in ('"loss"', '"ce_loss"', '"mask_bce_loss"', '"mask_dice_loss"', '"mask_loss"', '"pred_masks"', '"gt_masks"'):
+        assert key in src
+    assert list(inspect.signature(UniGRModel.forward).parameters) == ["self", "kwargs"]
