@@ -16,6 +16,7 @@
 //  * K/V tiles are register-staged (global_load 16 B -> ds_write_b128) one tile ahead, into rows padded by
 //    32 B so that both the b128 K reads and the transposed V reads are bank-conflict-free.
 #include "common.h"
+#include <type_traits>
 
 namespace rga3 {
 
@@ -142,56 +143,65 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
             }
         }
 
-        // ---- scale, mask, online softmax (per lane: one query per q-tile)
+        // ---- scale, mask, online softmax (per lane: one query per q-tile).  Interior tiles take the mask-free body.
         const int k0 = kt * KV_TILE;
         const bool need_mask = (k0 + KV_TILE > Lk) || (p.causal && (k0 + KV_TILE - 1 > qb0 + shift));
         bf16x8 pf[QT][2];
+        auto softmax_tile = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const int qi = qw0 + t * 16 + c;
-            float mx = -INFINITY;
+            for (int t = 0; t < QT; ++t) {
+                const int qi = qw0 + t * 16 + c;
+                float mx = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = s[t][j][r] * p.scale_log2;
-                    if (need_mask) {
-                        const int key = k0 + j * 16 + 4 * g + r;
-                        const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
-                        x = ok ? x : -INFINITY;
+                    for (int r = 0; r < 4; ++r) {
+                        float x = s[t][j][r] * p.scale_log2;
+                        if constexpr (MASKED) {
+                            const int key = k0 + j * 16 + 4 * g + r;
+                            const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
+                            x = ok ? x : -INFINITY;
+                        }
+                        s[t][j][r] = x;
+                        mx = fmaxf(mx, x);
                     }
-                    s[t][j][r] = x;
-                    mx = fmaxf(mx, x);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[t], mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);  // m_run = -inf -> 0
+                m_run[t] = m_new;
+                float ps = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e = __builtin_amdgcn_exp2f(s[t][j][r] - m_use);   // raw v_exp_f32: arguments <= 0, flush of tiny values is harmless
+                        s[t][j][r] = e;
+                        ps += e;
+                    }
+                l_run[t] = l_run[t] * alpha + ps;
+                // rescale O only when some lane's running max moved (alpha == 1 exactly otherwise): the accumulators stay in
+                // the MFMA accumulator file on the common path
+                if (__any(alpha != 1.0f)) {
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) oacc[t][d] *= alpha;
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[t], mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m_run[t] - m_use);  // m_run = -inf -> 0
-            m_run[t] = m_new;
-            float ps = 0.f;
+                // P^T B-operand fragments: 32-key step ss uses s[t][2ss] (elements 0..3) and s[t][2ss+1] (4..7)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float e = exp2f(s[t][j][r] - m_use);
-                    s[t][j][r] = e;
-                    ps += e;
+                for (int ss = 0; ss < 2; ++ss) {
+                    u32x4 pk;
+                    pk[0] = pack_bf2(s[t][2 * ss][0], s[t][2 * ss][1]);
+                    pk[1] = pack_bf2(s[t][2 * ss][2], s[t][2 * ss][3]);
+                    pk[2] = pack_bf2(s[t][2 * ss + 1][0], s[t][2 * ss + 1][1]);
+                    pk[3] = pack_bf2(s[t][2 * ss + 1][2], s[t][2 * ss + 1][3]);
+                    pf[t][ss] = __builtin_bit_cast(bf16x8, pk);
                 }
-            l_run[t] = l_run[t] * alpha + ps;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) oacc[t][d] *= alpha;
-            // P^T B-operand fragments: 32-key step ss uses s[t][2ss] (elements 0..3) and s[t][2ss+1] (4..7)
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                u32x4 pk;
-                pk[0] = pack_bf2(s[t][2 * ss][0], s[t][2 * ss][1]);
-                pk[1] = pack_bf2(s[t][2 * ss][2], s[t][2 * ss][3]);
-                pk[2] = pack_bf2(s[t][2 * ss + 1][0], s[t][2 * ss + 1][1]);
-                pk[3] = pack_bf2(s[t][2 * ss + 1][2], s[t][2 * ss + 1][3]);
-                pf[t][ss] = __builtin_bit_cast(bf16x8, pk);
             }
-        }
+        };
+        if (need_mask) softmax_tile(std::true_type{});
+        else softmax_tile(std::false_type{});
 
         // ---- O^T += V^T . P^T
 #pragma unroll
@@ -266,8 +276,15 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     return 0;
 }
 
+static int g_attn_variant = 0;  // 0: auto, 1: force 4 waves x QT=2, 2: force 8 waves x QT=1 (benchmark switch, read-only after init)
+
 template <int DP, bool USE_TR>
 static int launch_dp(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
+    if constexpr (DP == 128 || DP == 64 || DP == 32) {
+        // long sequences: 8 waves x 16 query rows keeps the register footprint near 110 VGPRs (4 waves/SIMD) instead of
+        // one 300-register wave per SIMD
+        if (max_q > 64 && g_attn_variant != 1) return launch_attn<DP, 1, 8, USE_TR>(a, nseg, max_q, st);
+    }
     if constexpr (DP >= 256) {
         return launch_attn<DP, 1, 4, USE_TR>(a, nseg, max_q, st);
     } else {
@@ -305,7 +322,9 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && (((uintptr_t)o) & 7) == 0,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
-    RGA3_CHECK_ARG(impl == 0 || impl == 1, "attn: impl %d", impl);
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 3, "attn: impl %d", impl);
+    g_attn_variant = (impl & 2) ? 1 : 0;
+    impl &= 1;
     AttnArgs a;
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
     a.o = (unsigned short*)o; a.lse = lse; a.cu_q = cu_q; a.cu_k = cu_k;

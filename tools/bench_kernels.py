@@ -62,7 +62,7 @@ def bench_attn(out):
         q, k, v = rnd(T, Hq, D), rnd(T, Hkv, D), rnd(T, Hkv, D)
         cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
         o = torch.empty_like(q)
-        for impl in (0, 1):
+        for impl in (0, 2):
             ms = timeit(lambda: ops.attn_varlen(q, k, v, cu, cu, max(lens), D ** -0.5, causal, out=o, impl=impl))
             fl = sum(4.0 * L * L * D * Hq for L in lens) * (0.5 if causal else 1.0)
             rec = {"op": "attn", "name": name, "impl": impl, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
