@@ -280,7 +280,7 @@ static int g_attn_variant = 0;  // 0: auto, 1: force 4 waves x QT=2, 2: force 8 
 
 template <int DP, bool USE_TR>
 static int launch_dp(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
-    if constexpr (DP == 128 || DP == 64 || DP == 32) {
+    if constexpr (DP == 128 || DP == 64) {
         // long sequences: 8 waves x 16 query rows keeps the register footprint near 110 VGPRs (4 waves/SIMD) instead of
         // one 300-register wave per SIMD
         if (max_q > 64 && g_attn_variant != 1) return launch_attn<DP, 1, 8, USE_TR>(a, nseg, max_q, st);
