@@ -125,8 +125,8 @@ def test_llm_training_step_gradients(dev):
     assert abs(out.loss.item() - ref["loss"].item()) / ref["loss"].item() < 1e-2
     got = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
     assert all(g is not None for g in got.values())
-    for k in train_keys:
-        tol = 3e-2 if k == "lm_head.weight" else 6e-2   # embed and LoRA grads cross every layer of bf16 backward
-        assert rel_l2(got[k], P[k].grad) < tol, (k, rel_l2(got[k], P[k].grad))
+    errs = {k: rel_l2(got[k], P[k].grad) for k in train_keys}
+    bad = {k: e for k, e in errs.items() if e >= (3e-2 if k == "lm_head.weight" else 6e-2)}   # embed / LoRA grads cross every layer's bf16 backward
+    assert not bad, (bad, errs)
     m = am.bool()
     assert rel_l2(out.hidden_states[-1][m], ref["hidden"][m].detach()) < 2e-2
