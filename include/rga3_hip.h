@@ -165,6 +165,23 @@ int rga3_adamw_step(void* param, float* master, const void* grad, float* m, floa
 /* *out += sum(g^2) (fp32 atomic): global gradient norm for clipping (train_joint.py:300 gradient_clipping 1.0) */
 int rga3_sumsq_accum(const void* g, float* out, int64_t n, void* stream);
 
+/* ---- mask-path backward (trainable sam_mask_decoder + text_hidden_fcs, train_joint.py:237-251) ---------------- */
+
+/* LayerNorm backward: dx (bf16) and, if non-NULL, f32 accumulators dweight/dbias += (atomics); model/sam2.py:1364-1376,2334-2346 */
+int rga3_layernorm_bwd(const void* x, const void* weight, const void* dy, void* dx, float* dweight, float* dbias, int64_t rows, int64_t dim,
+                       float eps, void* stream);
+/* out[c] += sum_r x[r,c] (bias gradients) */
+int rga3_colsum_accum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* stream);
+/* kind 0: out = gelu(a); kind 1: out = dy * gelu'(a) (a = pre-activation); kind 2: out = dy * (a > 0) (a = relu output) */
+int rga3_act(const void* a, const void* dy, void* out, int64_t n, int kind, void* stream);
+/* backward of rga3_bilinear into a pre-zeroed f32 input gradient (atomic adds) */
+int rga3_bilinear_bwd(const float* dout, float* din, const int32_t* plane_idx, int64_t N, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* backward of rga3_pixel_shuffle2x w.r.t. the GEMM output */
+int rga3_pixel_shuffle2x_bwd(const void* dout, void* dg, int64_t F, int H, int W, int Co, void* stream);
+/* dlogits = coef_bce * d(sum_n mean BCE) + coef_dice * d(sum_n dice_n) (model/qwen_2_5_vl_sam2.py:17-60) from the forward sums */
+int rga3_bce_dice_grad(const float* logits, const float* targets, const float* sums4, float* dlogits, int64_t n_masks, int64_t hw,
+                       float coef_bce, float coef_dice, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

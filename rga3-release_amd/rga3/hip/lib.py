@@ -47,6 +47,12 @@ SIGNATURES = {
     "rga3_segment_sum_rows": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "rga3_adamw_step": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _f, _p],
     "rga3_sumsq_accum": [_p, _p, _i64, _p],
+    "rga3_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _p],
+    "rga3_colsum_accum": [_p, _p, _i64, _i64, _i64, _p],
+    "rga3_act": [_p, _p, _p, _i64, _i, _p],
+    "rga3_bilinear_bwd": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
+    "rga3_pixel_shuffle2x_bwd": [_p, _p, _i64, _i, _i, _i, _p],
+    "rga3_bce_dice_grad": [_p, _p, _p, _p, _i64, _i64, _f, _f, _p],
 }
 
 _lib = None

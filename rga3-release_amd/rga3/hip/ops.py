@@ -389,3 +389,70 @@ def sumsq_accum_(g, out):
     _need_cuda(g, out)
     assert g.dtype == torch.bfloat16 and g.is_contiguous() and out.dtype == torch.float32
     _lib.check(_lib.load().rga3_sumsq_accum(g.data_ptr(), out.data_ptr(), g.numel(), _stream()), "sumsq_accum")
+
+
+# ------------------------------------------------------------------------------------------------ mask-path backward kernels
+def layernorm_bwd(x, weight, dy, eps: float, want_param_grads=True):
+    _need_cuda(x, weight, dy)
+    assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype == torch.bfloat16
+    dx = torch.empty_like(x)
+    dw = db = None
+    if want_param_grads:
+        dw = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+        db = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rga3_layernorm_bwd(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), x.shape[0], x.shape[1],
+                                              float(eps), _stream()), "layernorm_bwd")
+    return dx, dw, db
+
+
+def colsum(x):
+    """f32 column sums of a bf16 [rows, cols] tensor (row stride free)."""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rga3_colsum_accum(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0), _stream()), "colsum_accum")
+    return out
+
+
+def gelu(x):
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().rga3_act(x.data_ptr(), 0, out.data_ptr(), x.numel(), 0, _stream()), "act")
+    return out
+
+
+def act_bwd(a, dy, kind: str):
+    """kind 'gelu': a = pre-activation; 'relu': a = output."""
+    _need_cuda(a, dy)
+    assert a.dtype == dy.dtype == torch.bfloat16 and a.is_contiguous() and dy.is_contiguous()
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().rga3_act(a.data_ptr(), dy.data_ptr(), out.data_ptr(), a.numel(), 1 if kind == "gelu" else 2, _stream()), "act")
+    return out
+
+
+def bilinear_bwd(dout, in_shape, plane_idx=None):
+    _need_cuda(dout, plane_idx)
+    assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.dim() == 3
+    din = torch.zeros(in_shape, dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.load().rga3_bilinear_bwd(dout.data_ptr(), din.data_ptr(), _ptr(plane_idx), dout.shape[0], in_shape[1], in_shape[2], dout.shape[1],
+                                             dout.shape[2], _stream()), "bilinear_bwd")
+    return din
+
+
+def pixel_shuffle2x_bwd(dout, F: int, H: int, W: int):
+    _need_cuda(dout)
+    assert dout.dtype == torch.bfloat16 and dout.is_contiguous()
+    Co = dout.shape[1]
+    dg = torch.empty((F * H * W, 4 * Co), dtype=torch.bfloat16, device=dout.device)
+    _lib.check(_lib.load().rga3_pixel_shuffle2x_bwd(dout.data_ptr(), dg.data_ptr(), F, H, W, Co, _stream()), "pixel_shuffle2x_bwd")
+    return dg
+
+
+def bce_dice_grad(logits, targets, sums, coef_bce: float, coef_dice: float):
+    _need_cuda(logits, targets, sums)
+    assert logits.dtype == targets.dtype == sums.dtype == torch.float32 and logits.is_contiguous() and targets.is_contiguous()
+    d = torch.empty_like(logits)
+    _lib.check(_lib.load().rga3_bce_dice_grad(logits.data_ptr(), targets.data_ptr(), sums.data_ptr(), d.data_ptr(), logits.shape[0], logits[0].numel(),
+                                              float(coef_bce), float(coef_dice), _stream()), "bce_dice_grad")
+    return d

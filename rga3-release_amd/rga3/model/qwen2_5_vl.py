@@ -595,7 +595,11 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         if trainable:
             from .qwen_train import lm_train_forward
             loss, hn = lm_train_forward(self, x, pos3, cu, int(lens.max()), labels.detach().cpu().numpy(), am_cur, flat_keep, lens)
-            full = hn if flat_keep.size == B * S else ops.scatter_rows_(torch.zeros((B * S, hn.shape[-1]), dtype=hn.dtype, device=hn.device), keep_dev, hn)
+            if flat_keep.size == B * S:
+                full = hn
+            else:
+                from ..hip.autograd import ScatterRowsFn
+                full = ScatterRowsFn.apply(hn, keep_dev, B * S)
             return CausalLMOutput(loss=loss, logits=None, past_key_values=None, hidden_states=(full.view(B, S, -1),), rope_deltas=self.rope_deltas)
         if cache is not None:
             cache.begin(lens.tolist())

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ..hip import autograd as AG
 from ..hip import ops
 from .qwen2_5_vl import CausalLMOutput, Linear, Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
 from .sam2 import SAM2
@@ -104,8 +105,12 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
         counts = seg_token_mask_np.sum(-1).astype(np.int64)
         if where.size == 0:
             return torch.zeros((0, self.config.out_dim), dtype=hidden_last.dtype, device=hidden_last.device), counts
-        rows = ops.gather_rows(hidden_last.reshape(B * S, H), torch.from_numpy(where).to(hidden_last.device))
+        idx = torch.from_numpy(where).to(hidden_last.device)
         fc = self.text_hidden_fcs[0]
+        if torch.is_grad_enabled():
+            rows = AG.GatherRowsFn.apply(hidden_last.reshape(B * S, H), idx)
+            return AG.linear(AG.linear(rows, fc[0].weight, fc[0].bias, None, "relu"), fc[2].weight, fc[2].bias), counts
+        rows = ops.gather_rows(hidden_last.reshape(B * S, H), idx)
         return fc[2](fc[0](rows, act="relu")), counts
 
     @staticmethod
@@ -164,11 +169,16 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
             assert e.shape[0] == 1, "one [SEG] per sample on the training path (reference sam2.py:3356 assert)"
             st = gm.get_sam2_embeddings_train(images_sam[i])
             _, high = gm.inject_language_embd_train(st, e[None].expand(num_frames_sam, -1, -1))
-            pred = ops.bilinear(high[:, 0].contiguous(), tuple(label_list[i].shape))
+            grad = torch.is_grad_enabled()
+            pred = AG.BilinearFn.apply(high[:, 0].contiguous(), tuple(label_list[i].shape), None) if grad else ops.bilinear(high[:, 0].contiguous(), tuple(label_list[i].shape))
             assert gt_mask.shape[0] == pred.shape[0], "gt_mask.shape: {}, pred_mask.shape: {}".format(gt_mask.shape, pred.shape)
             n = gt_mask.shape[0]
-            mask_bce_loss = mask_bce_loss + sigmoid_ce_loss(pred, gt_mask.to(device), num_masks=n) * n
-            mask_dice_loss = mask_dice_loss + dice_loss(pred, gt_mask.to(device), num_masks=n) * n
+            if grad:   # sum over masks of (mean BCE, dice) == sigmoid_ce_loss * n, dice_loss * n of the reference (:297-304)
+                b_, d_ = AG.MaskLossFn.apply(pred, gt_mask.to(device))
+                mask_bce_loss, mask_dice_loss = mask_bce_loss + b_, mask_dice_loss + d_
+            else:
+                mask_bce_loss = mask_bce_loss + sigmoid_ce_loss(pred, gt_mask.to(device), num_masks=n) * n
+                mask_dice_loss = mask_dice_loss + dice_loss(pred, gt_mask.to(device), num_masks=n) * n
             num_masks += n
         mask_bce_loss = self.config.bce_loss_weight * mask_bce_loss / (num_masks + 1e-8)
         mask_dice_loss = self.config.dice_loss_weight * mask_dice_loss / (num_masks + 1e-8)

@@ -214,21 +214,23 @@ class NormHeadCEFn(torch.autograd.Function):
         hn = ops.rmsnorm(h, norm_w, eps)
         if n_valid == 0:
             ctx.n = 0
-            ctx.hshape = h.shape
-            ctx.mark_non_differentiable(hn)
+            ctx.save_for_backward(h, norm_w)
+            ctx.eps = eps
             return torch.zeros((), device=h.device, dtype=torch.float32), hn
         hv = ops.gather_rows(hn, valid_rows_dev)
         logits = ops.gemm(hv, lm_w)
         row_loss, dlogits = ops.cross_entropy_rows(logits, targets_dev, want_grad=True, grad_scale=1.0 / n_valid)
         ctx.save_for_backward(h, lm_w, norm_w, hv, dlogits, valid_rows_dev)
         ctx.eps, ctx.n = eps, n_valid
-        ctx.mark_non_differentiable(hn)
         return row_loss.sum() / n_valid, hn
 
     @staticmethod
     def backward(ctx, gloss, ghn):
-        if ctx.n == 0:
-            return torch.zeros(ctx.hshape, dtype=torch.bfloat16, device=gloss.device), None, None, None, None, None, None
+        if ctx.n == 0:   # no labelled row: only the hidden-state path (mask losses) carries gradient
+            h, norm_w = ctx.saved_tensors
+            with torch.no_grad():
+                dh = ops.rmsnorm_bwd(h, norm_w, ghn.contiguous() if ghn is not None else torch.zeros_like(h), ctx.eps)
+            return dh, None, None, None, None, None, None
         h, lm_w, norm_w, hv, dlogits, rows = ctx.saved_tensors
         n = ctx.n
         with torch.no_grad():
@@ -241,8 +243,9 @@ class NormHeadCEFn(torch.autograd.Function):
                 dl_t, hv_t = ops.pad_cols(dl_t, npad), ops.pad_cols(hv_t, npad)
             dW = ops.gemm(dl_t, hv_t) if lm_w.requires_grad else None      # [V, H]
             dhv = ops.gemm(dlogits, ops.transpose(lm_w.detach()))            # [n, H]
-            dhn = torch.zeros_like(h)
-            ops.scatter_rows_(dhn, rows, dhv)
+            dhn = ghn.contiguous().clone() if ghn is not None else torch.zeros_like(h)   # gradient arriving through hidden_states[-1]
+            dhn_rows = ops.add(ops.gather_rows(dhn, rows), dhv)
+            ops.scatter_rows_(dhn, rows, dhn_rows)
             dh = ops.rmsnorm_bwd(h, norm_w, dhn, ctx.eps)
         return dh, dW, None, None, None, None, None
 

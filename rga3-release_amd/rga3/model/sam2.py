@@ -25,8 +25,20 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..hip import autograd as AG
 from ..hip import ops
 from .qwen2_5_vl import Linear
+
+
+def _ag():
+    """Record autograd nodes (training of the mask decoder / text_hidden_fcs) instead of the fused inference kernels."""
+    return torch.is_grad_enabled()
+
+
+def _lin(l, x, residual=None, act="none"):
+    if _ag():
+        return AG.linear(x, l.weight, l.bias, residual, act)
+    return l(x, residual=residual, act=act)
 
 
 # ------------------------------------------------------------------------------------------------ parameter holders
@@ -51,6 +63,9 @@ class NormParams(nn.Module):
         self.eps = eps
 
     def forward(self, x2d, act="none"):
+        if _ag():
+            y = AG.LayerNormFn.apply(x2d.contiguous(), self.weight, self.bias, self.eps)
+            return AG.GeluFn.apply(y) if act == "gelu" else y
         return ops.layernorm(x2d, self.weight, self.bias, self.eps, act=act)
 
 
@@ -66,7 +81,10 @@ class MLP(nn.Module):
     def forward(self, x, residual=None):
         for i, l in enumerate(self.layers):
             last = i == self.num_layers - 1
-            x = l(x, act="none" if last else self.act, residual=residual if last else None)
+            if _ag() and not last and self.act == "gelu":
+                x = AG.GeluFn.apply(_lin(l, x))
+            else:
+                x = _lin(l, x, act="none" if last else self.act, residual=residual if last else None)
         return torch.sigmoid(x.float()).to(x.dtype) if self.sigmoid_output else x
 
 
@@ -303,9 +321,20 @@ class Attention(nn.Module):
     def forward(self, q, k, v, B, nq, nk, residual=None):
         """q [B*nq, C], k/v [B*nk, Ckv] -> out_proj(attn) (+ residual) [B*nq, C]."""
         H, hd = self.num_heads, self.internal_dim // self.num_heads
-        qp, kp, vp = self.q_proj(q), self.k_proj(k), self.v_proj(v)
-        o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5)
-        return self.out_proj(o.view(-1, self.internal_dim), residual=residual)
+        qp, kp, vp = _lin(self.q_proj, q), _lin(self.k_proj, k), _lin(self.v_proj, v)
+        if _ag():
+            o = AG.AttnFn.apply(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, nk, hd ** -0.5)
+        else:
+            o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5)
+        return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
+
+
+def _add(a, b):
+    return AG.AddFn.apply(a, b) if _ag() else ops.add(a, b)
+
+
+def _add_bcast(a, b, alpha=1.0):
+    return AG.AddBcastFn.apply(a, b, alpha) if _ag() else ops.add_bcast(a, b, alpha)
 
 
 class TwoWayAttentionBlock(nn.Module):
@@ -325,14 +354,14 @@ class TwoWayAttentionBlock(nn.Module):
         if self.skip_first_layer_pe:
             queries = self.self_attn(queries, queries, queries, B, nq, nq)
         else:
-            q = ops.add(queries, query_pe)
+            q = _add(queries, query_pe)
             queries = self.self_attn(q, q, queries, B, nq, nq, residual=queries)
         queries = self.norm1(queries)
-        q = ops.add(queries, query_pe)
-        k = ops.add_bcast(keys, key_pe)
+        q = _add(queries, query_pe)
+        k = _add_bcast(keys, key_pe)
         queries = self.norm2(self.cross_attn_token_to_image(q, k, keys, B, nq, nk, residual=queries))
         queries = self.norm3(self.mlp(queries, residual=queries))
-        q = ops.add(queries, query_pe)
+        q = _add(queries, query_pe)
         keys = self.norm4(self.cross_attn_image_to_token(k, q, queries, B, nk, nq, residual=keys))
         return queries, keys
 
@@ -348,8 +377,8 @@ class TwoWayTransformer(nn.Module):
         queries, query_pe = tokens, tokens
         for layer in self.layers:
             queries, keys = layer(queries, keys, query_pe, key_pe, B, nq, nk)
-        q = ops.add(queries, query_pe)
-        k = ops.add_bcast(keys, key_pe)
+        q = _add(queries, query_pe)
+        k = _add_bcast(keys, key_pe)
         queries = self.norm_final_attn(self.final_attn_token_to_image(q, k, keys, B, nq, nk, residual=queries))
         return queries, keys
 
@@ -369,6 +398,10 @@ class ConvTParams(nn.Module):
         if self._pk is None or self._pk[0] != key:
             self._pk = (key, self.weight.detach().permute(2, 3, 1, 0).reshape(-1, self.weight.shape[0]).contiguous())
         return self._pk[1]
+
+    def as_linear_grad(self):
+        """same matrix, recorded by autograd (the permute/reshape are views + one copy that torch differentiates)."""
+        return self.weight.permute(2, 3, 1, 0).reshape(-1, self.weight.shape[0]).contiguous()
 
 
 class MaskDecoder(nn.Module):
@@ -400,16 +433,25 @@ class MaskDecoder(nn.Module):
         hs = hs.view(B, nq, C)
         iou_tok, mask_toks = hs[:, 1], hs[:, 2:6]
         dc1, ln1, _, dc2, _ = self.output_upscaling
-        g1 = ops.gemm(src, dc1.as_linear())
-        up = ops.pixel_shuffle2x(g1, dc1.bias, feat_s1, B, h, w)
-        up = ln1(up, act="gelu")
-        g2 = ops.gemm(up, dc2.as_linear())
-        up = ops.pixel_shuffle2x(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w, act="gelu")          # [B*16hw, C/8]
-        hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)  # [B, 4, C/8]
         npx = 16 * h * w
-        masks = torch.empty((B, 4, 4 * h, 4 * w), dtype=torch.float32, device=src.device)
-        for b in range(B):  # masks[b] = hyper[b] @ up[b]^T : planes come out row-major, f32
-            ops.gemm(hyper[b].contiguous(), up[b * npx:(b + 1) * npx], out_dtype=torch.float32, out=masks[b].view(4, npx))
+        if _ag():
+            g1 = AG.linear(src, dc1.as_linear_grad())
+            up = AG.PixelShuffleFn.apply(g1, dc1.bias, feat_s1, B, h, w)
+            up = ln1(up, act="gelu")
+            g2 = AG.linear(up, dc2.as_linear_grad())
+            up = AG.GeluFn.apply(AG.PixelShuffleFn.apply(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w))
+            hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)
+            masks = torch.stack([AG.linear(hyper[b].contiguous(), up[b * npx:(b + 1) * npx], out_f32=True).view(4, 4 * h, 4 * w) for b in range(B)], dim=0)
+        else:
+            g1 = ops.gemm(src, dc1.as_linear())
+            up = ops.pixel_shuffle2x(g1, dc1.bias, feat_s1, B, h, w)
+            up = ln1(up, act="gelu")
+            g2 = ops.gemm(up, dc2.as_linear())
+            up = ops.pixel_shuffle2x(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w, act="gelu")          # [B*16hw, C/8]
+            hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)  # [B, 4, C/8]
+            masks = torch.empty((B, 4, 4 * h, 4 * w), dtype=torch.float32, device=src.device)
+            for b in range(B):  # masks[b] = hyper[b] @ up[b]^T : planes come out row-major, f32
+                ops.gemm(hyper[b].contiguous(), up[b * npx:(b + 1) * npx], out_dtype=torch.float32, out=masks[b].view(4, npx))
         iou = self.iou_prediction_head(iou_tok.contiguous())
         obj = self.pred_obj_score_head(hs[:, 0].contiguous())
         return masks, iou, mask_toks, obj
@@ -666,8 +708,11 @@ class SAM2VideoPredictor(nn.Module):
         best = torch.argmax(ious, dim=-1)
         bi = torch.arange(B, device=best.device)
         sel = (bi * 4 + 1 + best).to(torch.int32)
-        low = masks.view(B * 4, 4 * h, 4 * w)[sel.long()].unsqueeze(1)                                  # chosen candidate, f32
-        high = ops.bilinear(masks.view(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
+        low = masks.reshape(B * 4, 4 * h, 4 * w)[sel.long()].unsqueeze(1)                               # chosen candidate, f32
+        if _ag():
+            high = AG.BilinearFn.apply(masks.reshape(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
+        else:
+            high = ops.bilinear(masks.view(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
         tok = toks[:, 1:][bi, best]
         obj_ptr = self.obj_ptr_proj(tok.contiguous())
         lam = (obj > 0).to(obj_ptr.dtype)
@@ -698,7 +743,8 @@ class SAM2(nn.Module):
     # ---- training path: frames independent (reference :412-433, :343-375)
     def get_sam2_embeddings_train(self, images, expand_size=1):
         assert expand_size == 1, "num_objs == 1 on the RGA3 path (model/qwen_2_5_vl_sam2.py:263)"
-        return self.sam2_model.forward_image(images)
+        with torch.no_grad():  # the image encoder is frozen (reference qwen_2_5_vl_sam2.py:121); only the mask decoder records autograd
+            return self.sam2_model.forward_image(images)
 
     def inject_language_embd_train(self, sam_states, language_embd, nf_nobj=None):
         m = self.sam2_model

@@ -96,3 +96,71 @@ def test_evaluate_masks(model, dev, G):
     assert torch.equal(masks[0].cpu()[margin], rmasks[0][margin])
     assert iou(masks[0], rmasks[0]) >= 0.96
     assert iou(masks[0], torch.from_numpy(G["eval_masks"])) >= 0.95  # vs the reference's own bool masks (fp32, unrounded weights)
+
+
+def test_training_gradients_through_mask_path(dev, G):
+    """fwd+bwd of the joint model: CE + BCE + dice losses back-propagate through the mask decoder, text_hidden_fcs and the decoder
+    LLM into lm_head / embed_tokens.  Compared with fp32 autograd through the oracle (same bf16-rounded weights) and with the
+    gradients the reference itself produced (tests/golden/unigr_tiny.npz)."""
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
+
+    cfg = UniGRConfig(train_mask_decoder=True, out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=SEG,
+                      sam_pretrained=None, sam_config=SAM_TINY, **product_cfg_kwargs())
+    m = UniGRModel(cfg)
+    m.initialize_sam_modules(cfg)
+    P0, PS0 = params(G)
+    sd = dict(P0)
+    sd.update({"grounding_encoder.sam2_model." + k: v for k, v in PS0.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(torch.bfloat16).to(dev)
+    train_names = []
+    for n, p in m.named_parameters():
+        on = ("sam_mask_decoder" in n) or ("text_hidden_fcs" in n) or n in ("lm_head.weight", "model.embed_tokens.weight")
+        p.requires_grad_(on)
+        if on:
+            train_names.append(n)
+    case = "11"
+    b = make_batch(CASES[case], seed=int(case, 2) + 1)
+    out = m(**to_dev(b, dev), inference=False)
+    out["loss"].backward()
+    got = {n: p.grad for n, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+
+    P, PS = params(G, bf16_round=True)
+    for k in P:
+        if ("text_hidden_fcs" in k) or k in ("lm_head.weight", "model.embed_tokens.weight"):
+            P[k].requires_grad_(True)
+    for k in PS:
+        if k.startswith("sam_mask_decoder."):
+            PS[k].requires_grad_(True)
+    bb = dict(b)
+    bb["pixel_values_videos"] = b["pixel_values_videos"].to(torch.bfloat16).float()
+    bb["images_sam"] = b["images_sam"].to(torch.bfloat16).float()
+    ref = U.model_forward(P, PS, oracle_cfg(), sam_cfg(), bb, (1.0, 0.5, 2.0), SEG)
+    ref["loss"].backward()
+    for k in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss"):
+        assert abs(float(out[k]) - float(ref[k])) <= 1e-2 * abs(float(ref[k])) + 2e-3, k
+
+    def rl(a, b_):
+        a, b_ = a.float().cpu(), b_.float().cpu()
+        return ((a - b_).norm() / (b_.norm() + 1e-12)).item()
+
+    errs = {}
+    for k, v in P.items():
+        if v.requires_grad and v.grad is not None:
+            assert k in got, k
+            errs[k] = rl(got[k], v.grad)
+    for k, v in PS.items():
+        if v.requires_grad and v.grad is not None and float(v.grad.abs().max()) > 0:
+            name = "grounding_encoder.sam2_model." + k
+            assert name in got, name
+            errs[name] = rl(got[name], v.grad)
+    assert len(errs) > 60
+    bad = {k: e for k, e in errs.items() if e > 0.12}
+    assert not bad, (bad, sorted(errs.values())[-5:])
+    assert float(np.median(list(errs.values()))) < 5e-2
+    # the reference's own gradients (fp32, unrounded weights) for four tensors
+    for k in ("text_hidden_fcs.0.2.weight", "lm_head.weight", "grounding_encoder.sam2_model.sam_mask_decoder.output_hypernetworks_mlps.1.layers.2.weight",
+              "grounding_encoder.sam2_model.sam_mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight"):
+        gk = f"train_{case}_grad::{k}"
+        if gk in G.files:
+            assert rl(got[k], torch.from_numpy(G[gk])) < 0.15, k
