@@ -121,7 +121,7 @@ class PixelShuffleFn(torch.autograd.Function):
         dy = dy.contiguous()
         dg = ops.pixel_shuffle2x_bwd(dy, F, H, W)
         db = ops.colsum(dy).to(torch.bfloat16) if ctx.needs_input_grad[1] else None
-        return dg, db, None, None, None, None
+        return dg, db, (dy if ctx.needs_input_grad[2] else None), None, None, None
 
 
 class BilinearFn(torch.autograd.Function):

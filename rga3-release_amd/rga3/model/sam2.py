@@ -682,11 +682,18 @@ class SAM2VideoPredictor(nn.Module):
     def forward_image(self, img):
         """reference sam2.py:2790-2802 (+ FPN, scalp). Returns dict of raster token maps."""
         Fn = img.shape[0]
-        stages = self.image_encoder.trunk(img.to(self.dtype))
-        lv = self.image_encoder.neck(stages, Fn)[: len(stages) - self.image_encoder.scalp]
+        with torch.no_grad():  # trunk + neck are frozen on every RGA3 path (reference qwen_2_5_vl_sam2.py:121)
+            stages = self.image_encoder.trunk(img.to(self.dtype))
+            lv = self.image_encoder.neck(stages, Fn)[: len(stages) - self.image_encoder.scalp]
         (f0, H0, W0), (f1, H1, W1), (f2, H2, W2) = lv
-        dec = self.sam_mask_decoder
-        return {"feat_s0": ops.gemm(f0, dec.conv_s0.as_linear(), dec.conv_s0.bias), "feat_s1": ops.gemm(f1, dec.conv_s1.as_linear(), dec.conv_s1.bias),
+        dec = self.sam_mask_decoder   # conv_s0 / conv_s1 belong to the (trainable) mask decoder: they record autograd when enabled
+
+        def conv1x1(conv, x):
+            if _ag():
+                return AG.linear(x, conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
+            return ops.gemm(x, conv.as_linear(), conv.bias)
+
+        return {"feat_s0": conv1x1(dec.conv_s0, f0), "feat_s1": conv1x1(dec.conv_s1, f1),
                 "feat": f2, "hw": (H2, W2), "n": Fn, "pos": self.image_encoder.neck.pos(H2, W2, f2.device, f2.dtype)}
 
     # -- SAM heads (language path: no clicks, no mask prompt) ---------------------------------------------
@@ -743,8 +750,7 @@ class SAM2(nn.Module):
     # ---- training path: frames independent (reference :412-433, :343-375)
     def get_sam2_embeddings_train(self, images, expand_size=1):
         assert expand_size == 1, "num_objs == 1 on the RGA3 path (model/qwen_2_5_vl_sam2.py:263)"
-        with torch.no_grad():  # the image encoder is frozen (reference qwen_2_5_vl_sam2.py:121); only the mask decoder records autograd
-            return self.sam2_model.forward_image(images)
+        return self.sam2_model.forward_image(images)
 
     def inject_language_embd_train(self, sam_states, language_embd, nf_nobj=None):
         m = self.sam2_model
