@@ -144,16 +144,25 @@ def test_training_gradients_through_mask_path(dev, G):
         a, b_ = a.float().cpu(), b_.float().cpu()
         return ((a - b_).norm() / (b_.norm() + 1e-12)).item()
 
-    errs = {}
+    pairs = {}
     for k, v in P.items():
         if v.requires_grad and v.grad is not None:
             assert k in got, k
-            errs[k] = rl(got[k], v.grad)
+            pairs[k] = (got[k], v.grad)
     for k, v in PS.items():
         if v.requires_grad and v.grad is not None and float(v.grad.abs().max()) > 0:
             name = "grounding_encoder.sam2_model." + k
             assert name in got, name
-            errs[name] = rl(got[name], v.grad)
+            pairs[name] = (got[name], v.grad)
+    # gradients that are analytically zero (e.g. key-projection biases: softmax is invariant to a common shift of the scores)
+    # come out as pure rounding noise on both sides: compare those by absolute size against the typical gradient norm
+    typical = float(np.median([float(r.float().norm()) for _, r in pairs.values()]))
+    errs = {}
+    for k, (g_, r_) in pairs.items():
+        if float(r_.float().norm()) < 1e-4 * typical:
+            assert float(g_.float().norm()) < 2e-2 * typical, (k, float(g_.float().norm()), typical)
+        else:
+            errs[k] = rl(g_, r_)
     assert len(errs) > 60
     bad = {k: e for k, e in errs.items() if e > 0.12}
     assert not bad, (bad, sorted(errs.values())[-5:])
