@@ -66,6 +66,33 @@ def make_inputs(cfg, dev, seed=0):
                 video_grid_thw=torch.tensor([[8, 32, 32]]), second_per_grid_ts=torch.tensor([1.0]))
 
 
+def build_full(dev, rank, sam_frames):
+    """UniGRModel at 7B + SAM2-L (random init) and one synthetic training sample (SURVEY.md 8(d) config 3, B = 1 per GPU)."""
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
+    from rga3.utils.data import make_batch
+
+    cfg = UniGRConfig(train_mask_decoder=True, out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=151665)
+    torch.manual_seed(1)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            model = UniGRModel(cfg)
+            model.initialize_sam_modules(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+            elif "norm" in n or "ln_q" in n:
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02)
+    batch = make_batch(cfg, dev, batch=1, frames_mllm=16, frames_sam=sam_frames, seed=rank)
+    return model.train(), cfg, batch
+
+
 def cpu_baseline():
     """Oracle (fp32 restatement, 'port') on the host cores: one windowed + one full ViT block, one decoder layer and
     a 1/16 lm_head slice at 7B dims, extrapolated to a whole forward (28 win + 4 full blocks, 28 layers, lm_head)."""
@@ -133,8 +160,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
-                    help="forward = BASELINE configs[1] (default, the driver's metric); train = LLM fwd+bwd LoRA step with DDP gradient exchange")
+    ap.add_argument("--mode", choices=["forward", "train", "train_full"], default="forward",
+                    help="forward = BASELINE configs[1] (default, the driver's metric); train = LLM fwd+bwd LoRA step with DDP gradient exchange; "
+                         "train_full = BASELINE configs[2] per GPU: full RGA3 (Qwen2.5-VL-7B + SAM2-L, 16 SAM frames) fwd+bwd + AdamW")
+    ap.add_argument("--sam-frames", type=int, default=16)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,23 +180,28 @@ def main():
 
     from rga3.hip import lib, ops
     lib.load()  # fail loudly if the HIP extension is missing
-    model, cfg = build_model(dev)
-    inputs = make_inputs(cfg, dev, seed=rank)
+    if args.mode == "train_full":
+        model, cfg, inputs = build_full(dev, rank, args.sam_frames)
+    else:
+        model, cfg = build_model(dev)
+        inputs = make_inputs(cfg, dev, seed=rank)
 
-    if args.mode == "train":
+    if args.mode in ("train", "train_full"):
         from rga3.model.qwen_train import add_lora
         from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
 
-        add_lora(model, r=128, alpha=256)
-        for n, p in model.named_parameters():
-            p.requires_grad_(("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight"))
+        add_lora(model, r=128, alpha=256, exclude=("sam_model", "grounding_encoder", "visual", "text_hidden_fcs"))
+        full = args.mode == "train_full"
+        for n, p in model.named_parameters():   # trainable set of reference train_joint.py:237-251
+            p.requires_grad_(("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight") or (full and ("sam_mask_decoder" in n or "text_hidden_fcs" in n)))
         with torch.no_grad():
             for n, p in model.named_parameters():
                 if "lora_B" in n:
                     p.normal_(0.0, 0.01)
-        labels = torch.full_like(inputs["input_ids"], -100)
-        labels[:, -6:] = inputs["input_ids"][:, -6:]
-        inputs["labels"] = labels
+        if not full:
+            labels = torch.full_like(inputs["input_ids"], -100)
+            labels[:, -6:] = inputs["input_ids"][:, -6:]
+            inputs["labels"] = labels
         trainables = [p for p in model.parameters() if p.requires_grad]
         reducer = GradBucketReducer(trainables, bucket_mb=256.0)
         opt = FusedAdamW(trainables, lr=4e-5, betas=(0.9, 0.95), weight_decay=0.0, max_grad_norm=1.0)
@@ -179,6 +213,8 @@ def main():
             reducer.begin_step()
             reducer.begin_micro_step()
             out = model(**inputs)
+            if isinstance(out, dict):
+                out = type("O", (), {"loss": out["loss"]})()
             out.loss.backward()
             reducer.finish()
             opt.step(reducer.grad_view)
@@ -249,14 +285,20 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.mode == "forward":
         cpu = cpu_baseline()
 
-    if rank == 0 and args.mode == "train":
+    if rank == 0 and args.mode in ("train", "train_full"):
         n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
         fl = (10.8 + 30.8 - 2.3 + 28.5 + 28.5) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + recompute + dX
-        line = {"metric": "video-QA samples/sec (fwd+bwd) at 7B/16-frame — LLM-side LoRA training step (no SAM2 mask path)", "value": round(value, 4),
+        if args.mode == "train_full":
+            fl += (1.82 * args.sam_frames + 3 * 0.0036 * args.sam_frames) * 1e12   # frozen Hiera-L fwd + mask decoder fwd+bwd
+        line = {"metric": ("video-QA samples/sec (fwd+bwd) at 7B/16-frame — full RGA3 step (Qwen2.5-VL-7B + SAM2-L + mask losses)" if args.mode == "train_full"
+                           else "video-QA samples/sec (fwd+bwd) at 7B/16-frame — LLM-side LoRA training step (no SAM2 mask path)"), "value": round(value, 4),
                 "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd with per-layer recompute, LoRA r128 q/v + lm_head + embed_tokens "
-                                       "trainable, AdamW step, bucketed RCCL all-reduce; 16 frames 448x448, S=2112, 1 sample/GPU", "per_gpu_batch": 1,
+                "config": {"workload": ("BASELINE.json configs[2] per GPU: " if args.mode == "train_full" else "") +
+                                       "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd with per-layer recompute, LoRA r128 q/v + lm_head + embed_tokens "
+                                       "trainable, AdamW step, bucketed RCCL all-reduce; 16 frames 448x448, S=2112, 1 sample/GPU" +
+                                       (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)"
+                                        if args.mode == "train_full" else ""), "per_gpu_batch": 1,
                            "seq_len": 2112, "parallelism": f"dp{world}", "trainable_params": n_train, "approx_flops_per_sample": fl},
                 "roofline": {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                              "frac": round(fl / (ms * 1e-3) / PEAK_BF16, 4), "traffic": None, "note": "whole-step algorithmic FLOPs / step time"},
