@@ -253,6 +253,7 @@ def main():
     roof = None
     if rank == 0 and args.mode == "forward":
         ev = []
+        alg_bytes = [0]
         real_gemm = ops.gemm
 
         def timed_gemm(*a, **k):
@@ -261,6 +262,7 @@ def main():
             r = real_gemm(*a, **k)
             e.record()
             ev.append((s, e))
+            alg_bytes[0] += 2 * (a[0].numel() + a[1].numel()) + r.numel() * r.element_size()
             return r
 
         import rga3.model.qwen2_5_vl as qm
@@ -279,7 +281,15 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
                 "launches_per_step": n_launch, "avg_launch_ms": round(gemm_ms_step / max(n_launch, 1), 5),
                 "gemm_ms_per_step": round(gemm_ms_step, 3),
-                "whole_forward_frac": round(TOTAL_FLOPS / (ms * 1e-3) / PEAK_BF16, 4)}
+                "whole_forward_frac": round(TOTAL_FLOPS / (ms * 1e-3) / PEAK_BF16, 4),
+                "algorithmic_bytes_per_launch": round(alg_bytes[0] / max(len(ev), 1))}
+        # HBM traffic cannot be sampled inside the timed run (PMC needs rocprofv3): it comes from the committed two-pass
+        # FETCH_SIZE / WRITE_SIZE collection of this same command, summarised by tools/pmc_traffic.py.
+        tpath = os.path.join(ROOT, "profiles", "r01_bench_forward_gemm_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            roof["traffic"] = round(tj["traffic_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/r01_bench_forward_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.mode == "forward":

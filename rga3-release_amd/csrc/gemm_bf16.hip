@@ -18,8 +18,13 @@
 //    16 B/lane, 128 B contiguous per row; the residual add is fused there with coalesced loads.
 //  * 1-D grid with a bijective XCD remap + grouped tile order so neighbouring tiles share an L2.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <type_traits>
 
 namespace rga3 {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SWIGLU = 2, ACT_RELU = 3 };
 
@@ -40,6 +45,151 @@ __device__ const u32x4 g_zero16 = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- epilogue shared by all main loops.  Lane (g = lane>>4, c = lane&15) holds, for m-tile i / n-tile j of the wave's
+//      WTM x WTN block, row c and columns 4g..4g+3 of the 16x16 sub-block (swapped-operand MFMA).
+template <int NTL, int ACT, bool OUT_F32>
+constexpr int epi_wave_bytes() {  // LDS staging bytes one wave needs in gemm_epilogue (16 rows, padded)
+    return 16 * (((ACT == ACT_SWIGLU) ? NTL / 2 : NTL) * 16 * (OUT_F32 ? 4 : 2) + 16);
+}
+
+template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmArgs& p, char* est, int lane, int m0, int n0,
+                                              int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr) {
+    // part1 / part2 (stream-K owner slices only): this lane's view of up to two f32 partial-sum slabs in accumulator order
+    // (quad (i, j) at [(i * NTL + j) * 64]).  They are added to the accumulators as those are READ, one m-tile ahead of use,
+    // so the accumulator registers are never modified after the main loop (a post-loop "acc += slab" makes the register
+    // allocator keep two copies of the 128 accumulators and spill).
+    constexpr int PD = (ACT == ACT_SWIGLU) ? 1 : 2;  // m-tiles of slab reads in flight (latency-bound below 8 x 16 B per lane;
+                                                     // the SwiGLU epilogue has no registers for the second one)
+    f32x4 pn[PD][NTL];
+    auto load_part = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            f32x4 v = part1[(i * NTL + j) * 64];
+            if (part2) v += part2[(i * NTL + j) * 64];
+            pn[i % PD][j] = v;
+        }
+    };
+    if (part1) {
+        load_part(0);
+        if (PD > 1 && MT > 1) load_part(1);
+    }
+
+    // ---- epilogue.  Lane (g = lane>>4, c = lane&15) holds, for m-tile i / n-tile j, row c and
+    //      columns 4g..4g+3 of the 16x16 block.
+    constexpr int OUT_NT = (ACT == ACT_SWIGLU) ? NTL / 2 : NTL;  // output n-tiles per wave
+    constexpr int OW = OUT_NT * 16;                               // output columns per wave
+    constexpr int ESZ = OUT_F32 ? 4 : 2;
+    constexpr int EDAT = OW * ESZ;  // payload bytes per staged row
+    constexpr int EROW = EDAT + 16; // +16 B pad: rows no longer alias on the 128-B ds_write bank period (was 16-way conflicts)
+    const int g = lane >> 4, c = lane & 15;
+    const int ncol0 = (ACT == ACT_SWIGLU) ? (n0 / 2 + wn * OW) : (n0 + wn * OW);  // first output column of this wave
+    const int Nout = (ACT == ACT_SWIGLU) ? p.N / 2 : p.N;
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        f32x4 pc[NTL];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) pc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (part1) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) pc[j] = pn[i % PD][j];
+            if (i + PD < MT) load_part(i + PD);
+        }
+#pragma unroll
+        for (int jo = 0; jo < OUT_NT; ++jo) {
+            float v[4];
+            if constexpr (ACT == ACT_SWIGLU) {
+                // packed weight layout: n-tile 2*jo = gate columns, 2*jo+1 = up columns of the same 16 outputs
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float gt = acc[i][2 * jo][r] + pc[2 * jo][r], up = acc[i][2 * jo + 1][r] + pc[2 * jo + 1][r];
+                    if (p.bias) {
+                        int nb = n0 + wn * WTN + (2 * jo) * 16 + 4 * g + r;
+                        gt += bf2f(p.bias[min(nb, p.N - 1)]);
+                        up += bf2f(p.bias[min(nb + 16, p.N - 1)]);
+                    }
+                    // reference rounds gate/up linear outputs to bf16 before the activation (bf16 nn.Linear)
+                    gt = bf2f(f2bf(gt));
+                    up = bf2f(f2bf(up));
+                    v[r] = bf2f(f2bf(silu_f(gt))) * up;
+                    if (p.colscale) v[r] *= bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][jo][r] + pc[jo][r];
+                    if (p.bias) {
+                        int nb = n0 + wn * WTN + jo * 16 + 4 * g + r;
+                        x += bf2f(p.bias[min(nb, p.N - 1)]);
+                    }
+                    if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
+                    if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
+                    if (p.colscale) x = bf2f(f2bf(x)) * bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);
+                    v[r] = x;
+                }
+            }
+            if constexpr (OUT_F32) {
+                *(f32x4*)(est + c * EROW + (jo * 16 + 4 * g) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                u32x2 pk;
+                pk[0] = pack_bf2(v[0], v[1]);
+                pk[1] = pack_bf2(v[2], v[3]);
+                *(u32x2*)(est + c * EROW + (jo * 16 + 4 * g) * 2) = pk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // read back row-major: 16 rows x EROW bytes, 16 B per lane
+        constexpr int CPR = EDAT / 16;       // 16-byte chunks per row
+        constexpr int TOTAL = 16 * CPR;      // chunks in the staged block
+        constexpr int EPC = 16 / ESZ;        // elements per chunk
+#pragma unroll
+        for (int q = lane; q < TOTAL; q += 64) {
+            int rr = q / CPR, cc = q % CPR;
+            int gm = m0 + wm * WTM + i * 16 + rr;
+            int gn = ncol0 + cc * EPC;
+            u32x4 val = *(const u32x4*)(est + rr * EROW + cc * 16);
+            if (gm < p.M && gn < Nout) {
+                if constexpr (OUT_F32) {
+                    float* dst = (float*)p.C + (long)gm * p.ldc + gn;
+                    if (gn + 4 <= Nout && ((p.ldc & 3) == 0)) {
+                        *(u32x4*)dst = val;
+                    } else {
+                        for (int e = 0; e < 4 && gn + e < Nout; ++e) dst[e] = __uint_as_float(val[e]);
+                    }
+                } else {
+                    unsigned short* dst = (unsigned short*)p.C + (long)gm * p.ldc + gn;
+                    const bool vec = (gn + 8 <= Nout) && ((p.ldc & 7) == 0);
+                    if (p.res) {
+                        const unsigned short* rs = p.res + (long)gm * p.ldr + gn;
+                        unsigned short o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            unsigned int w = val[e >> 1];
+                            unsigned short h = (e & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffff);
+                            float rv = (gn + e < Nout) ? bf2f(rs[e]) : 0.f;
+                            o[e] = f2bf(bf2f(h) + rv);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) val[e] = (unsigned)o[2 * e] | ((unsigned)o[2 * e + 1] << 16);
+                    }
+                    if (vec) {
+                        *(u32x4*)dst = val;
+                    } else {
+                        for (int e = 0; e < 8 && gn + e < Nout; ++e) {
+                            unsigned int w = val[e >> 1];
+                            dst[e] = (e & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffff);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
 
 template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
@@ -208,113 +358,591 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     }
     }
     __syncthreads();  // all waves done with the last stage: LDS is free for the epilogue staging
+    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wm, wn);
+}
 
-    // ---- epilogue.  Lane (g = lane>>4, c = lane&15) holds, for m-tile i / n-tile j, row c and
-    //      columns 4g..4g+3 of the 16x16 block.
-    constexpr int OUT_NT = (ACT == ACT_SWIGLU) ? NTL / 2 : NTL;  // output n-tiles per wave
-    constexpr int OW = OUT_NT * 16;                               // output columns per wave
-    constexpr int ESZ = OUT_F32 ? 4 : 2;
-    constexpr int EDAT = OW * ESZ;  // payload bytes per staged row
-    constexpr int EROW = EDAT + 16; // +16 B pad: rows no longer alias on the 128-B ds_write bank period (was 16-way conflicts)
-    char* est = smem + wid * (16 * EROW);
-    const int g = lane >> 4, c = lane & 15;
-    const int ncol0 = (ACT == ACT_SWIGLU) ? (n0 / 2 + wn * OW) : (n0 + wn * OW);  // first output column of this wave
-    const int Nout = (ACT == ACT_SWIGLU) ? p.N / 2 : p.N;
+// =====================================================================================================================
+// 256x256 "ping-pong" main loop (tile id 20): 8 waves = two groups of four (one wave of each group per SIMD) that run
+// the same phase sequence ONE BARRIER APART, so while one group issues its MFMA cluster the other reads fragments and
+// issues the next LDS-DMA.  Structure after cdna_hip_programming.md "256^2 8-phase template" (counted vmcnt, never 0 in
+// the steady state; raw s_barrier; s_setprio around the MFMA clusters), laid out for this kernel's operand order:
+//
+//  * a K-tile (64 deep) is four 16-KiB half-tiles  A0 A1 B0 B1  (128 LDS rows x 128 B).  A_h holds, for each of the two
+//    wave rows wr, tile rows wr*128 + h*64 + [0,64); B_h holds for each wave column wc tile columns wc*64 + h*32 + [0,32):
+//    every wave still owns one CONTIGUOUS 128x64 block of C (the epilogue above is unchanged), and quadrant (ha, hb) of
+//    that block needs exactly half-tiles A_ha and B_hb.
+//  * per K-tile four phases, one quadrant (16 MFMAs) each:  Q00 [reads A0,B0]  Q01 [reads B1]  Q11 [reads A1]  Q10 [-].
+//  * half-tiles are staged in the order S = A0 B0 B1 A1 of tile 0, tile 1, ...; phase g (counted from 0) issues S[g+6]
+//    into a region whose last read was >= 2 phases earlier, then waits until all but the 4 youngest half-tiles (8 loads
+//    per lane) have landed => S[<= g+2] are complete, and they are first read in phase g+1 (two barriers later).
+// LDS: 2 buffers x 4 half-tiles x 16 KiB = 128 KiB, one workgroup per CU, 2 waves per SIMD.
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
+    constexpr int HALF = 128 * ROWB;  // 16 KiB
+    constexpr int BUF = 4 * HALF;     // A0 | A1 | B0 | B1
+    constexpr int MT = 8, NTL = 4;
 
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;  // waves w and w+4 share a SIMD: one of each group per SIMD
+
+    const unsigned nwg = (unsigned)(p.ntm * p.ntn);
+    const unsigned t = xcd_remap(blockIdx.x, nwg);
+    constexpr unsigned GROUP_M = 4;
+    const unsigned per_group = GROUP_M * p.ntn;
+    const unsigned group = t / per_group;
+    const unsigned first_m = group * GROUP_M;
+    const unsigned gsz = min((unsigned)p.ntm - first_m, GROUP_M);
+    const unsigned tm = first_m + (t % per_group) % gsz;
+    const unsigned tn = (t % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging: every half-tile is 2 LDS-DMA pieces (8 rows x 128 B) per wave; source-side XOR swizzle as above.
+    //      kind 0..3 = A0 A1 B0 B1 (LDS order); soff[kind][piece] = element offset of this lane's 16-byte chunk at k = 0
+    const int sch = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);  // source chunk (same for both pieces)
+    unsigned soff[4][2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wid + 8 * i) * 8 + (lane >> 3);  // LDS row of the half-tile, 0..127
 #pragma unroll
-        for (int jo = 0; jo < OUT_NT; ++jo) {
-            float v[4];
-            if constexpr (ACT == ACT_SWIGLU) {
-                // packed weight layout: n-tile 2*jo = gate columns, 2*jo+1 = up columns of the same 16 outputs
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float gt = acc[i][2 * jo][r], up = acc[i][2 * jo + 1][r];
-                    if (p.bias) {
-                        int nb = n0 + wn * WTN + (2 * jo) * 16 + 4 * g + r;
-                        gt += bf2f(p.bias[min(nb, p.N - 1)]);
-                        up += bf2f(p.bias[min(nb + 16, p.N - 1)]);
-                    }
-                    // reference rounds gate/up linear outputs to bf16 before the activation (bf16 nn.Linear)
-                    gt = bf2f(f2bf(gt));
-                    up = bf2f(f2bf(up));
-                    v[r] = bf2f(f2bf(silu_f(gt))) * up;
-                    if (p.colscale) v[r] *= bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][jo][r];
-                    if (p.bias) {
-                        int nb = n0 + wn * WTN + jo * 16 + 4 * g + r;
-                        x += bf2f(p.bias[min(nb, p.N - 1)]);
-                    }
-                    if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
-                    if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
-                    if (p.colscale) x = bf2f(f2bf(x)) * bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);
-                    v[r] = x;
-                }
-            }
-            if constexpr (OUT_F32) {
-                *(f32x4*)(est + c * EROW + (jo * 16 + 4 * g) * 4) = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                u32x2 pk;
-                pk[0] = pack_bf2(v[0], v[1]);
-                pk[1] = pack_bf2(v[2], v[3]);
-                *(u32x2*)(est + c * EROW + (jo * 16 + 4 * g) * 2) = pk;
-            }
+        for (int h = 0; h < 2; ++h) {
+            const int arow = (r >> 6) * 128 + h * 64 + (r & 63);
+            const int bcol = (r >> 5) * 64 + h * 32 + (r & 31);
+            soff[h][i] = (unsigned)((long)min(m0 + arow, p.M - 1) * p.lda + sch * 8);
+            soff[2 + h][i] = (unsigned)((long)min(n0 + bcol, p.N - 1) * p.ldw + sch * 8);
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // read back row-major: 16 rows x EROW bytes, 16 B per lane
-        constexpr int CPR = EDAT / 16;       // 16-byte chunks per row
-        constexpr int TOTAL = 16 * CPR;      // chunks in the staged block
-        constexpr int EPC = 16 / ESZ;        // elements per chunk
-#pragma unroll
-        for (int q = lane; q < TOTAL; q += 64) {
-            int rr = q / CPR, cc = q % CPR;
-            int gm = m0 + wm * WTM + i * 16 + rr;
-            int gn = ncol0 + cc * EPC;
-            u32x4 val = *(const u32x4*)(est + rr * EROW + cc * 16);
-            if (gm < p.M && gn < Nout) {
-                if constexpr (OUT_F32) {
-                    float* dst = (float*)p.C + (long)gm * p.ldc + gn;
-                    if (gn + 4 <= Nout && ((p.ldc & 3) == 0)) {
-                        *(u32x4*)dst = val;
-                    } else {
-                        for (int e = 0; e < 4 && gn + e < Nout; ++e) dst[e] = __uint_as_float(val[e]);
-                    }
-                } else {
-                    unsigned short* dst = (unsigned short*)p.C + (long)gm * p.ldc + gn;
-                    const bool vec = (gn + 8 <= Nout) && ((p.ldc & 7) == 0);
-                    if (p.res) {
-                        const unsigned short* rs = p.res + (long)gm * p.ldr + gn;
-                        unsigned short o[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            unsigned int w = val[e >> 1];
-                            unsigned short h = (e & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffff);
-                            float rv = (gn + e < Nout) ? bf2f(rs[e]) : 0.f;
-                            o[e] = f2bf(bf2f(h) + rv);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) val[e] = (unsigned)o[2 * e] | ((unsigned)o[2 * e + 1] << 16);
-                    }
-                    if (vec) {
-                        *(u32x4*)dst = val;
-                    } else {
-                        for (int e = 0; e < 8 && gn + e < Nout; ++e) {
-                            unsigned int w = val[e >> 1];
-                            dst[e] = (e & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffff);
-                        }
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    const int nk = (p.K + BK - 1) / BK;
+    const bool ktail = (p.K % BK) != 0;
+    auto stage = [&](auto KIND, int kt, int buf) {
+        constexpr int kind = decltype(KIND)::value;
+        const unsigned short* base = ((kind < 2) ? p.A : p.W) + (long)kt * BK;  // scalar part first: saddr + 32-bit voffset form
+        char* dst = smem + buf * BUF + kind * HALF + wid * 1024;
+        if (ktail && kt == nk - 1) {
+            const bool ok = kt * BK + sch * 8 < p.K;  // chunks at or beyond K come from 16 zero bytes
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned short* src = ok ? base + soff[kind][i] : (const unsigned short*)&g_zero16;
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + i * 8192), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(base + soff[kind][i]), (lds_void*)(dst + i * 8192), 16, 0, 0);
+        }
+    };
+    using K_A0 = std::integral_constant<int, 0>;
+    using K_A1 = std::integral_constant<int, 1>;
+    using K_B0 = std::integral_constant<int, 2>;
+    using K_B1 = std::integral_constant<int, 3>;
+    // wait until at most n half-tiles (2 loads each) issued by this lane are still in flight
+    auto wait_halftiles = [&](int n) {
+        if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    int foff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + (((kk * 4 + (lane >> 4)) ^ ((lane >> 1) & 7)) << 4);
+    const int a_rd = (wr * 64) * ROWB;                 // + h*HALF + mi*2048 + foff[kk]
+    const int b_rd = 2 * HALF + (wc * 32) * ROWB;      // + h*HALF + ni*2048 + foff[kk]
+
+    f32x4 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    auto read_a = [&](const char* cur, int h) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8*)(cur + a_rd + h * HALF + mi * 2048 + foff[kk]);
+    };
+    auto read_b = [&](bf16x8 (&bf)[2][2], const char* cur, int h) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bf[ni][kk] = *(const bf16x8*)(cur + b_rd + h * HALF + ni * 2048 + foff[kk]);
+    };
+    auto mma_quadrant = [&](auto HA, auto HB, const bf16x8 (&bf)[2][2]) {
+        constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[ha * 4 + mi][hb * 2 + ni] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni][kk], af[mi][kk], acc[ha * 4 + mi][hb * 2 + ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: S[0..5] = tile 0 complete + A0, B0 of tile 1
+    stage(K_A0{}, 0, 0);
+    stage(K_B0{}, 0, 0);
+    stage(K_B1{}, 0, 0);
+    stage(K_A1{}, 0, 0);
+    if (nk > 1) {
+        stage(K_A0{}, 1, 1);
+        stage(K_B0{}, 1, 1);
+    }
+    wait_halftiles(nk > 1 ? 4 : 2);  // S[0], S[1] landed (own loads) ...
+    __builtin_amdgcn_s_barrier();    // ... and everyone's
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind the first
+
+    const int last = 4 * nk - 1;  // index of the last half-tile
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const char* cur = smem + buf * BUF;
+        const int g = 4 * kt;
+        const bool steady = kt + 2 < nk;
+        // phase 1: Q00
+        read_a(cur, 0);
+        read_b(b0, cur, 0);
+        if (kt + 1 < nk) stage(K_B1{}, kt + 1, buf ^ 1);
+        if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(min(g + 6, last) - (g + 2));
+        mma_quadrant(H0{}, H0{}, b0);
+        // phase 2: Q01
+        read_b(b1, cur, 1);
+        if (kt + 1 < nk) stage(K_A1{}, kt + 1, buf ^ 1);
+        if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(min(g + 7, last) - (g + 3));
+        mma_quadrant(H0{}, H1{}, b1);
+        // phase 3: Q11
+        read_a(cur, 1);
+        if (kt + 2 < nk) stage(K_A0{}, kt + 2, buf);
+        if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(min(g + 8, last) - (g + 4));
+        mma_quadrant(H1{}, H1{}, b1);
+        // phase 4: Q10
+        if (kt + 2 < nk) stage(K_B0{}, kt + 2, buf);
+        if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(max(min(g + 9, last) - (g + 5), 0));
+        mma_quadrant(H1{}, H0{}, b0);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the groups
+    __syncthreads();  // LDS is free for the epilogue staging
+    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wr, wc);
+}
+
+// In-place accumulate (C-in register == C-out register).  The builtin lets the register allocator pick a different
+// destination, and inside the persistent item loop it does - 32 extra live registers and spills in the MFMA phases.
+// Hazards: operands come from ds_read (waited by lgkmcnt) and from MFMAs >= 7 instructions earlier; the first VALU
+// read of an accumulator after the loop is behind several barriers.
+__device__ __forceinline__ void mfma_inplace(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// =====================================================================================================================
+// Persistent ping-pong GEMM with a stream-K tail (tile ids 21 / 22).  One workgroup per CU walks a list of work items:
+//   [its non-owner slice of a split tile]  [its data-parallel tiles  w, w+P, w+2P, ...]  [its owner slice of a split tile]
+// * The first K-tile of the NEXT item is prefetched (LDS-DMA) before the epilogue of the current one, so the store tail
+//   and the load prologue overlap (short-K shapes: ViT K = 1280 is 20 K-tiles per tile).
+// * Stream-K tail (id 22): the T mod P tiles of the last, partly filled round are cut into equal runs of K-iterations over
+//   P_sk workgroups instead of leaving P - (T mod P) CUs idle.  A run touches at most two tiles: the END of tile a (this
+//   workgroup then owns a: it adds the partial sums of the lower-numbered workgroups that computed a's earlier
+//   K-iterations and runs the epilogue) and the START of tile a+1 (partial sums go to this workgroup's f32 slab).
+//   Non-owner slices never wait and are computed first, owner slices last, so an owner only ever waits for work that needs
+//   nothing from anybody (no cycles; every spin is bounded all the same and reports into sk.tmo).
+//   Hand-off = cdna_hip_programming.md Guideline 16, plain-store form: slab stores, every wave vmcnt(0), barrier, one lane
+//   agent-scope release fence + wait, relaxed agent flag store; owner: one lane polls relaxed, agent-scope acquire fence,
+//   wait, barrier, then plain vector loads.  Flags are zero at allocation and reset by their single consumer.
+//   The split is a pure function of (M, N, K, P): results are reproducible run to run.
+struct SkArgs {
+    float* slabs;     // [P][512 lanes][32] f32x4 in register order (256 KiB per workgroup)
+    unsigned* flags;  // [P] 1 = slab written
+    unsigned* tmo;    // bounded-spin give-up counter (diagnostic)
+    int P;            // workgroups launched
+    int P_sk;         // workgroups that take part in the stream-K tail
+    int t_dp;         // tiles [0, t_dp) are data-parallel (t_dp % P == 0 or sk_tiles == 0)
+    int sk_tiles;     // tiles [t_dp, t_dp + sk_tiles) are split
+};
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) {
+    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
+    constexpr int HALF = 128 * ROWB;
+    constexpr int BUF = 4 * HALF;
+    constexpr int MT = 8, NTL = 4;
+    constexpr int EPW = epi_wave_bytes<NTL, ACT, OUT_F32>();
+    // epilogue staging lives in the A1 / B1 regions of buffer 0 (waves 0-3 / 4-7) so that the next item's first six
+    // half-tiles (buffer 1 complete, A0 + B0 of buffer 0) can be in flight during the epilogue; the f32 epilogue needs
+    // more than 16 KiB per four waves, so that variant prefetches after its epilogue instead.
+    constexpr bool PREFETCH = (4 * EPW <= HALF);
+#ifndef FIXB_N
+#define FIXB_N 8
+#endif
+    constexpr int FIXB = FIXB_N;  // slab quads in flight per batch while adding partial sums
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int w = (int)xcd_remap(blockIdx.x, (unsigned)sk.P);  // logical workgroup id: consecutive ids share an XCD
+    const int nk = (p.K + BK - 1) / BK;
+    // K % 64 == 0 here (the launcher sends ragged K to the one-tile-per-workgroup kernel, which has the zero-source tail)
+    char* est = PREFETCH ? smem + (wr ? 3 * HALF : HALF) + wc * EPW : smem + wid * EPW;
+
+    // ---- work list
+    int na_tile = -1, na_kb = 0, na_ke = 0;  // non-owner slice (first)
+    int ow_tile = -1, ow_kb = 0;             // owner slice [ow_kb, nk) (last)
+    if (sk.sk_tiles > 0 && w < sk.P_sk) {
+        const long tot = (long)sk.sk_tiles * nk;
+        const long it0 = (long)w * tot / sk.P_sk, it1 = (long)(w + 1) * tot / sk.P_sk;
+        if (it0 < it1) {
+            const int ta = (int)(it0 / nk);
+            const long tend = (long)(ta + 1) * nk;
+            if (it1 >= tend) {
+                ow_tile = sk.t_dp + ta;
+                ow_kb = (int)(it0 - (long)ta * nk);
+                if (it1 > tend) { na_tile = sk.t_dp + ta + 1; na_kb = 0; na_ke = (int)(it1 - tend); }
+            } else {
+                na_tile = sk.t_dp + ta; na_kb = (int)(it0 - (long)ta * nk); na_ke = (int)(it1 - (long)ta * nk);
+            }
+        }
+    }
+    const int n_dp = (w < sk.t_dp) ? (sk.t_dp - w + sk.P - 1) / sk.P : 0;
+    const int n_items = (na_tile >= 0) + n_dp + (ow_tile >= 0);
+    if (n_items == 0) return;
+    // item i -> (tile, kb, ke, kind): kind 0 = whole tile, 1 = non-owner slice, 2 = owner slice
+    auto item = [&](int i, int& tile, int& kb, int& ke, int& kind) {
+        if (na_tile >= 0) {
+            if (i == 0) { tile = na_tile; kb = na_kb; ke = na_ke; kind = 1; return; }
+            --i;
+        }
+        if (i < n_dp) { tile = w + i * sk.P; kb = 0; ke = nk; kind = 0; return; }
+        tile = ow_tile; kb = ow_kb; ke = nk; kind = (ow_kb > 0) ? 2 : 0;
+    };
+
+    unsigned soff[4][2];
+    int nm0 = 0, nn0 = 0;  // tile origin of the item whose offsets are in soff
+    auto setup_tile = [&](int tile, int lane) {
+        const int sch = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
+        constexpr unsigned GROUP_M = 4;
+        const unsigned t = (unsigned)tile;
+        const unsigned per_group = GROUP_M * p.ntn;
+        const unsigned group = t / per_group;
+        const unsigned first_m = group * GROUP_M;
+        const unsigned gsz = min((unsigned)p.ntm - first_m, GROUP_M);
+        nm0 = (int)(first_m + (t % per_group) % gsz) * BM;
+        nn0 = (int)((t % per_group) / gsz) * BN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wid + 8 * i) * 8 + (lane >> 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int arow = (r >> 6) * 128 + h * 64 + (r & 63);
+                const int bcol = (r >> 5) * 64 + h * 32 + (r & 31);
+                soff[h][i] = (unsigned)((long)min(nm0 + arow, p.M - 1) * p.lda + sch * 8);
+                soff[2 + h][i] = (unsigned)((long)min(nn0 + bcol, p.N - 1) * p.ldw + sch * 8);
+            }
+        }
+    };
+    auto stage = [&](auto KIND, int kt, int buf) {
+        constexpr int kind = decltype(KIND)::value;
+        const unsigned short* base = ((kind < 2) ? p.A : p.W) + (long)kt * BK;  // scalar part first: saddr + 32-bit voffset form
+        char* dst = smem + buf * BUF + kind * HALF + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned o = soff[kind][i];
+            asm volatile("" : "+v"(o));  // keep the offsets 32-bit in registers (the compiler otherwise holds 8 zero-extended pairs)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(dst + i * 8192), 16, 0, 0);
+        }
+    };
+    using K_A0 = std::integral_constant<int, 0>;
+    using K_A1 = std::integral_constant<int, 1>;
+    using K_B0 = std::integral_constant<int, 2>;
+    using K_B1 = std::integral_constant<int, 3>;
+    auto wait_halftiles = [&](int n) {
+        if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // the first K-tile of an item always goes to buffer 1, the second to buffer 0, ...
+    auto prologue_issue = [&](int kb, int ke) {
+        stage(K_A0{}, kb, 1);
+        stage(K_B0{}, kb, 1);
+        stage(K_B1{}, kb, 1);
+        stage(K_A1{}, kb, 1);
+        if (ke - kb > 1) {
+            stage(K_A0{}, kb + 1, 0);
+            stage(K_B0{}, kb + 1, 0);
+        }
+    };
+
+    int foff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + (((kk * 4 + (lane >> 4)) ^ ((lane >> 1) & 7)) << 4);
+    const int a_rd = (wr * 64) * ROWB;
+    const int b_rd = 2 * HALF + (wc * 32) * ROWB;
+
+    f32x4 acc[MT][NTL];
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    auto read_a = [&](const char* cur, int h) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8*)(cur + a_rd + h * HALF + mi * 2048 + foff[kk]);
+    };
+    auto read_b = [&](bf16x8 (&bf)[2][2], const char* cur, int h) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bf[ni][kk] = *(const bf16x8*)(cur + b_rd + h * HALF + ni * 2048 + foff[kk]);
+    };
+    auto mma_quadrant = [&](auto HA, auto HB, const bf16x8 (&bf)[2][2]) {
+        constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    mfma_inplace(acc[ha * 4 + mi][hb * 2 + ni], bf[ni][kk], af[mi][kk]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+
+    int tile, kb, ke, kind;
+    item(0, tile, kb, ke, kind);
+    setup_tile(tile, lane);
+    prologue_issue(kb, ke);
+
+    for (int it = 0; it < n_items; ++it) {
+        const int m0 = nm0, n0 = nn0;
+        // ---- all six (or four) prologue half-tiles have been issued; older stores of the previous epilogue count in
+        //      vmcnt too, so simply drain: the loads have been in flight for a whole epilogue
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        const int nkt = ke - kb;
+        const int last = 4 * nkt - 1;
+        int q = 0;
+        do {  // nkt >= 1 always; the do-while form keeps one accumulator live range (no zero-trip merge after the loop)
+            const int kt = kb + q;
+            const int buf = (q + 1) & 1;
+            const char* cur = smem + buf * BUF;
+            const int g = 4 * q;
+            const bool steady = q + 2 < nkt;
+            read_a(cur, 0);
+            read_b(b0, cur, 0);
+            if (q + 1 < nkt) stage(K_B1{}, kt + 1, buf ^ 1);
+            if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(min(g + 6, last) - (g + 2));
+            mma_quadrant(H0{}, H0{}, b0);
+            read_b(b1, cur, 1);
+            if (q + 1 < nkt) stage(K_A1{}, kt + 1, buf ^ 1);
+            if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(min(g + 7, last) - (g + 3));
+            mma_quadrant(H0{}, H1{}, b1);
+            read_a(cur, 1);
+            if (q + 2 < nkt) stage(K_A0{}, kt + 2, buf);
+            if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(min(g + 8, last) - (g + 4));
+            mma_quadrant(H1{}, H1{}, b1);
+            if (q + 2 < nkt) stage(K_B0{}, kt + 2, buf);
+            if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(max(min(g + 9, last) - (g + 5), 0));
+            mma_quadrant(H1{}, H0{}, b0);
+        } while (++q < nkt);
+        asm volatile("s_nop 15" ::: "memory");  // asm MFMA results -> first compiler-generated reader (hipcc pads nothing for asm)
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        __syncthreads();  // every wave is past its last fragment read: both buffers are free
+
+        const int cur_kind = kind;
+        const bool has_next = it + 1 < n_items;
+        // everything below is per-item work: keep its lane-dependent address math out of the main loop's live ranges
+        // (the compiler otherwise hoists it above the item loop and spills inside the MFMA phases)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        if (has_next) {
+            item(it + 1, tile, kb, ke, kind);
+            setup_tile(tile, lane_e);
+            if constexpr (PREFETCH) prologue_issue(kb, ke);
+        }
+
+        if (cur_kind == 1) {
+            // ---- non-owner slice: partial sums -> this workgroup's slab, then publish
+            f32x4* slab = (f32x4*)sk.slabs + (size_t)w * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    *slab = acc[i][j];
+                    slab += 64;
+                    asm volatile("" : "+v"(slab));  // one running address, not 32 precomputed ones
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(sk.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            const f32x4 *part1 = nullptr, *part2 = nullptr;
+            if (cur_kind == 2) {
+                // ---- owner slice: add the partial sums of the (at most two: P_sk <= 2 * sk_tiles) lower-numbered
+                //      workgroups that computed this tile's earlier K-iterations
+                const long tot = (long)sk.sk_tiles * nk;
+                const long x0 = (long)(ow_tile - sk.t_dp) * nk;  // first iteration of this tile in stream-K numbering
+                const bool two = w >= 2 && ((long)(w - 1) * tot / sk.P_sk) > x0;
+                if (tid == 0) {
+                    for (int c = 0; c < (two ? 2 : 1); ++c) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(sk.flags + (w - 1 - c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 22)) {
+                                __hip_atomic_fetch_add(sk.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                part1 = (const f32x4*)sk.slabs + (size_t)(w - 1) * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
+                if (two) part2 = part1 - 512 * 32;
+            }
+            gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32>(acc, p, est, lane_e, m0, n0, wr, wc, part1, part2);
+            if (cur_kind == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // every wave has consumed its slab values ...
+                if (tid == 0) {   // ... re-arm the flags for the next launch
+                    __hip_atomic_store(sk.flags + (w - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (part2) __hip_atomic_store(sk.flags + (w - 2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();  // epilogue staging reads are done before phase 0 / 1 of the next item restage A1 / B1 of buffer 0
+        if constexpr (!PREFETCH) {
+            if (has_next) prologue_issue(kb, ke);
+        }
+    }
+}
+
+struct SkWorkspace { float* slabs; unsigned* flags; int P; };
+
+// one workspace per stream (kernels on a stream serialize; different streams must not share slabs)
+static int sk_workspace(hipStream_t st, SkWorkspace& out) {
+    static std::mutex mu;
+    static std::map<hipStream_t, SkWorkspace> table;
+    std::lock_guard<std::mutex> lk(mu);
+    auto f = table.find(st);
+    if (f != table.end()) { out = f->second; return 0; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 1;  // cannot allocate while capturing
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cus <= 0) return fail(-(int)e, "gemm: cannot query CU count: %s", hipGetErrorString(e));
+    SkWorkspace ws;
+    ws.P = cus;
+    const size_t slab_bytes = (size_t)cus * 512 * 32 * 16;
+    const size_t flag_bytes = ((size_t)(cus + 4) * 4 + 255) / 256 * 256;
+    char* base = nullptr;
+    e = hipMalloc((void**)&base, flag_bytes + slab_bytes);
+    if (e != hipSuccess) return fail(-(int)e, "gemm: stream-K workspace hipMalloc(%zu): %s", flag_bytes + slab_bytes, hipGetErrorString(e));
+    e = hipMemset(base, 0, flag_bytes);
+    if (e != hipSuccess) return fail(-(int)e, "gemm: stream-K workspace memset: %s", hipGetErrorString(e));
+    ws.flags = (unsigned*)base;
+    ws.slabs = (float*)(base + flag_bytes);
+    table[st] = ws;
+    out = ws;
+    return 0;
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_pp(const GemmArgs& a0, hipStream_t st);
+
+template <int ACT, bool OUT_F32>
+static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
+    GemmArgs a = a0;
+    a.ntm = (int)cdiv(a.M, 256);
+    a.ntn = (int)cdiv(a.N, 256);
+    SkWorkspace ws;
+    if (a.K % 64 != 0) return launch_pp<ACT, OUT_F32>(a0, st);  // ragged K: zero-source tail lives in the one-tile kernel
+    int rc = sk_workspace(st, ws);
+    if (rc == 1) return launch_pp<ACT, OUT_F32>(a0, st);  // graph capture before the first eager call on this stream
+    if (rc) return rc;
+    const int T = a.ntm * a.ntn;
+    const int nk = (int)cdiv(a.K, 64);
+    SkArgs sk;
+    sk.slabs = ws.slabs;
+    sk.flags = ws.flags;
+    sk.tmo = ws.flags + ws.P;
+    const int rem = T % ws.P;
+    if (!split || rem == 0) {
+        sk.P = T < ws.P ? T : ws.P;
+        sk.t_dp = T;
+        sk.sk_tiles = 0;
+        sk.P_sk = 0;
+    } else {
+        // slices per split tile <= 3 (owner + two contributors: the kernel's accumulator init reads at most two slabs)
+        // <=> run length >= nk / 2 <=> P_sk <= 2 * sk_tiles; and no slice shorter than MIN_SEG K-iterations
+        constexpr int MIN_SEG = 8;
+        sk.P = ws.P;
+        sk.t_dp = T - rem;
+        sk.sk_tiles = rem;
+        long cap = (long)rem * nk / MIN_SEG;
+        long want = 2L * rem;
+        if (want > cap) want = cap;
+        if (want > ws.P) want = ws.P;
+        if (want < rem) want = rem;
+        sk.P_sk = (int)want;
+    }
+    constexpr int LDS = 2 * 4 * 128 * 128;
+    auto kern = gemm_nt_sk_kernel<ACT, OUT_F32>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)sk.P), dim3(512), LDS, st, a, sk);
+    RGA3_CHECK_LAUNCH("gemm_nt_sk_kernel");
+    return 0;
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_pp(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
+    a.ntm = (int)cdiv(a.M, 256);
+    a.ntn = (int)cdiv(a.N, 256);
+    constexpr int LDS = 2 * 4 * 128 * 128;
+    auto kern = gemm_nt_pp_kernel<ACT, OUT_F32>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn)), dim3(512), LDS, st, a);
+    RGA3_CHECK_LAUNCH("gemm_nt_pp_kernel");
+    return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE>
@@ -354,7 +982,8 @@ static int pick_tile(int M, int N, int forced) {
         double s = fill * useful * cfgs[i].prior;
         if (s > bs) { bs = s; best = i; }
     }
-    return best;
+    static const int ids[3] = {20, 11, 12};  // ping-pong 256x256, single-phase 256x128 / 128x128
+    return ids[best];
 }
 
 template <int ACT, bool OUT_F32>
@@ -365,6 +994,9 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 2: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 1>(a, st);
         case 3: return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 10: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
+        case 20: return launch_pp<ACT, OUT_F32>(a, st);
+        case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
+        case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
         case 11: return launch_cfg<256, 128, 2, 4, ACT, OUT_F32, 0>(a, st);
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);
     }
@@ -386,7 +1018,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile >= -1 && tile <= 12, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile >= -1 && tile <= 22, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;

@@ -8,7 +8,8 @@ import os
 
 import torch
 
-CANDIDATES = (10, 11, 12, 3, 1)   # 256x256, 256x128, 128x128, 128x256 (single-phase loop) and 256x128 register-pipelined
+CANDIDATES = (20, 21, 22, 11, 12, 3)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
+                                       # single-phase 256x128, 128x128, 128x256
 _cache = {}
 _enabled = os.environ.get("RGA3_GEMM_TUNE", "1") != "0"
 

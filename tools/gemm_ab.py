@@ -1,0 +1,55 @@
+"""Interleaved A/B of GEMM tilings in one process (cdna_hip_programming.md 5.4 rule 24) on random data + a race screen:
+every tiling accumulates each output element in the same k order, so outputs must be BIT-IDENTICAL across tilings and runs.
+  python tools/gemm_ab.py [rounds]"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
+from rga3.hip import ops  # noqa: E402
+
+SHAPES = [(8192, 3840, 1280), (8192, 1280, 1280), (8192, 6848, 1280), (8192, 1280, 3424), (2048, 5120, 5120), (2048, 3584, 5120),
+          (2112, 4608, 3584), (2112, 3584, 3584), (2112, 37888, 3584), (2112, 3584, 18944), (4096, 4096, 4096), (8192, 8192, 8192),
+          (2112, 3584, 1176), (300, 520, 200)]
+TILES = [10, 11, 12, 20, 21, 22]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+res = {}
+for (M, N, K) in SHAPES:
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+    ref = ops.gemm(a, w, tile=10)
+    outs = {t: torch.empty_like(ref) for t in TILES}
+    bad = 0
+    for rep in range(6):            # race screen (20/21 bit-identical to 10; 22 splits K: must be stable run to run and close)
+        for tl in (20, 21):
+            o = ops.gemm(a, w, tile=tl)
+            bad += int(not torch.equal(o, ref))
+    o22 = ops.gemm(a, w, tile=22)
+    for rep in range(6):
+        o = ops.gemm(a, w, tile=22)
+        bad += int(not torch.equal(o, o22))
+    err22 = float((o22.float() - ref.float()).norm() / ref.float().norm())
+    times = {t: [] for t in TILES}
+    iters = max(3, int(2e12 / (2.0 * M * N * K)))
+    iters = min(iters, 50)
+    for r in range(rounds):
+        for t in TILES:
+            ops.gemm(a, w, out=outs[t], tile=t)
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            for _ in range(iters):
+                ops.gemm(a, w, out=outs[t], tile=t)
+            en.record()
+            en.synchronize()
+            times[t].append(st.elapsed_time(en) / iters)
+    line = {"shape": [M, N, K], "race_mismatch": bad, "sk_rel_err": err22}
+    for t in TILES:
+        ts = sorted(times[t])
+        line[f"t{t}_med_tf"] = round(2.0 * M * N * K / ts[len(ts) // 2] / 1e9, 1)
+        line[f"t{t}_eq"] = bool(torch.equal(outs[t], ref))
+    print(json.dumps(line), flush=True)
+    res[f"{M}x{N}x{K}"] = line
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_ab.json"), "w"), indent=1)
