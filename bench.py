@@ -291,6 +291,14 @@ def main():
             roof["traffic"] = round(tj["traffic_bytes_per_launch"])
             roof["traffic_source"] = "profiles/r01_bench_forward_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
 
+    if rank == 0 and os.environ.get("RGA3_TUNE_DUMP"):
+        from rga3.hip import tuner
+        rows = []
+        for k, v in tuner.timings().items():
+            Mb, N, K = k[0], k[1], k[2]
+            rows.append({"key": [str(x) for x in k], "best": tuner.table().get(k), "tf": {str(t): round(2.0 * Mb * 256 * N * K / ms / 1e9, 1) for t, ms in v.items()}})
+        json.dump(rows, open(os.environ["RGA3_TUNE_DUMP"], "w"), indent=1)
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.mode == "forward":
         cpu = cpu_baseline()

@@ -11,6 +11,7 @@ import torch
 CANDIDATES = (20, 21, 22, 11, 12, 3)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
                                        # single-phase 256x128, 128x128, 128x256
 _cache = {}
+_times = {}   # key -> {tile: ms of 3 launches} (diagnostic, see table())
 _enabled = os.environ.get("RGA3_GEMM_TUNE", "1") != "0"
 
 
@@ -28,6 +29,7 @@ def pick(key, run):
     if torch.cuda.is_current_stream_capturing():
         return -1
     best, best_ms = -1, float("inf")
+    _times[key] = {}
     for tile in CANDIDATES:
         run(tile)  # warm (also sets the func attribute for large dynamic LDS)
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,6 +39,7 @@ def pick(key, run):
         en.record()
         en.synchronize()
         ms = st.elapsed_time(en)
+        _times[key][tile] = ms / 3.0
         if ms < best_ms:
             best, best_ms = tile, ms
     _cache[key] = best
@@ -45,3 +48,7 @@ def pick(key, run):
 
 def table():
     return dict(_cache)
+
+
+def timings():
+    return {k: dict(v) for k, v in _times.items()}
