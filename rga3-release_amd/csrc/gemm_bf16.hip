@@ -18,6 +18,7 @@
 //    16 B/lane, 128 B contiguous per row; the residual add is fused there with coalesced loads.
 //  * 1-D grid with a bijective XCD remap + grouped tile order so neighbouring tiles share an L2.
 #include "common.h"
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -38,6 +39,7 @@ struct GemmArgs {
     int M, N, K;
     long lda, ldw, ldc, ldr;
     int ntm, ntn;
+    int dbg;  // RGA3_GEMM_DBG (timing ablations only): bit0 = skip the global stores, bit1 = skip the whole epilogue
 };
 
 // 16 bytes of zeros in device memory: source for staging chunks that lie beyond K in the last K-tile
@@ -73,6 +75,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     // so the accumulator registers are never modified after the main loop (a post-loop "acc += slab" makes the register
     // allocator keep two copies of the 128 accumulators and spill).
     constexpr int PD = 1;  // m-tiles of slab reads in flight ahead of use (2 would hide more latency but spills in the persistent kernel)
+    if (p.dbg & 2) return;
     f32x4 pn[PD][NTL];
     auto load_part = [&](int i) {
 #pragma unroll
@@ -130,6 +133,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             for (int j = 0; j < NTL; ++j) pc[j] = pn[i % PD][j];
             if (i + PD < MT) load_part(i + PD);
         }
+        u32x2 pk[OUT_NT];
+        f32x4 vf[OUT_F32 ? OUT_NT : 1];
 #pragma unroll
         for (int jo = 0; jo < OUT_NT; ++jo) {
             float v[4];
@@ -160,63 +165,86 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 }
             }
             if constexpr (OUT_F32) {
-                *(f32x4*)(est + c * EROW + (jo * 16 + 4 * g) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+                vf[jo] = f32x4{v[0], v[1], v[2], v[3]};
             } else {
-                u32x2 pk;
-                pk[0] = pack_bf2(v[0], v[1]);
-                pk[1] = pack_bf2(v[2], v[3]);
-                *(u32x2*)(est + c * EROW + (jo * 16 + 4 * g) * 2) = pk;
+                pk[jo][0] = pack_bf2(v[0], v[1]);
+                pk[jo][1] = pack_bf2(v[2], v[3]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // read back row-major: 16 rows x EROW bytes, 16 B per lane
-        constexpr int CPR = EDAT / 16;       // 16-byte chunks per row
-        constexpr int TOTAL = 16 * CPR;      // chunks in the staged block
-        constexpr int EPC = 16 / ESZ;        // elements per chunk
+        // ---- stores straight from registers (no LDS round trip).  f32: the lane's 4 columns are 16 B already.  bf16: one
+        //      v_permlane16_swap per dword hands the odd 16-lane rows' quads of n-tile jo to the even rows and the even rows'
+        //      quads of n-tile jo+1 to the odd rows, so every lane owns 8 consecutive columns (16 B) of one row:
+        //      a wave-store covers 16 rows x 64 contiguous bytes.
+        const int row = m0 + wm * WTM + i * 16 + c;
+        const bool row_ok = row < p.M && !(p.dbg & 1);
+        if constexpr (OUT_F32) {
 #pragma unroll
-        for (int q = lane; q < TOTAL; q += 64) {
-            int rr = q / CPR, cc = q % CPR;
-            int gm = m0 + wm * WTM + i * 16 + rr;
-            int gn = ncol0 + cc * EPC;
-            u32x4 val = *(const u32x4*)(est + rr * EROW + cc * 16);
-            if (gm < p.M && gn < Nout) {
-                if constexpr (OUT_F32) {
-                    float* dst = (float*)p.C + (long)gm * p.ldc + gn;
-                    if (gn + 4 <= Nout && ((p.ldc & 3) == 0)) {
-                        *(u32x4*)dst = val;
+            for (int jo = 0; jo < OUT_NT; ++jo) {
+                const int col = ncol0 + jo * 16 + 4 * g;
+                if (row_ok && col < Nout) {
+                    float* dst = (float*)p.C + (long)row * p.ldc + col;
+                    if (col + 4 <= Nout && ((p.ldc & 3) == 0)) {
+                        *(f32x4*)dst = vf[jo];
                     } else {
-                        for (int e = 0; e < 4 && gn + e < Nout; ++e) dst[e] = __uint_as_float(val[e]);
+                        for (int e = 0; e < 4 && col + e < Nout; ++e) dst[e] = vf[jo][e];
                     }
-                } else {
-                    unsigned short* dst = (unsigned short*)p.C + (long)gm * p.ldc + gn;
-                    const bool vec = (gn + 8 <= Nout) && ((p.ldc & 7) == 0);
-                    if (p.res) {
-                        const unsigned short* rs = p.res + (long)gm * p.ldr + gn;
-                        unsigned short o[8];
+                }
+            }
+        } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            unsigned int w = val[e >> 1];
-                            unsigned short h = (e & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffff);
-                            float rv = (gn + e < Nout) ? bf2f(rs[e]) : 0.f;
-                            o[e] = f2bf(bf2f(h) + rv);
+            for (int jo = 0; jo + 1 < OUT_NT; jo += 2) {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[jo][0], pk[jo + 1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[jo][1], pk[jo + 1][1], false, false);
+                u32x4 val = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                const int col = ncol0 + ((g & 1) ? (jo + 1) * 16 + 4 * (g - 1) : jo * 16 + 4 * g);
+                if (row_ok && col < Nout) {
+                    unsigned short* dst = (unsigned short*)p.C + (long)row * p.ldc + col;
+                    const bool vec = (col + 8 <= Nout) && ((p.ldc & 7) == 0);
+                    if (p.res) {
+                        const unsigned short* rs = p.res + (long)row * p.ldr + col;
+                        u32x4 rv;
+                        if (vec && ((p.ldr & 7) == 0) && ((((size_t)p.res) & 15) == 0)) {
+                            rv = *(const u32x4*)rs;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned lo = (col + 2 * e < Nout) ? rs[2 * e] : 0u, hi = (col + 2 * e + 1 < Nout) ? rs[2 * e + 1] : 0u;
+                                rv[e] = lo | (hi << 16);
+                            }
                         }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) val[e] = (unsigned)o[2 * e] | ((unsigned)o[2 * e + 1] << 16);
+                        for (int e = 0; e < 4; ++e)  // the linear output is rounded to bf16 first (bf16 nn.Linear), then the sum is
+                            val[e] = pack_bf2(__uint_as_float(val[e] << 16) + __uint_as_float(rv[e] << 16),
+                                              __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(rv[e] & 0xffff0000u));
                     }
                     if (vec) {
                         *(u32x4*)dst = val;
                     } else {
-                        for (int e = 0; e < 8 && gn + e < Nout; ++e) {
-                            unsigned int w = val[e >> 1];
-                            dst[e] = (e & 1) ? (unsigned short)(w >> 16) : (unsigned short)(w & 0xffff);
-                        }
+                        for (int e = 0; e < 8 && col + e < Nout; ++e) dst[e] = (unsigned short)(val[e >> 1] >> (16 * (e & 1)));
                     }
                 }
             }
+            if constexpr (OUT_NT % 2 == 1) {  // leftover n-tile: 8 bytes per lane
+            const int col = ncol0 + (OUT_NT - 1) * 16 + 4 * g;
+            if (row_ok && col < Nout) {
+                u32x2 val = pk[OUT_NT - 1];
+                unsigned short* dst = (unsigned short*)p.C + (long)row * p.ldc + col;
+                if (p.res) {
+                    const unsigned short* rs = p.res + (long)row * p.ldr + col;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float lo = (col + 2 * e < Nout) ? bf2f(rs[2 * e]) : 0.f, hi = (col + 2 * e + 1 < Nout) ? bf2f(rs[2 * e + 1]) : 0.f;
+                        val[e] = pack_bf2(__uint_as_float(val[e] << 16) + lo, __uint_as_float(val[e] & 0xffff0000u) + hi);
+                    }
+                }
+                if (col + 4 <= Nout && ((p.ldc & 3) == 0)) {
+                    *(u32x2*)dst = val;
+                } else {
+                    for (int e = 0; e < 4 && col + e < Nout; ++e) dst[e] = (unsigned short)(val[e >> 1] >> (16 * (e & 1)));
+                }
+            }
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -1022,6 +1050,9 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 1: return launch_cfg<256, 128, 2, 4, ACT, OUT_F32, 1>(a, st);
         case 2: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 1>(a, st);
         case 3: return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
+        case 4:  // 128x320: N = 1280 (ViT proj / fc2) at M = 8192 is exactly 256 tiles; 5 n-tiles per wave, so no SwiGLU pairs
+            if constexpr (ACT != ACT_SWIGLU) return launch_cfg<128, 320, 2, 4, ACT, OUT_F32, 0>(a, st);
+            else return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 10: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 20: return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
@@ -1058,6 +1089,8 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.colscale = (const unsigned short*)colscale;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    static const int dbg_flags = [] { const char* e = getenv("RGA3_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg_flags;
     hipStream_t st = (hipStream_t)stream;
     int tl = pick_tile((int)M, (int)N, tile);
     if (out_dtype == RGA3_F32) return launch_act<ACT_NONE, true>(a, tl, st);

@@ -8,8 +8,8 @@ import os
 
 import torch
 
-CANDIDATES = (20, 21, 22, 11, 12, 3)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
-                                       # single-phase 256x128, 128x128, 128x256
+CANDIDATES = (20, 21, 22, 11, 12, 3, 4)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
+                                       # single-phase 256x128, 128x128, 128x256, 128x320
 _cache = {}
 _times = {}   # key -> {tile: ms of 3 launches} (diagnostic, see table())
 _enabled = os.environ.get("RGA3_GEMM_TUNE", "1") != "0"
