@@ -39,6 +39,7 @@ struct GemmArgs {
     int M, N, K;
     long lda, ldw, ldc, ldr;
     int ntm, ntn;
+    int group_m;  // tile rows per group of the tile order (see launchers)
     int dbg;  // RGA3_GEMM_DBG (timing ablations only): bit0 = skip the global stores, bit1 = skip the whole epilogue
 };
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     // ---- logical tile for this workgroup: XCD-contiguous chunks, grouped (GROUP_M rows of tiles) order
     const unsigned nwg = (unsigned)(p.ntm * p.ntn);
     const unsigned t = xcd_remap(blockIdx.x, nwg);
-    constexpr unsigned GROUP_M = 4;
+    const unsigned GROUP_M = (unsigned)p.group_m;
     const unsigned per_group = GROUP_M * p.ntn;
     const unsigned group = t / per_group;
     const unsigned first_m = group * GROUP_M;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
 
     const unsigned nwg = (unsigned)(p.ntm * p.ntn);
     const unsigned t = xcd_remap(blockIdx.x, nwg);
-    constexpr unsigned GROUP_M = 4;
+    const unsigned GROUP_M = (unsigned)p.group_m;
     const unsigned per_group = GROUP_M * p.ntn;
     const unsigned group = t / per_group;
     const unsigned first_m = group * GROUP_M;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     int nm0 = 0, nn0 = 0;  // tile origin of the item whose offsets are in soff
     auto setup_tile = [&](int tile, int lane) {
         const int sch = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
-        constexpr unsigned GROUP_M = 4;
+        const unsigned GROUP_M = (unsigned)p.group_m;
         const unsigned t = (unsigned)tile;
         const unsigned per_group = GROUP_M * p.ntn;
         const unsigned group = t / per_group;
@@ -901,6 +902,18 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     }
 }
 
+// Tile order: consecutive logical tiles walk down GROUP_M tile rows, then step to the next tile column.  An XCD holds 32
+// consecutive tiles, i.e. GROUP_M x (32 / GROUP_M) of them share its L2.  GROUP_M = 4 keeps that block squarish (least
+// L2 fill traffic) but walks the whole weight matrix once per group of 4 tile rows: with few tile rows (M = 2112 is 9) and
+// a weight matrix larger than the 256 MiB Infinity Cache that is 3 passes over HBM; one group spanning all rows streams the
+// weights once and re-reads the small activation block from the Infinity Cache instead.
+static int pick_group_m(int ntm, int tile_m) {
+    static const int forced = [] { const char* e = getenv("RGA3_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    (void)tile_m;
+    return (ntm <= 16) ? ntm : 4;
+}
+
 struct SkWorkspace { float* slabs; unsigned* flags; int P; };
 
 // one workspace per stream (kernels on a stream serialize; different streams must not share slabs)
@@ -940,6 +953,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
+    a.group_m = pick_group_m(a.ntm, 256);
     SkWorkspace ws;
     if (a.K % 64 != 0) return launch_pp<ACT, OUT_F32>(a0, st);  // ragged K: zero-source tail lives in the one-tile kernel
     int rc = sk_workspace(st, ws);
@@ -989,6 +1003,7 @@ static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
+    a.group_m = pick_group_m(a.ntm, 256);
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_pp_kernel<ACT, OUT_F32>;
     static bool attr_done = false;
@@ -1007,6 +1022,7 @@ static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, BM);
     a.ntn = (int)cdiv(a.N, BN);
+    a.group_m = pick_group_m(a.ntm, BM);
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int LDS = 2 * STAGE;
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, ACT, OUT_F32, PIPE>;

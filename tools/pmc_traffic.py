@@ -3,7 +3,7 @@
 Usage (on the GPU box, two separate passes as MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE do not fit one pass):
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gemm_nt_kernel gpurun_out/gemm_traffic.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gemm_nt_ gpurun_out/gemm_traffic.json
 
 Corrections (guide, HBM section): both counters are in KB; on gfx950 FETCH_SIZE counts 128-B requests at 64 B, so it is doubled;
 WRITE_SIZE is exact.  Infinity-Cache hits are included in FETCH_SIZE (fabric-side requests), so `traffic` is an upper bound on HBM bytes.
