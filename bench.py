@@ -277,7 +277,7 @@ def main():
         n_launch = len(ev) // args.steps
         gemm_ms_step = tot_ms / args.steps
         achieved = GEMM_FLOPS / (gemm_ms_step * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 16x16x32 MFMA)", "achieved": round(achieved, 1), "peak": PEAK_BF16 / 1e12,
+        roof = {"bound": "mfma", "kernel": "gemm_nt_* family: gemm_nt_pp_kernel / gemm_nt_sk_kernel / gemm_nt_kernel (bf16 16x16x32 MFMA)", "achieved": round(achieved, 1), "peak": PEAK_BF16 / 1e12,
                 "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
                 "launches_per_step": n_launch, "avg_launch_ms": round(gemm_ms_step / max(n_launch, 1), 5),
                 "gemm_ms_per_step": round(gemm_ms_step, 3),
