@@ -37,7 +37,7 @@ struct AttnArgs {
 
 constexpr int KV_TILE = 64;
 
-template <int DP, int QT, int NWAVE, bool USE_TR>
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR>
 __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     constexpr int NT = 64 * NWAVE;
     constexpr int BLOCK_M = NWAVE * QT * 16;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     constexpr int DT = DP / 16;           // 16-wide d tiles of the output
     constexpr int LOADS = (KV_TILE * CH) / NT;
     static_assert((KV_TILE * CH) % NT == 0, "tile chunks must divide evenly over threads");
+    constexpr int RING = (LOADS <= 2) ? 3 : (LOADS <= 3) ? 2 : 1;  // K/V register slots in flight (8 * LOADS registers each)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -60,9 +61,24 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     const int hk = hq / (p.Hq / p.Hkv);
     const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
     const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
-    const int qb0 = blockIdx.x * BLOCK_M;
-    if (qb0 >= Lq) return;
     const int shift = Lk - Lq;  // causal: key j visible to query i iff j <= i + shift
+    // Causal launches pair q-block i with q-block n-1-i in one workgroup: every workgroup then walks the same number of
+    // key tiles (a plain grid leaves the chip to the few longest rows at the end: 34 tiles vs 2 at S = 2112).
+    const int nqb = (Lq + BLOCK_M - 1) / BLOCK_M;
+    int qb_first = blockIdx.x, qb_second = -1;
+    if constexpr (PAIR) {
+        qb_first = nqb - 1 - (int)blockIdx.x;           // the long one first
+        qb_second = (int)blockIdx.x;
+        if (qb_second > qb_first) return;
+        if (qb_second == qb_first) qb_second = -1;
+    } else if (qb_first >= nqb) {
+        return;
+    }
+    for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+    const int qbi = pass == 0 ? qb_first : qb_second;
+    if (qbi < 0) break;
+    if (pass == 1) __syncthreads();  // the previous block's last tile is still being read from LDS
+    const int qb0 = qbi * BLOCK_M;
 
     // ---- Q fragments (B operand): lane (c, g) holds Q[q = c][d = 32*ds + 8g .. +7]
     bf16x8 qf[QT][DS];
@@ -94,8 +110,25 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     if (kv_end < 0) kv_end = 0;
     const int ntiles = (kv_end + KV_TILE - 1) / KV_TILE;
 
-    u32x4 kreg[LOADS], vreg[LOADS];
-    auto load_tile = [&](int kt) {
+    // K/V tiles travel HBM -> registers -> LDS.  A ring of RING register slots keeps RING tiles in flight: with one slot the
+    // loop ran at one global-load latency per 64-key tile (~3 us for a 34-tile causal row at S = 2112, 7 % MFMA use).
+    u32x4 kreg[RING][LOADS], vreg[RING][LOADS];
+    // per-lane element offsets of this thread's chunks in tile 0 (32-bit: K/V of one call are < 2^31 elements from the
+    // segment/head base); the tile index only adds kt * KV_TILE * stride
+    const unsigned short* kbase = p.k + (long)ks * p.k_st + (long)hk * p.k_sh;
+    const unsigned short* vbase = p.v + (long)ks * p.v_st + (long)hk * p.v_sh;
+    int koff0[LOADS], voff0[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / CH, ch = idx % CH;
+        koff0[i] = (int)(r * p.k_st + ch * 8);
+        voff0[i] = (int)(r * p.v_st + ch * 8);
+    }
+    auto load_tile = [&](auto SLOT, int kt) {
+        constexpr int slot = decltype(SLOT)::value;
+        const unsigned short* kt_k = kbase + (long)kt * KV_TILE * p.k_st;
+        const unsigned short* kt_v = vbase + (long)kt * KV_TILE * p.v_st;
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const int idx = tid + i * NT;
@@ -103,29 +136,29 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
             const int key = kt * KV_TILE + r;
             u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
             if (key < Lk && ch * 8 < p.D) {
-                zk = *(const u32x4*)(p.k + (long)(ks + key) * p.k_st + (long)hk * p.k_sh + ch * 8);
-                zv = *(const u32x4*)(p.v + (long)(ks + key) * p.v_st + (long)hk * p.v_sh + ch * 8);
+                zk = *(const u32x4*)(kt_k + koff0[i]);
+                zv = *(const u32x4*)(kt_v + voff0[i]);
             }
-            kreg[i] = zk;
-            vreg[i] = zv;
+            kreg[slot][i] = zk;
+            vreg[slot][i] = zv;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](auto SLOT) {
+        constexpr int slot = decltype(SLOT)::value;
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / CH, ch = idx % CH;
-            *(u32x4*)(Ks + r * STRIDE + ch * 16) = kreg[i];
-            *(u32x4*)(Vs + r * STRIDE + ch * 16) = vreg[i];
+            *(u32x4*)(Ks + r * STRIDE + ch * 16) = kreg[slot][i];
+            *(u32x4*)(Vs + r * STRIDE + ch * 16) = vreg[slot][i];
         }
     };
 
-    if (ntiles > 0) load_tile(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
+    auto tile_body = [&](auto SLOT, int kt) {
         __syncthreads();  // everyone finished reading the previous tile
-        store_tile();
+        store_tile(SLOT);
         __syncthreads();
-        if (kt + 1 < ntiles) load_tile(kt + 1);  // in flight under the MFMAs below
+        if (kt + RING < ntiles) load_tile(SLOT, kt + RING);  // refill the slot just emptied: RING tiles stay in flight
 
         // ---- S^T tiles: s[t][j] = keys 16j..16j+15 (lane holds keys 16j + 4g + r) x query c of q-tile t
         f32x4 s[QT][4];
@@ -157,18 +190,18 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x = s[t][j][r] * p.scale_log2;
+                        float x = s[t][j][r];  // raw score: the softmax scale (> 0) is folded into the exp argument's FMA below
                         if constexpr (MASKED) {
                             const int key = k0 + j * 16 + 4 * g + r;
                             const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
                             x = ok ? x : -INFINITY;
+                            s[t][j][r] = x;
                         }
-                        s[t][j][r] = x;
                         mx = fmaxf(mx, x);
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float m_new = fmaxf(m_run[t], mx);
+                const float m_new = fmaxf(m_run[t], mx * p.scale_log2);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);  // m_run = -inf -> 0
                 m_run[t] = m_new;
@@ -177,7 +210,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float e = __builtin_amdgcn_exp2f(s[t][j][r] - m_use);   // raw v_exp_f32: arguments <= 0, flush of tiny values is harmless
+                        float e = __builtin_amdgcn_exp2f(fmaf(s[t][j][r], p.scale_log2, -m_use));   // raw v_exp_f32: arguments <= 0, flush of tiny values is harmless
                         s[t][j][r] = e;
                         ps += e;
                     }
@@ -229,6 +262,17 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
                 for (int t = 0; t < QT; ++t) oacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ss], oacc[t][d], 0, 0, 0);
             }
         }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+        if (ntiles > 0) load_tile(S0{}, 0);
+    if (RING > 1 && ntiles > 1) load_tile(S1{}, 1);
+    if (RING > 2 && ntiles > 2) load_tile(std::integral_constant<int, (RING > 2 ? 2 : 0)>{}, 2);
+    for (int kt = 0; kt < ntiles; kt += RING) {
+        tile_body(S0{}, kt);
+        if (RING > 1 && kt + 1 < ntiles) tile_body(S1{}, kt + 1);
+        if (RING > 2 && kt + 2 < ntiles) tile_body(std::integral_constant<int, (RING > 2 ? 2 : 0)>{}, kt + 2);
     }
 
     // ---- finalize: lane holds query c, output dims 16d + 4g + r
@@ -257,23 +301,34 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
             }
         }
     }
+    }  // pass
 }
 
-template <int DP, int QT, int NWAVE, bool USE_TR>
-static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
-    constexpr int BLOCK_M = NWAVE * QT * 16;
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR>
+static int launch_attn_p(const AttnArgs& a, int nseg, unsigned gx, hipStream_t st) {
     constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
-    auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR>;
+    auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, PAIR>;
     static bool attr_done = false;
     if (!attr_done && LDS > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    dim3 grid((unsigned)cdiv(max_q, BLOCK_M), (unsigned)a.Hq, (unsigned)nseg);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWAVE), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NWAVE), LDS, st, a);
     RGA3_CHECK_LAUNCH("attn_fwd_kernel");
     return 0;
+}
+
+template <int DP, int QT, int NWAVE, bool USE_TR>
+static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
+    constexpr int BLOCK_M = NWAVE * QT * 16;
+    const unsigned nqb = (unsigned)cdiv(max_q, BLOCK_M);
+    // the paired-q-block form only for the long causal rows of the decoder (D = 64 / 128, 8 waves): elsewhere it would only
+    // cost registers
+    if constexpr (NWAVE == 8) {
+        if (a.causal && nqb >= 4) return launch_attn_p<DP, QT, NWAVE, USE_TR, true>(a, nseg, (nqb + 1) / 2, st);
+    }
+    return launch_attn_p<DP, QT, NWAVE, USE_TR, false>(a, nseg, nqb, st);
 }
 
 static int g_attn_variant = 0;  // 0: auto, 1: force 4 waves x QT=2, 2: force 8 waves x QT=1 (benchmark switch, read-only after init)
@@ -322,6 +377,8 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && (((uintptr_t)o) & 7) == 0,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
+    RGA3_CHECK_ARG(scale > 0.f, "attn: softmax scale must be positive");
+    RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
     RGA3_CHECK_ARG(impl >= 0 && impl <= 3, "attn: impl %d", impl);
     g_attn_variant = (impl & 2) ? 1 : 0;
     impl &= 1;
