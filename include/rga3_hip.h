@@ -146,11 +146,14 @@ int rga3_bce_dice_sums(const float* logits, const float* targets, float* out4, i
 
 /* Flash-style attention backward (recompute from q,k,v,dO and the forward's lse): dq, dk, dv in bf16, no atomics.
  * strides16 = HOST array {q_st,q_sh,k_st,k_sh,v_st,v_sh,o_st,o_sh,do_st,do_sh,dq_st,dq_sh,dk_st,dk_sh,dv_st,dv_sh} (elements);
- * delta_ws: f32 workspace [Hq*total_q].  Replaces the autograd of flash-attn / SDPA under train_joint.py:534. D <= 128. */
+ * delta_ws: f32 workspace [Hq*total_q].  dkv_ws (optional, GQA only): f32 workspace [2 * Hq * total_k * D]; with it the dK/dV pass
+ * runs one workgroup per (key block, QUERY head) and a fixed-order reduce adds the heads of a group (7x the parallelism for the
+ * decoder's 28:4 heads); NULL keeps the single-pass form.  total_k = rows of k/v (= cu_k[nseg]).
+ * Replaces the autograd of flash-attn / SDPA under train_joint.py:534. D <= 128. */
 int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
                          void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
                          int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale, int causal,
-                         void* stream);
+                         float* dkv_ws, int64_t total_k, void* stream);
 /* dx = d rmsnorm(x; weight)/dx . dy (+ add): backward of HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:74-79) w.r.t. x */
 int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim, float eps,
                      void* stream);

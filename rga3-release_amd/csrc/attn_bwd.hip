@@ -25,6 +25,8 @@ struct AttnBwdArgs {
     long total_q;
     float scale, scale_log2;
     int causal;
+    float* dkv_ws;   // GQA split: f32 partial dK | dV, each [group][total_k][Hkv][D]; null = loop the group inside one workgroup
+    long total_k;
 };
 
 constexpr int BT = 64;  // tile of the streamed (LDS-staged) dimension
@@ -217,7 +219,10 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) 
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
-template <int DP, int NWAVE>
+// SPLIT (GQA with a workspace): grid.y runs over the QUERY heads; each workgroup handles one head of the group and writes f32
+// partial sums, attn_dkv_reduce_kernel adds the group in a fixed order (still no atomics, still bitwise reproducible).  Without
+// it one workgroup loops all heads of the group: 33 x 4 = 132 workgroups for the decoder at S = 2112, 0.97 ms per layer.
+template <int DP, int NWAVE, bool SPLIT>
 __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     constexpr int NT = 64 * NWAVE;
     constexpr int BLOCK_N = NWAVE * 16;  // keys per workgroup (one 16-key tile per wave)
@@ -235,8 +240,10 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int seg = blockIdx.z, hk = blockIdx.y;
+    const int seg = blockIdx.z;
     const int group = p.Hq / p.Hkv;
+    const int hk = SPLIT ? (int)blockIdx.y / group : (int)blockIdx.y;
+    const int hh0 = SPLIT ? (int)blockIdx.y % group : 0, hh1 = SPLIT ? hh0 + 1 : group;
     const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
     const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
     const int kb0 = blockIdx.x * BLOCK_N;
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
     const int t0 = q_begin / BT;
     const int ntq = (Lq + BT - 1) / BT;
 
-    for (int hh = 0; hh < group; ++hh) {
+    for (int hh = hh0; hh < hh1; ++hh) {
         const int hq = hk * group + hh;
         for (int qt = t0; qt < ntq; ++qt) {
             __syncthreads();  // previous tile fully consumed
@@ -343,6 +350,21 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
                 }
         }
     }
+    if constexpr (SPLIT) {
+        if (key < Lk) {
+            const long half = (long)group * p.total_k * p.Hkv * p.D;
+            float* wk = p.dkv_ws + (((long)hh0 * p.total_k + ks + key) * p.Hkv + hk) * p.D;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int dd = d * 16 + 4 * g;
+                if (dd < p.D) {
+                    *(f32x4*)(wk + dd) = dkacc[d];
+                    *(f32x4*)(wk + half + dd) = dvacc[d];
+                }
+            }
+        }
+        return;
+    }
     if (key < Lk) {
         unsigned short* rk = p.dk + (long)(ks + key) * p.dk_st + (long)hk * p.dk_sh;
         unsigned short* rv = p.dv + (long)(ks + key) * p.dv_st + (long)hk * p.dv_sh;
@@ -360,6 +382,31 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
     }
 }
 
+// dK / dV = sum over the query heads of a GQA group of the f32 partials, in head order (thread = 4 consecutive d of one (key, kv head))
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
+    const int group = p.Hq / p.Hkv;
+    const int d4 = p.D / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = p.total_k * p.Hkv * d4;
+    if (idx >= total) return;
+    const int dd = (int)(idx % d4) * 4;
+    const long row = idx / d4;            // key * Hkv + hk
+    const int hk = (int)(row % p.Hkv);
+    const long key = row / p.Hkv;
+    const long plane = p.total_k * p.Hkv * (long)p.D, half = (long)group * plane;
+    const float* w = p.dkv_ws + row * p.D + dd;
+    f32x4 sk = *(const f32x4*)w, sv = *(const f32x4*)(w + half);
+    for (int h = 1; h < group; ++h) {
+        sk += *(const f32x4*)(w + h * plane);
+        sv += *(const f32x4*)(w + half + h * plane);
+    }
+    u32x2 a, b;
+    a[0] = pack_bf2(sk[0], sk[1]); a[1] = pack_bf2(sk[2], sk[3]);
+    b[0] = pack_bf2(sv[0], sv[1]); b[1] = pack_bf2(sv[2], sv[3]);
+    *(u32x2*)(p.dk + key * p.dk_st + (long)hk * p.dk_sh + dd) = a;
+    *(u32x2*)(p.dv + key * p.dv_st + (long)hk * p.dv_sh + dd) = b;
+}
+
 template <int DP>
 static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipStream_t st) {
     constexpr int QT = (DP >= 128) ? 1 : 2;
@@ -367,7 +414,7 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
     constexpr int LDS_DQ = 2 * BT * (DP * 2 + 32);
     constexpr int LDS_DKV = 2 * BT * (DP * 2 + 32) + 2 * BT * 4;
     auto kq = attn_bwd_dq_kernel<DP, QT, 4>;
-    auto kk = attn_bwd_dkv_kernel<DP, 4>;
+    auto kk = attn_bwd_dkv_kernel<DP, 4, false>;
     static bool attr_done = false;
     if (!attr_done && LDS_DKV > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
@@ -379,6 +426,21 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
     RGA3_CHECK_LAUNCH("attn_delta_kernel");
     hipLaunchKernelGGL(kq, dim3((unsigned)cdiv(max_q, BLOCK_M), (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DQ, st, a);
     RGA3_CHECK_LAUNCH("attn_bwd_dq_kernel");
+    if (a.dkv_ws && a.Hq > a.Hkv) {
+        auto ks_ = attn_bwd_dkv_kernel<DP, 4, true>;
+        static bool attr2 = false;
+        if (!attr2 && LDS_DKV > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)ks_, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+            if (e != hipSuccess) return fail(-(int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(ks_, dim3((unsigned)cdiv(max_k, 64), (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+        RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel<split>");
+        const long rows = a.total_k * a.Hkv;
+        hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv(rows * (a.D / 4), 256)), dim3(256), 0, st, a);
+        RGA3_CHECK_LAUNCH("attn_dkv_reduce_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(kk, dim3((unsigned)cdiv(max_k, 64), (unsigned)a.Hkv, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
     RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel");
     return 0;
@@ -391,7 +453,7 @@ using namespace rga3;
 extern "C" int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                                     void* dq, void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg,
                                     int max_q, int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale,
-                                    int causal, void* stream) {
+                                    int causal, float* dkv_ws, int64_t total_k, void* stream) {
     RGA3_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta_ws && cu_q && cu_k && strides16, "attn_bwd: null pointer");
     RGA3_CHECK_ARG(nseg > 0 && max_q > 0 && max_k > 0 && total_q > 0, "attn_bwd: sizes");
     RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attn_bwd: Hq=%d Hkv=%d", Hq, Hkv);
@@ -406,6 +468,8 @@ extern "C" int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v,
     a.o_st = strides16[6]; a.o_sh = strides16[7]; a.do_st = strides16[8]; a.do_sh = strides16[9]; a.dq_st = strides16[10]; a.dq_sh = strides16[11];
     a.dk_st = strides16[12]; a.dk_sh = strides16[13]; a.dv_st = strides16[14]; a.dv_sh = strides16[15];
     a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.total_q = total_q; a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f; a.causal = causal;
+    a.dkv_ws = dkv_ws; a.total_k = total_k;
+    RGA3_CHECK_ARG(!dkv_ws || (total_k > 0 && D % 4 == 0), "attn_bwd: dkv_ws needs total_k");
     hipStream_t st = (hipStream_t)stream;
     if (D <= 32) return launch_bwd<32>(a, nseg, max_q, max_k, st);
     if (D <= 64) return launch_bwd<64>(a, nseg, max_q, max_k, st);

@@ -330,11 +330,13 @@ def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, max_q: int, max_k: int, s
     for t in (q, k, v, o, dout, dq, dk, dv):
         assert t.dtype == torch.bfloat16 and t.stride(2) == 1
     delta = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)
+    Tk = k.shape[0]
+    dkv_ws = torch.empty((2 * Hq * Tk * D,), dtype=torch.float32, device=q.device) if (Hq > Hkv and D % 4 == 0) else None
     st = (ctypes.c_int64 * 16)(q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), o.stride(0), o.stride(1),
                                dout.stride(0), dout.stride(1), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1))
     rc = _lib.load().rga3_attn_varlen_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dq.data_ptr(),
                                           dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), cu_q.numel() - 1, int(max_q),
-                                          int(max_k), Tq, Hq, Hkv, D, ctypes.cast(st, ctypes.c_void_p), float(scale), int(bool(causal)), _stream())
+                                          int(max_k), Tq, Hq, Hkv, D, ctypes.cast(st, ctypes.c_void_p), float(scale), int(bool(causal)), _ptr(dkv_ws), Tk, _stream())
     _lib.check(rc, "attn_varlen_bwd")
     return dq, dk, dv
 
