@@ -154,6 +154,8 @@ int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
                          void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
                          int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale, int causal,
                          float* dkv_ws, int64_t total_k, void* stream);
+/* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up so far (expected 0; < 0 = HIP error) */
+int rga3_gemm_stream_k_timeouts(void);
 /* dx = d rmsnorm(x; weight)/dx . dy (+ add): backward of HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:74-79) w.r.t. x */
 int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim, float eps,
                      void* stream);

@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace rga3 {
 
@@ -923,18 +924,23 @@ static int pick_group_m(int ntm, int tile_m) {
 
 struct SkWorkspace { float* slabs; unsigned* flags; int P; };
 
-// one workspace per stream (kernels on a stream serialize; different streams must not share slabs)
+// one workspace per (device, stream): kernels on a stream serialize; different streams must not share slabs, and the null stream
+// handle is the same value on every device of a multi-GPU process
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, hipStream_t>, SkWorkspace> g_sk_table;
+
 static int sk_workspace(hipStream_t st, SkWorkspace& out) {
-    static std::mutex mu;
-    static std::map<hipStream_t, SkWorkspace> table;
-    std::lock_guard<std::mutex> lk(mu);
-    auto f = table.find(st);
+    auto& table = g_sk_table;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(-(int)e, "gemm: hipGetDevice: %s", hipGetErrorString(e));
+    const auto key = std::make_pair(dev, st);
+    auto f = table.find(key);
     if (f != table.end()) { out = f->second; return 0; }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 1;  // cannot allocate while capturing
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess || cus <= 0) return fail(-(int)e, "gemm: cannot query CU count: %s", hipGetErrorString(e));
     SkWorkspace ws;
     ws.P = cus;
@@ -947,7 +953,7 @@ static int sk_workspace(hipStream_t st, SkWorkspace& out) {
     if (e != hipSuccess) return fail(-(int)e, "gemm: stream-K workspace memset: %s", hipGetErrorString(e));
     ws.flags = (unsigned*)base;
     ws.slabs = (float*)(base + flag_bytes);
-    table[st] = ws;
+    table[key] = ws;
     out = ws;
     return 0;
 }
@@ -1088,6 +1094,26 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
 }  // namespace rga3
 
 using namespace rga3;
+
+// Diagnostic: number of bounded spins that gave up in stream-K launches so far (0 unless a contributor workgroup never ran).
+// Synchronises the devices that own a workspace.
+extern "C" int rga3_gemm_stream_k_timeouts(void) {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return -1;
+    long total = 0;
+    for (auto& kv : g_sk_table) {
+        unsigned v = 0;
+        if (hipSetDevice(kv.first.first) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(&v, kv.second.flags + kv.second.P, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+            total = -1;
+            break;
+        }
+        total += v;
+    }
+    (void)hipSetDevice(cur);
+    return (int)(total > 0x7fffffff ? 0x7fffffff : total);
+}
 
 extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
                               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,

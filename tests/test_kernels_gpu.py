@@ -45,6 +45,21 @@ def test_gemm_plain(dev, M, N, K, tile):
     assert _rel_l2(out, ref) < 6e-3
 
 
+def test_gemm_stream_k_split_shapes(dev):
+    """Tile 22 on shapes whose last round is split over K (1, 2 contributors per tile, ragged M): equal to the unsplit result up to
+    the f32 re-association of the split tiles, reproducible run to run, and no slab wait ever timed out."""
+    from rga3.hip import lib, ops
+
+    for (M, N, K) in [(2112, 3584, 3584), (2112, 4608, 3584), (2000, 5120, 2048), (8192, 1280, 1280), (300, 70000 // 8 * 8, 512)]:
+        a, w = _rand((M, K), dev, seed=11), _rand((N, K), dev, 0.05, seed=12)
+        ref = ops.gemm(a, w, tile=20)
+        o1 = ops.gemm(a, w, tile=22)
+        o2 = ops.gemm(a, w, tile=22)
+        assert torch.equal(o1, o2), (M, N, K)
+        assert _rel_l2(o1, ref.float().cpu()) < 1e-3, (M, N, K)
+    assert lib.load().rga3_gemm_stream_k_timeouts() == 0
+
+
 @pytest.mark.parametrize("act", ["none", "gelu", "relu", "swiglu"])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 10, 20, 21, 22])
 def test_gemm_epilogues(dev, act, tile):
