@@ -191,6 +191,17 @@ int rga3_pixel_shuffle2x_bwd(const void* dout, void* dg, int64_t F, int H, int W
 int rga3_bce_dice_grad(const float* logits, const float* targets, const float* sums4, float* dlogits, int64_t n_masks, int64_t hw,
                        float coef_bce, float coef_dice, void* stream);
 
+/* ---- SAM-side input pipeline: Pillow-exact antialiased bicubic resize + normalise + bf16, replacing
+ * DirectResize.apply_image + preprocess + .bfloat16() (reference utils/utils.py:230-256, inference_mevis.py:175-180).
+ * rga3_pil_bicubic_coeffs is HOST-ONLY: Pillow's precompute_coeffs / normalize_coeffs_8bpc tables (bounds [out*2], kk [out*ksize]);
+ * bounds == NULL only queries *ksize_out. */
+int rga3_pil_bicubic_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int64_t kk_capacity, int* ksize_out);
+/* frames u8 [T,H,W,3] -> u8 [T,out_h,out_w,3] (dst_u8, optional) and/or bf16 [T,3,out_h,out_w] = (u8 - mean)/std (dst_bf16, optional).
+ * bh/kh, bv/kv: device copies of the tables above; tmp: device workspace T*H*out_w*3 bytes; mean3/std3: host floats. */
+int rga3_sam_preprocess_u8(const void* frames, int64_t T, int H, int W, int out_h, int out_w, const int32_t* bh, const int32_t* kh,
+                           int ksize_h, const int32_t* bv, const int32_t* kv, int ksize_v, void* tmp, void* dst_u8, void* dst_bf16,
+                           const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,198 @@
+// SAM-side input pipeline on the GPU: the reference resizes every frame on the CPU with Pillow
+// (DirectResize.apply_image, reference utils/utils.py:246-256: Image.resize -> antialiased bicubic, uint8 fixed point),
+// normalises in fp32 (preprocess, utils/utils.py:230-243) and casts to bf16 (evaluation/mevis_val_u/inference_mevis.py:178-180);
+// that makes images_sam [T,3,1024,1024], the largest tensor handed to the hot path.
+//
+// Bit-exact restatement of Pillow's two-pass 8-bit resample (src/libImaging/Resample.c): coefficient tables are computed on
+// the HOST in double precision with Pillow's operation order (rga3_pil_bicubic_coeffs), the passes run on the device in int32:
+//   horizontal: tmp[t][y][xo][c] = clip8((sum_k src[t][y][xmin+k][c] * kk[xo][k] + 2^21) >> 22)
+//   vertical  : u8 = clip8((sum_k tmp[t][ymin+k][xo][c] * kk[yo][k] + 2^21) >> 22);  out = bf16((u8 - mean[c]) / std[c])
+// Both are HBM-bound byte kernels: the vertical pass writes 6 B per output pixel (bf16 CHW planes) and reads ksize x 3 B that
+// neighbouring threads share through L2; nothing here belongs on MFMA.
+#include "common.h"
+
+#include <cmath>
+
+namespace rga3 {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+
+static inline double bicubic_filter(double x) {
+#pragma clang fp contract(off)  // Pillow's C is compiled without FMA contraction: keep the double rounding identical
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= PRECISION_BITS;  // arithmetic shift, as Pillow's lookup index
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+struct ResampleArgs {
+    const unsigned char* src;
+    unsigned char* dst_u8;
+    unsigned short* dst_bf16;
+    const int* bounds;
+    const int* kk;
+    int ksize;
+    long T;
+    int n_in_rows, in_w, out_h, out_w;  // horizontal: rows = n_in_rows, in_w -> out_w; vertical: n_in_rows -> out_h at width out_w
+    float mean[3], stdv[3];
+};
+
+// thread = (t, y, xo): 3 channels of one output pixel of a row
+__global__ __launch_bounds__(256) void resample_h_kernel(ResampleArgs p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = p.T * p.n_in_rows * p.out_w;
+    if (idx >= total) return;
+    const int xo = (int)(idx % p.out_w);
+    const long row = idx / p.out_w;  // t * rows + y
+    const int xmin = p.bounds[2 * xo], n = p.bounds[2 * xo + 1];
+    const int* k = p.kk + (long)xo * p.ksize;
+    const unsigned char* s = p.src + (row * p.in_w + xmin) * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int i = 0; i < n; ++i) {
+        const int w = k[i];
+        a0 += (int)s[3 * i] * w;
+        a1 += (int)s[3 * i + 1] * w;
+        a2 += (int)s[3 * i + 2] * w;
+    }
+    unsigned char* d = p.dst_u8 + idx * 3;
+    d[0] = (unsigned char)clip8(a0);
+    d[1] = (unsigned char)clip8(a1);
+    d[2] = (unsigned char)clip8(a2);
+}
+
+// thread = (t, yo, 4 consecutive xo): 12 source bytes per tap (3 dwords), 8-byte bf16 stores per channel plane
+__global__ __launch_bounds__(256) void resample_v_kernel(ResampleArgs p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int w4 = p.out_w / 4;
+    const long plane = (long)p.out_h * p.out_w;
+    const long total = p.T * (long)p.out_h * w4;
+    if (idx >= total) return;
+    const int xo = (int)(idx % w4) * 4;
+    const int yo = (int)((idx / w4) % p.out_h);
+    const long t = idx / ((long)w4 * p.out_h);
+    const int ymin = p.bounds[2 * yo], n = p.bounds[2 * yo + 1];
+    const int* k = p.kk + (long)yo * p.ksize;
+    const unsigned char* s = p.src + ((t * p.n_in_rows + ymin) * p.out_w + xo) * 3;
+    const long rstride = (long)p.out_w * 3;
+    int acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 1 << (PRECISION_BITS - 1);
+    for (int i = 0; i < n; ++i) {
+        const int w = k[i];
+        const unsigned* r = (const unsigned*)(s + i * rstride);
+        const unsigned d0 = r[0], d1 = r[1], d2 = r[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += (int)((d0 >> (8 * e)) & 255u) * w;
+            acc[4 + e] += (int)((d1 >> (8 * e)) & 255u) * w;
+            acc[8 + e] += (int)((d2 >> (8 * e)) & 255u) * w;
+        }
+    }
+    int v[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) v[e] = clip8(acc[e]);   // byte e = pixel e / 3, channel e % 3
+    if (p.dst_u8) {
+        unsigned* d = (unsigned*)(p.dst_u8 + ((t * p.out_h + yo) * (long)p.out_w + xo) * 3);
+        d[0] = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+        d[1] = (unsigned)v[4] | ((unsigned)v[5] << 8) | ((unsigned)v[6] << 16) | ((unsigned)v[7] << 24);
+        d[2] = (unsigned)v[8] | ((unsigned)v[9] << 8) | ((unsigned)v[10] << 16) | ((unsigned)v[11] << 24);
+    }
+    if (p.dst_bf16) {
+        unsigned short* o = p.dst_bf16 + t * 3 * plane + (long)yo * p.out_w + xo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // fp32 subtract, IEEE divide, round to nearest even: the reference's (x - mean) / std then .bfloat16()
+            u32x2 pk;
+            pk[0] = pack_bf2(((float)v[c] - p.mean[c]) / p.stdv[c], ((float)v[3 + c] - p.mean[c]) / p.stdv[c]);
+            pk[1] = pack_bf2(((float)v[6 + c] - p.mean[c]) / p.stdv[c], ((float)v[9 + c] - p.mean[c]) / p.stdv[c]);
+            *(u32x2*)(o + c * plane) = pk;
+        }
+    }
+}
+
+}  // namespace rga3
+
+using namespace rga3;
+
+// Host-only: Pillow's precompute_coeffs + normalize_coeffs_8bpc for the full box.  bounds [out*2] = (first index, taps), kk
+// [out*ksize].  With bounds == NULL only *ksize_out is written (size query).  Returns 0 or a negative code.
+extern "C" int rga3_pil_bicubic_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int64_t kk_capacity, int* ksize_out) {
+#pragma clang fp contract(off)
+    RGA3_CHECK_ARG(in_size > 0 && out_size > 0 && ksize_out, "coeffs: sizes %d -> %d", in_size, out_size);
+    const double scale = (double)((float)in_size - 0.0f) / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    *ksize_out = ksize;
+    if (!bounds) return 0;
+    RGA3_CHECK_ARG(kk && kk_capacity >= (int64_t)out_size * ksize, "coeffs: kk capacity %ld < %ld", (long)kk_capacity, (long)out_size * ksize);
+    const double ss = 1.0 / filterscale;
+    double wbuf[512];
+    RGA3_CHECK_ARG(ksize <= 512, "coeffs: filter too wide (%d taps)", ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = 0.0 + (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            wbuf[x] = w;
+            ww += w;
+        }
+        int32_t* k = kk + (int64_t)xx * ksize;
+        for (int x = 0; x < ksize; ++x) {
+            double v = 0.0;
+            if (x < xmax) v = (ww != 0.0) ? wbuf[x] / ww : wbuf[x];
+            k[x] = v < 0 ? (int)(-0.5 + v * (1 << PRECISION_BITS)) : (int)(0.5 + v * (1 << PRECISION_BITS));
+        }
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+    return 0;
+}
+
+// frames u8 [T, H, W, 3] -> resized u8 [T, out_h, out_w, 3] (dst_u8, optional) and / or normalised bf16 [T, 3, out_h, out_w]
+// (dst_bf16, optional).  bh/kh (horizontal, out_w rows) and bv/kv (vertical, out_h rows) are DEVICE copies of the tables of
+// rga3_pil_bicubic_coeffs; tmp is a device workspace of T*H*out_w*3 bytes (unused when W == out_w).  mean3 / std3: host floats.
+extern "C" int rga3_sam_preprocess_u8(const void* frames, int64_t T, int H, int W, int out_h, int out_w, const int32_t* bh,
+                                      const int32_t* kh, int ksize_h, const int32_t* bv, const int32_t* kv, int ksize_v, void* tmp,
+                                      void* dst_u8, void* dst_bf16, const float* mean3, const float* std3, void* stream) {
+    RGA3_CHECK_ARG(frames && T > 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0, "preprocess: sizes");
+    RGA3_CHECK_ARG(dst_u8 || dst_bf16, "preprocess: no output");
+    RGA3_CHECK_ARG(!dst_bf16 || (mean3 && std3), "preprocess: mean/std");
+    RGA3_CHECK_ARG(W == out_w || (bh && kh && tmp && ksize_h > 0), "preprocess: horizontal tables / workspace");
+    RGA3_CHECK_ARG(H == out_h || (bv && kv && ksize_v > 0), "preprocess: vertical tables");
+    RGA3_CHECK_ARG(H != out_h || W != out_w, "preprocess: same-size input is a copy + normalise: use the row kernels");
+    hipStream_t st = (hipStream_t)stream;
+    ResampleArgs a;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3 ? mean3[c] : 0.f; a.stdv[c] = std3 ? std3[c] : 1.f; }
+    a.T = T;
+    const unsigned char* mid = (const unsigned char*)frames;
+    if (W != out_w) {
+        const bool last = (H == out_h);
+        RGA3_CHECK_ARG(!last || (dst_u8 && !dst_bf16), "preprocess: horizontal-only resize writes u8");
+        a.src = (const unsigned char*)frames; a.dst_u8 = last ? (unsigned char*)dst_u8 : (unsigned char*)tmp; a.dst_bf16 = nullptr;
+        a.bounds = bh; a.kk = kh; a.ksize = ksize_h; a.n_in_rows = H; a.in_w = W; a.out_h = H; a.out_w = out_w;
+        const long total = T * (long)H * out_w;
+        hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, a);
+        RGA3_CHECK_LAUNCH("resample_h_kernel");
+        mid = (const unsigned char*)tmp;
+        if (last) return 0;
+    }
+    a.src = mid; a.dst_u8 = (unsigned char*)dst_u8; a.dst_bf16 = (unsigned short*)dst_bf16;
+    a.bounds = bv; a.kk = kv; a.ksize = ksize_v; a.n_in_rows = H; a.in_w = out_w; a.out_h = out_h; a.out_w = out_w;
+    RGA3_CHECK_ARG(out_w % 4 == 0, "preprocess: out_w %d must be a multiple of 4", out_w);
+    const long total = T * (long)out_h * (out_w / 4);
+    hipLaunchKernelGGL(resample_v_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, a);
+    RGA3_CHECK_LAUNCH("resample_v_kernel");
+    return 0;
+}

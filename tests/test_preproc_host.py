@@ -1,0 +1,16 @@
+"""CPU: the host-only coefficient entry point of the C ABI reproduces the oracle's (= Pillow's) fixed-point tables."""
+import numpy as np
+import pytest
+
+from oracle import preproc as P
+
+
+@pytest.mark.parametrize("sizes", [(854, 1024), (480, 1024), (1920, 1024), (1080, 1024), (1024, 256), (37, 1024), (2000, 1024), (999, 1024)])
+def test_coeff_tables_match_oracle(sizes):
+    from rga3.utils.preproc import pil_bicubic_tables
+
+    b, k = pil_bicubic_tables(*sizes)
+    ob, ok_, ks = P.pil_bicubic_coeffs(*sizes)
+    assert k.shape[1] == ks
+    assert np.array_equal(b.numpy(), ob)
+    assert np.array_equal(k.numpy(), ok_)
