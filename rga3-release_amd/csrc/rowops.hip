@@ -28,13 +28,78 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = dim / 8;
-    u32x4 buf[MAXC];
+    u32x4 buf[MAXC], abuf[MAXC];
     float ss = 0.f;
+    // all loads first (16 B per lane each, MAXC of them in flight), then chunk-by-chunk arithmetic behind scheduling barriers: the
+    // unpacked floats of one chunk die before the next chunk is touched (free scheduling kept all of them live: 235 VGPRs at MAXC = 8)
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int ch = lane + i * 64;
         if (ch < nch) {
+            buf[i] = *(const u32x4*)(x + row * ldx + ch * 8);
+            if (add) abuf[i] = *(const u32x4*)(add + row * ldx + ch * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            u32x4 v = buf[i];
+            float f[8];
+            unpack8(v, f);
+            if (add) {
+                float fa[8];
+                unpack8(abuf[i], fa);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bf2f(f2bf(f[e] + fa[e]));  // bf16 residual stream
+                v = pack8(f);
+                if (res_out) *(u32x4*)(res_out + row * ldx + ch * 8) = v;
+                buf[i] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    ss = wave_sum(ss);
+    const float rinv = rsqrtf(ss / (float)dim + eps);
+    // keep only the PACKED row between the two passes: left alone the compiler carries the 8 unpacked floats of every chunk across
+    // the reduction (235 VGPRs for MAXC = 8, two waves per SIMD)
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) asm volatile("" : "+v"(buf[i]));
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nch) {
+            float f[8], fw[8];
+            unpack8(buf[i], f);
+            unpack8(*(const u32x4*)(w + ch * 8), fw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fw[e] * bf2f(f2bf(f[e] * rinv));  // HF: weight * normed.to(bf16)
+            *(u32x4*)(y + row * ldx + ch * 8) = pack8(f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Wide rows (decoder hidden 3584 = 448 chunks): one 256-thread block per row, <= MAXC chunks per thread, cross-wave sum through LDS.
+// The wave-per-row form needs 7 chunks (+ 7 of the residual) and as many 64-bit addresses per lane there: 220 VGPRs, 2 waves / SIMD.
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_block_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ add,
+                                                            const unsigned short* __restrict__ w, unsigned short* __restrict__ y,
+                                                            unsigned short* __restrict__ res_out, long rows, int dim, long ldx, float eps) {
+    __shared__ float part[4];
+    const int tid = threadIdx.x;
+    const long row = blockIdx.x;
+    const int nch = dim / 8;
+    u32x4 buf[MAXC], wv[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = tid + i * 256;
+        if (ch < nch) {
             u32x4 v = *(const u32x4*)(x + row * ldx + ch * 8);
+            wv[i] = *(const u32x4*)(w + ch * 8);
             float f[8];
             unpack8(v, f);
             if (add) {
@@ -52,14 +117,17 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const unsigned short* __re
         }
     }
     ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    ss = part[0] + part[1] + part[2] + part[3];
     const float rinv = rsqrtf(ss / (float)dim + eps);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const int ch = lane + i * 64;
+        const int ch = tid + i * 256;
         if (ch < nch) {
             float f[8], fw[8];
             unpack8(buf[i], f);
-            unpack8(*(const u32x4*)(w + ch * 8), fw);
+            unpack8(wv[i], fw);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = fw[e] * bf2f(f2bf(f[e] * rinv));  // HF: weight * normed.to(bf16)
             *(u32x4*)(y + row * ldx + ch * 8) = pack8(f);
@@ -121,31 +189,49 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
 }
 
 // ------------------------------------------------------------------------------------------------ rotary
-// thread = (token, head, 8-wide chunk of the first half); rotates the chunk and its partner in the second half.
+// thread = (token, group of HG heads, 8-wide chunk of the first half): the cos / sin values (4 x 8 floats, the bulk of this kernel's
+// load instructions when fetched per head) are read once and reused for the HG heads; each head rotates the chunk and its partner
+// in the second half.
+template <int HG>
 __global__ __launch_bounds__(256) void rope_kernel(unsigned short* __restrict__ x, const float* __restrict__ cs, const float* __restrict__ sn,
                                                    long T, int h0, int nh, int D, long st, long sh) {
     const int half = D / 2, cph = half / 8;
+    const int ngrp = nh / HG;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = T * nh * cph;
+    const long total = T * ngrp * cph;
     if (idx >= total) return;
     const int ch = (int)(idx % cph);
-    const int h = (int)((idx / cph) % nh);
-    const long t = idx / ((long)cph * nh);
-    unsigned short* p1 = x + t * st + (long)(h0 + h) * sh + ch * 8;
-    unsigned short* p2 = p1 + half;
-    float a[8], b[8];
-    unpack8(*(const u32x4*)p1, a);
-    unpack8(*(const u32x4*)p2, b);
-    const float* c1 = cs + t * D + ch * 8;
-    const float* s1 = sn + t * D + ch * 8;
-    float o1[8], o2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        o1[e] = a[e] * c1[e] - b[e] * s1[e];                 // x*cos + rotate_half(x)*sin, first half: -x2
-        o2[e] = b[e] * c1[e + half] + a[e] * s1[e + half];   // second half: +x1
+    const int hg = (int)((idx / cph) % ngrp);
+    const long t = idx / ((long)cph * ngrp);
+    float c1[8], s1[8], c2[8], s2[8];
+    {
+        const float* cp = cs + t * D + ch * 8;
+        const float* sp = sn + t * D + ch * 8;
+        *(f32x4*)&c1[0] = *(const f32x4*)cp;        *(f32x4*)&c1[4] = *(const f32x4*)(cp + 4);
+        *(f32x4*)&s1[0] = *(const f32x4*)sp;        *(f32x4*)&s1[4] = *(const f32x4*)(sp + 4);
+        *(f32x4*)&c2[0] = *(const f32x4*)(cp + half); *(f32x4*)&c2[4] = *(const f32x4*)(cp + half + 4);
+        *(f32x4*)&s2[0] = *(const f32x4*)(sp + half); *(f32x4*)&s2[4] = *(const f32x4*)(sp + half + 4);
     }
-    *(u32x4*)p1 = pack8(o1);
-    *(u32x4*)p2 = pack8(o2);
+    unsigned short* p1 = x + t * st + (long)(h0 + hg * HG) * sh + ch * 8;
+    u32x4 va[HG], vb[HG];
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+        va[h] = *(const u32x4*)(p1 + h * sh);
+        vb[h] = *(const u32x4*)(p1 + h * sh + half);
+    }
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+        float a[8], b[8], o1[8], o2[8];
+        unpack8(va[h], a);
+        unpack8(vb[h], b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o1[e] = a[e] * c1[e] - b[e] * s1[e];   // x*cos + rotate_half(x)*sin, first half: -x2
+            o2[e] = b[e] * c2[e] + a[e] * s2[e];   // second half: +x1
+        }
+        *(u32x4*)(p1 + h * sh) = pack8(o1);
+        *(u32x4*)(p1 + h * sh + half) = pack8(o2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ gather / scatter rows
@@ -279,9 +365,28 @@ extern "C" int rga3_rmsnorm_fwd(const void* x, const void* add, const void* weig
     dim3 grid((unsigned)cdiv(rows, 4));
     const unsigned short *xp = (const unsigned short*)x, *ap = (const unsigned short*)add, *wp = (const unsigned short*)weight;
     unsigned short *yp = (unsigned short*)y, *rp = (unsigned short*)res_out;
-    if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
-    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
-    else hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
+    if (dim >= 2048 && dim <= 256 * 8 * 4) {  // wide rows: a block per row
+        const int nb = (int)cdiv(dim / 8, 256);
+        dim3 g2((unsigned)rows);
+        if (nb <= 2) hipLaunchKernelGGL(rmsnorm_block_kernel<2>, g2, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
+        else hipLaunchKernelGGL(rmsnorm_block_kernel<4>, g2, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps);
+        RGA3_CHECK_LAUNCH("rmsnorm_block_kernel");
+        return 0;
+    }
+    const int nslot = (int)cdiv(dim / 8, 64);  // 16-byte chunks per lane
+#define RGA3_RMS(N) hipLaunchKernelGGL(rmsnorm_kernel<N>, grid, dim3(256), 0, st, xp, ap, wp, yp, rp, (long)rows, (int)dim, (long)ldx, eps)
+    switch (nslot) {
+        case 1: RGA3_RMS(1); break;
+        case 2: RGA3_RMS(2); break;
+        case 3: RGA3_RMS(3); break;
+        case 4: RGA3_RMS(4); break;
+        case 5: RGA3_RMS(5); break;
+        case 6: RGA3_RMS(6); break;
+        case 7: RGA3_RMS(7); break;
+        case 8: RGA3_RMS(8); break;
+        default: RGA3_RMS(16); break;
+    }
+#undef RGA3_RMS
     RGA3_CHECK_LAUNCH("rmsnorm_kernel");
     return 0;
 }
@@ -305,9 +410,16 @@ extern "C" int rga3_rope_inplace(void* x, const float* cos, const float* sin, in
                                  int64_t sh, void* stream) {
     RGA3_CHECK_ARG(x && cos && sin, "rope: null pointer");
     RGA3_CHECK_ARG(T > 0 && nh > 0 && D > 0 && D % 16 == 0 && st % 8 == 0 && sh % 8 == 0, "rope: T=%ld nh=%d D=%d", (long)T, nh, D);
-    const long total = (long)T * nh * (D / 16);
-    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cos, sin, (long)T, h0,
-                       nh, D, (long)st, (long)sh);
+    RGA3_CHECK_ARG((((uintptr_t)cos | (uintptr_t)sin) & 15) == 0, "rope: cos/sin tables must be 16-byte aligned");
+    if (nh % 4 == 0) {
+        const long total = (long)T * (nh / 4) * (D / 16);
+        hipLaunchKernelGGL(rope_kernel<4>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cos, sin, (long)T,
+                           h0, nh, D, (long)st, (long)sh);
+    } else {
+        const long total = (long)T * nh * (D / 16);
+        hipLaunchKernelGGL(rope_kernel<1>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short*)x, cos, sin, (long)T,
+                           h0, nh, D, (long)st, (long)sh);
+    }
     RGA3_CHECK_LAUNCH("rope_kernel");
     return 0;
 }
