@@ -765,24 +765,21 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) bf[ni][kk] = *(const bf16x8*)(cur + b_rd + h * HALF + ni * 2048 + foff[kk]);
     };
-    // rows_ok[h]: this wave's 64-row half h of the current tile has rows below M.  Ragged last tile rows (M = 2112 leaves 64
-    // of 256) skip the MFMA clusters of their dead halves; the barriers stay, the other wave group keeps its cadence.
-    bool rows_ok[2] = {true, true};
+    // (Skipping the MFMA clusters of a ragged tile row's dead 64-row halves was tried: at M = 2112 the uniform branches around the
+    //  clusters cost more in every tile than the skipped work saves in one tile row of nine.)
     auto mma_quadrant = [&](auto HA, auto HB, const bf16x8 (&bf)[2][2]) {
         constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (rows_ok[ha]) {
-            __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        mfma_inplace(acc[ha * 4 + mi][hb * 2 + ni], bf[ni][kk], af[mi][kk]);
-            __builtin_amdgcn_s_setprio(0);
-        }
+                for (int ni = 0; ni < 2; ++ni)
+                    mfma_inplace(acc[ha * 4 + mi][hb * 2 + ni], bf[ni][kk], af[mi][kk]);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
     using H0 = std::integral_constant<int, 0>;
@@ -795,8 +792,6 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
 
     for (int it = 0; it < n_items; ++it) {
         const int m0 = nm0, n0 = nn0;
-        rows_ok[0] = m0 + wr * 128 < p.M;
-        rows_ok[1] = m0 + wr * 128 + 64 < p.M;
         // ---- all six (or four) prologue half-tiles have been issued; older stores of the previous epilogue count in
         //      vmcnt too, so simply drain: the loads have been in flight for a whole epilogue
 #pragma unroll
@@ -1086,7 +1081,6 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 20: return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
         case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
-        case 11: return launch_cfg<256, 128, 2, 4, ACT, OUT_F32, 0>(a, st);
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);
     }
 }

@@ -14,13 +14,13 @@ from rga3.hip import ops  # noqa: E402
 SHAPES = [(8192, 3840, 1280), (8192, 1280, 1280), (8192, 6848, 1280), (8192, 1280, 3424), (2048, 5120, 5120), (2048, 3584, 5120),
           (2112, 4608, 3584), (2112, 3584, 3584), (2112, 37888, 3584), (2112, 3584, 18944), (4096, 4096, 4096), (8192, 8192, 8192),
           (2112, 3584, 1176), (300, 520, 200)]
-TILES = [10, 11, 12, 20, 21, 22]
+TILES = [11, 12, 4, 20, 21, 22]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 res = {}
 for (M, N, K) in SHAPES:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
-    ref = ops.gemm(a, w, tile=10)
+    ref = ops.gemm(a, w, tile=12)
     outs = {t: torch.empty_like(ref) for t in TILES}
     bad = 0
     for rep in range(6):            # race screen (20/21 bit-identical to 10; 22 splits K: must be stable run to run and close)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
 from rga3.hip import ops
 M, N = 8192, 4096   # 512 tiles of 256x256 = exactly two rounds on 256 CUs
 for tile in (20, 21):
-    for act, bias in (("none", False), ("none", True), ("gelu", True)):
+    for act, bias in (("none", False),):
         pts = []
         for K in (256, 512, 1024, 2048, 4096):
             a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
