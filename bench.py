@@ -93,6 +93,86 @@ def build_full(dev, rank, sam_frames):
     return model.train(), cfg, batch
 
 
+def sam2_stream(args, dev, rank, world, dist):
+    """BASELINE configs[3]: one step = one 32-frame ref-VOS stream through SAM2-L's memory path -- language
+    prompt on frame 0 only, then propagate (memory attention over the growing bank, mask decoder, memory encoder per frame).
+    `value` counts the stream with the per-frame image features already computed ("memory-attention mask-decoder only"); the
+    encoder-inclusive rate is reported beside it."""
+    from rga3.model.sam2 import SAM2, VideoSession
+
+    T = args.stream_frames
+    torch.manual_seed(1)
+    m = SAM2().to(torch.bfloat16).to(dev).eval()
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if p_.dim() >= 2:
+                p_.normal_(0, 0.02)
+    g = torch.Generator().manual_seed(rank)
+    vid = torch.randn(T, 3, 1024, 1024, generator=g).to(torch.bfloat16).to(dev)
+    emb = torch.randn(1, 1, 256, generator=g).to(torch.bfloat16).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        s0 = VideoSession(m.sam2_model, vid)
+        feats = s0._ensure_feats()          # image encoder, once (kept across steps: the timed region is the memory path)
+
+        def step():
+            sess = VideoSession(m.sam2_model, vid, feats=feats)
+            sess.add_language_embd(0, emb)
+            return sess, sess.propagate()
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sess, res = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # encoder-inclusive variant (fresh features every stream), same number of steps
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            se = VideoSession(m.sam2_model, vid)
+            se.add_language_embd(0, emb)
+            se.propagate()
+        barrier()
+        elapsed_enc = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([elapsed, elapsed_enc], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, elapsed_enc = float(t[0]), float(t[1])
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        fps = world * T / (elapsed / args.steps)
+        # algorithmic FLOPs per frame of the memory path (SURVEY.md 8(d)): memory attention <= 0.61 T (cross-attention grows with the bank:
+        # 4.19 M x KV, KV = 4096 x min(t, 7) + 4 x min(t, 16) pointer tokens), memory encoder 11.6 G, mask decoder 3.6 G
+        fl = 0.0
+        for tt in range(1, T):
+            kv = 4096 * min(tt, 7) + 4 * min(tt, 16)
+            fl += 54.8e9 + 68.7e9 + 4.19e6 * kv + 11.6e9 + 3.6e9
+        line = {"metric": "SAM2-L memory-attention mask-decoder stream, frames/sec (32-frame 1024x1024 ref-VOS stream, prompt on frame 0)", "value": round(fps, 2),
+                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"BASELINE.json configs[3]: SAM2-L (random init) memory path over {T} frames 1024x1024: frame 0 prompted with a language "
+                                       "embedding, frames 1.. propagate (memory attention over <= 7 memory frames + <= 16 object pointers, mask decoder, "
+                                       "memory encoder); image features precomputed outside the timed region", "frames": T, "parallelism": f"replicas x{world}",
+                           "encoder_inclusive_frames_per_s": round(world * T / (elapsed_enc / args.steps), 2), "counts": sess.counts},
+                "roofline": {"bound": "mfma", "achieved": round(fl / (elapsed / args.steps) / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                             "frac": round(fl / (elapsed / args.steps) / PEAK_BF16, 4), "traffic": None,
+                             "note": "whole-stream algorithmic FLOPs / stream time; the streaming stages (bank concat, RoPE over the keys, mask upsample, "
+                                     "LayerNorm2d / dw-conv of the memory encoder) are HBM-bound, the attention cores MFMA-bound (SURVEY.md 8(d))"},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def cpu_baseline():
     """Oracle (fp32 restatement, 'port') on the host cores: one windowed + one full ViT block, one decoder layer and
     a 1/16 lm_head slice at 7B dims, extrapolated to a whole forward (28 win + 4 full blocks, 28 layers, lm_head)."""
@@ -160,9 +240,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["forward", "train", "train_full"], default="forward",
+    ap.add_argument("--mode", choices=["forward", "train", "train_full", "sam2_stream"], default="forward",
                     help="forward = BASELINE configs[1] (default, the driver's metric); train = LLM fwd+bwd LoRA step with DDP gradient exchange; "
-                         "train_full = BASELINE configs[2] per GPU: full RGA3 (Qwen2.5-VL-7B + SAM2-L, 16 SAM frames) fwd+bwd + AdamW")
+                         "train_full = BASELINE configs[2] per GPU: full RGA3 (Qwen2.5-VL-7B + SAM2-L, 16 SAM frames) fwd+bwd + AdamW; "
+                         "sam2_stream = BASELINE configs[3]: SAM2-L memory-attention mask-decoder stream over 32 frames 1024x1024, prompt on frame 0")
+    ap.add_argument("--stream-frames", type=int, default=32)
     ap.add_argument("--sam-frames", type=int, default=16)
     args = ap.parse_args()
 
@@ -180,6 +262,8 @@ def main():
 
     from rga3.hip import lib, ops
     lib.load()  # fail loudly if the HIP extension is missing
+    if args.mode == "sam2_stream":
+        return sam2_stream(args, dev, rank, world, dist)
     if args.mode == "train_full":
         model, cfg, inputs = build_full(dev, rank, args.sam_frames)
     else:

@@ -64,11 +64,14 @@ int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* r
  * Replaces flash_attn_varlen_func / F.scaled_dot_product_attention at HF modeling_qwen2_5_vl.py:211-291
  * (ViT windows), :602-700 (causal GQA), reference model/sam2.py:1021 (Hiera), :1476 (two-way decoder),
  * :1543 (memory attention).  D in {16..256}, multiple of 8. impl: 0 = transposed LDS read, 1 = scalar-read
- * variant (debug cross-check). */
+ * variant (debug cross-check). 
+ * split_ws (optional, f32, split_ws_elems floats): non-causal calls whose grid would leave most CUs idle (query blocks x heads x
+ * segments < 128) over a long key range (max_k >= 1024; max_k is only read for this decision) cut the keys into <= 8 slices, one
+ * workgroup each, and merge them by their log-sum-exp in a second pass; needs nsplit * total_q * Hq * (D + 1) floats. */
 int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q,
                          const int32_t* cu_k, int nseg, int max_q, int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh,
                          int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
-                         float scale, int causal, int impl, void* stream);
+                         float scale, int causal, int impl, float* split_ws, int64_t split_ws_elems, int max_k, void* stream);
 
 /* y = weight * (x * rsqrt(mean(x^2) + eps)) rounded to bf16 before the weight multiply, exactly as
  * HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:65-79).  x,y: [rows, dim] bf16; optional fused residual:
@@ -132,6 +135,9 @@ int rga3_bilinear(const void* in, int in_dtype, float* out, const int32_t* plane
  * (model/sam2.py:3017-3022 + MaskDownSampler :611-643) */
 int rga3_conv3x3s2(const void* x, int x_dtype, const void* w, const void* bias, void* y, int64_t F, int H, int W, int Cin, int Cout,
                    float sig_scale, float sig_bias, void* stream);
+/* cols [F*(H/2)*(W/2), 9*C] (K index (kh*3+kw)*C + c, zero padded) of x [F,H,W,C] for Conv2d(k3,s2,p1) through rga3_gemm_bf16 with the weight
+ * repacked [Cout, (kh,kw,ci)]: the wide stages of the memory encoder's mask downsampler (reference model/sam2.py:611-643) */
+int rga3_im2col3x3s2(const void* x, void* cols, int64_t F, int H, int W, int C, void* stream);
 /* depthwise Conv2d(k7,p3) token-major (CXBlock.dwconv, model/sam2.py:669-675) */
 int rga3_dwconv7x7(const void* x, const void* w, const void* bias, void* y, int64_t F, int H, int W, int C, void* stream);
 /* axial complex RoPE in place on [T, C] single-head tokens; rows t < n_rope use table row t % nq (model/sam2.py:1901-1923) */

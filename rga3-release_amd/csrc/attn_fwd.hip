@@ -33,12 +33,17 @@ struct AttnArgs {
     long total_q;
     float scale_log2;  // softmax scale * log2(e)
     int causal;
+    // split-KV (few query blocks x heads, long key range: SAM2 memory attention is 64 workgroups of one head over 28 736 keys):
+    float* split_o;    // f32 [nsplit][total_q][Hq][D] normalised partial outputs
+    float* split_lse;  // f32 [nsplit][Hq][total_q] partial log2-sum-exp (of the scaled scores)
+    int nsplit;
 };
 
 constexpr int KV_TILE = 64;
 
-template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR>
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
+    static_assert(!(PAIR && SPLIT), "pairing and KV splitting are alternatives");
     constexpr int NT = 64 * NWAVE;
     constexpr int BLOCK_M = NWAVE * QT * 16;
     constexpr int CH = DP / 8;            // 16-byte chunks per (padded) row
@@ -65,7 +70,8 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     // Causal launches pair q-block i with q-block n-1-i in one workgroup: every workgroup then walks the same number of
     // key tiles (a plain grid leaves the chip to the few longest rows at the end: 34 tiles vs 2 at S = 2112).
     const int nqb = (Lq + BLOCK_M - 1) / BLOCK_M;
-    int qb_first = blockIdx.x, qb_second = -1;
+    const int sp = SPLIT ? (int)blockIdx.x % p.nsplit : 0;   // this workgroup's slice of the key range
+    int qb_first = SPLIT ? (int)blockIdx.x / p.nsplit : (int)blockIdx.x, qb_second = -1;
     if constexpr (PAIR) {
         qb_first = nqb - 1 - (int)blockIdx.x;           // the long one first
         qb_second = (int)blockIdx.x;
@@ -108,7 +114,12 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     int kv_end = Lk;
     if (p.causal) kv_end = min(Lk, qb0 + BLOCK_M + shift);  // last visible key + 1 (for the block's last row)
     if (kv_end < 0) kv_end = 0;
-    const int ntiles = (kv_end + KV_TILE - 1) / KV_TILE;
+    int kt_begin = 0, ntiles = (kv_end + KV_TILE - 1) / KV_TILE;
+    if constexpr (SPLIT) {
+        const int per = (ntiles + p.nsplit - 1) / p.nsplit;
+        kt_begin = min(sp * per, ntiles);
+        ntiles = min(kt_begin + per, ntiles);   // tiles [kt_begin, ntiles)
+    }
 
     // K/V tiles travel HBM -> registers -> LDS.  A ring of RING register slots keeps RING tiles in flight: with one slot the
     // loop ran at one global-load latency per 64-key tile (~3 us for a 34-tile causal row at S = 2112, 7 % MFMA use).
@@ -267,10 +278,10 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-        if (ntiles > 0) load_tile(S0{}, 0);
-    if (RING > 1 && ntiles > 1) load_tile(S1{}, 1);
-    if (RING > 2 && ntiles > 2) load_tile(std::integral_constant<int, (RING > 2 ? 2 : 0)>{}, 2);
-    for (int kt = 0; kt < ntiles; kt += RING) {
+    if (kt_begin < ntiles) load_tile(S0{}, kt_begin);
+    if (RING > 1 && kt_begin + 1 < ntiles) load_tile(S1{}, kt_begin + 1);
+    if (RING > 2 && kt_begin + 2 < ntiles) load_tile(std::integral_constant<int, (RING > 2 ? 2 : 0)>{}, kt_begin + 2);
+    for (int kt = kt_begin; kt < ntiles; kt += RING) {
         tile_body(S0{}, kt);
         if (RING > 1 && kt + 1 < ntiles) tile_body(S1{}, kt + 1);
         if (RING > 2 && kt + 2 < ntiles) tile_body(std::integral_constant<int, (RING > 2 ? 2 : 0)>{}, kt + 2);
@@ -284,6 +295,18 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
         l += __shfl_xor(l, 32, 64);
         const float inv = (l > 0.f) ? 1.f / l : 0.f;
         const int qi = qw0 + t * 16 + c;
+        if constexpr (SPLIT) {
+            if (qi < Lq) {
+                float* orow = p.split_o + (((long)sp * p.total_q + qs + qi) * p.Hq + hq) * p.D;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int dd = d * 16 + 4 * g;
+                    if (dd < p.D) *(f32x4*)(orow + dd) = oacc[t][d] * inv;
+                }
+                if (g == 0) p.split_lse[((long)sp * p.Hq + hq) * p.total_q + qs + qi] = (l > 0.f) ? m_run[t] + log2f(l) : -INFINITY;
+            }
+            continue;
+        }
         if (qi < Lq) {
             unsigned short* orow = p.o + (long)(qs + qi) * p.o_st + (long)hq * p.o_sh;
 #pragma unroll
@@ -303,6 +326,33 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
         }
     }
     }  // pass
+}
+
+// out = sum_i w_i o_i / sum_i w_i with w_i = 2^(lse2_i - max): one wave per (query row, head), 4 floats of D per lane per pass
+__global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnArgs p) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (token, head)
+    const int lane = threadIdx.x & 63;
+    if (row >= p.total_q * p.Hq) return;
+    const long tq = row / p.Hq;
+    const int hq = (int)(row % p.Hq);
+    float m = -INFINITY;
+    for (int i = 0; i < p.nsplit; ++i) m = fmaxf(m, p.split_lse[((long)i * p.Hq + hq) * p.total_q + tq]);
+    float wsum = 0.f, w[8];
+    for (int i = 0; i < p.nsplit; ++i) {
+        const float l2 = p.split_lse[((long)i * p.Hq + hq) * p.total_q + tq];
+        w[i] = (m == -INFINITY) ? 0.f : exp2f(l2 - m);
+        wsum += w[i];
+    }
+    const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+    for (int dd = lane * 4; dd < p.D; dd += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < p.nsplit; ++i) acc += *(const f32x4*)(p.split_o + (((long)i * p.total_q + tq) * p.Hq + hq) * p.D + dd) * w[i];
+        u32x2 pk;
+        pk[0] = pack_bf2(acc[0] * inv, acc[1] * inv);
+        pk[1] = pack_bf2(acc[2] * inv, acc[3] * inv);
+        *(u32x2*)(p.o + tq * p.o_st + (long)hq * p.o_sh + dd) = pk;
+    }
+    if (p.lse && lane == 0) p.lse[(long)hq * p.total_q + tq] = wsum > 0.f ? (m + log2f(wsum)) * 0.6931471805599453f : -INFINITY;
 }
 
 template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR>
@@ -328,6 +378,21 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     // cost registers
     if constexpr (NWAVE == 8) {
         if (a.causal && nqb >= 4) return launch_attn_p<DP, QT, NWAVE, USE_TR, true>(a, nseg, (nqb + 1) / 2, st);
+    }
+    if (a.nsplit > 1) {
+        constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
+        auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, false, true>;
+        static bool attr_done = false;
+        if (!attr_done && LDS > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(nqb * (unsigned)a.nsplit, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NWAVE), LDS, st, a);
+        RGA3_CHECK_LAUNCH("attn_fwd_kernel<split>");
+        hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)cdiv(a.total_q * a.Hq, 4)), dim3(256), 0, st, a);
+        RGA3_CHECK_LAUNCH("attn_split_combine_kernel");
+        return 0;
     }
     return launch_attn_p<DP, QT, NWAVE, USE_TR, false>(a, nseg, nqb, st);
 }
@@ -367,7 +432,7 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                                     const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q, int64_t total_q,
                                     int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh,
                                     int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal,
-                                    int impl, void* stream) {
+                                    int impl, float* split_ws, int64_t split_ws_elems, int max_k, void* stream) {
     RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k, "attn: null pointer");
     RGA3_CHECK_ARG(nseg > 0 && max_q > 0 && total_q > 0, "attn: nseg=%d max_q=%d total_q=%ld", nseg, max_q, (long)total_q);
     RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attn: Hq=%d Hkv=%d", Hq, Hkv);
@@ -390,6 +455,20 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     a.total_q = total_q;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.causal = causal;
+    // split the key range when the grid would leave most CUs idle: <= 8 slices, >= 8 key tiles each, workspace permitting
+    a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1;
+    if (split_ws && !causal && D % 4 == 0 && max_k >= 1024) {
+        const long wgs = (long)cdiv(max_q, 64) * Hq * nseg;
+        int ns = (int)(256 / (wgs > 0 ? wgs : 1));
+        if (ns > 8) ns = 8;
+        if (ns > max_k / (8 * KV_TILE)) ns = max_k / (8 * KV_TILE);
+        const long need = (long)ns * total_q * Hq * (D + 1);
+        if (ns >= 2 && need <= split_ws_elems) {
+            a.nsplit = ns;
+            a.split_o = split_ws;
+            a.split_lse = split_ws + (long)ns * total_q * Hq * D;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (impl == 0) return launch_any<true>(a, nseg, max_q, st);
     return launch_any<false>(a, nseg, max_q, st);

@@ -95,10 +95,18 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
     if out is None:
         out = torch.empty((Tq, Hq, D), dtype=torch.bfloat16, device=q.device)
     lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device) if return_lse else None
+    # few query blocks x heads over a long key range (SAM2 memory attention: one head, 4096 queries, <= 28 736 keys): hand the kernel a
+    # workspace so it can split the keys over up to 8 workgroups per query block
+    split_ws, max_k = None, 0
+    if not causal and ((int(max_q) + 63) // 64) * Hq * nseg < 128 and k.shape[0] >= 1024 and D % 4 == 0:
+        max_k = k.shape[0] if nseg == 1 else int((cu_k[1:] - cu_k[:-1]).max())
+        if max_k >= 1024:
+            split_ws = torch.empty((8 * Tq * Hq * (D + 1),), dtype=torch.float32, device=q.device)
     rc = _lib.load().rga3_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(lse),
                                           cu_q.data_ptr(), cu_k.data_ptr(), nseg, int(max_q), Tq, Hq, Hkv, D,
                                           q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                          out.stride(0), out.stride(1), float(scale), int(bool(causal)), impl, _stream())
+                                          out.stride(0), out.stride(1), float(scale), int(bool(causal)), impl, _ptr(split_ws),
+                                          split_ws.numel() if split_ws is not None else 0, int(max_k), _stream())
     _lib.check(rc, "attn_varlen_fwd")
     return (out, lse) if return_lse else out
 
@@ -264,11 +272,25 @@ def bilinear(x, size, plane_idx=None):
     return out
 
 
+_conv_pack = {}
+
+
 def conv3x3s2(x, weight, bias, F: int, H: int, W: int, sig_scale: float = 0.0, sig_bias: float = 0.0):
     """token-major x [F*H*W, Cin] (bf16, or f32 single plane with the sigmoid affine) -> [F*(H/2)*(W/2), Cout]."""
     _need_cuda(x, weight, bias)
     Cout, Cin = weight.shape[0], weight.shape[1]
     assert weight.dtype == torch.bfloat16 and weight.is_contiguous() and x.is_contiguous() and x.numel() == F * H * W * Cin
+    if x.dtype == torch.bfloat16 and Cin % 8 == 0 and Cin >= 16:
+        # wide stages: im2col (16-byte copies) + the NT GEMM on the weight repacked [Cout, (kh, kw, ci)] (cached per weight version)
+        key = (weight.data_ptr(), weight._version)
+        wp = _conv_pack.get(key)
+        if wp is None:
+            if len(_conv_pack) > 64:
+                _conv_pack.clear()
+            wp = _conv_pack[key] = weight.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+        cols = torch.empty((F * (H // 2) * (W // 2), 9 * Cin), dtype=torch.bfloat16, device=x.device)
+        _lib.check(_lib.load().rga3_im2col3x3s2(x.data_ptr(), cols.data_ptr(), F, H, W, Cin, _stream()), "im2col3x3s2")
+        return gemm(cols, wp, bias)
     y = torch.empty((F * (H // 2) * (W // 2), Cout), dtype=torch.bfloat16, device=x.device)
     rc = _lib.load().rga3_conv3x3s2(x.data_ptr(), F32 if x.dtype == torch.float32 else BF16, weight.data_ptr(), _ptr(bias), y.data_ptr(), F, H, W,
                                     Cin, Cout, float(sig_scale), float(sig_bias), _stream())

@@ -111,6 +111,8 @@ ATTN_CASES = [
     ([9], [9], 8, 8, 32, False),
     ([512], [1500], 1, 1, 256, False),            # memory attention, 1 head x 256
     ([5], [133], 2, 2, 64, True),                 # causal with Lk > Lq (decode-style)
+    ([1024], [7000], 1, 1, 256, False),           # memory attention over a grown bank: key range split over workgroups
+    ([100, 700], [3000, 1200], 2, 2, 64, False),  # split-KV with ragged segments (second segment shorter than a slice set)
 ]
 
 

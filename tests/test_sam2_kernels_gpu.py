@@ -81,7 +81,7 @@ def test_conv3x3s2_dwconv_pixel_shuffle(dev):
     from rga3.hip import ops
 
     Fn, H, W = 2, 16, 16
-    for cin in (1, 4, 16):
+    for cin in (1, 4, 16, 64):
         x = rnd((Fn * H * W, cin), dev, seed=cin)
         w, b = rnd((cin * 4, cin, 3, 3), dev, 0.2, seed=cin + 1), rnd((cin * 4,), dev, 0.1, seed=cin + 2)
         ref = F.conv2d(x.float().cpu().view(Fn, H, W, cin).permute(0, 3, 1, 2), w.float().cpu(), b.float().cpu(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, cin * 4)
