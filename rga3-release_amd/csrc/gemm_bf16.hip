@@ -342,7 +342,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    if constexpr (PIPE == 0) {
+    static_assert(PIPE == 0, "the register-pipelined variant was removed (it spilled at 256x256 and lost to the ping-pong kernel)");
+    {
     stage_tile(0, 0, nk == 1);
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed (own loads: vmcnt(0); everyone's: barrier) and everyone is done reading
@@ -365,55 +366,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
                 for (int j = 0; j < NTL; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-    }
-    } else {
-    // Two-phase register pipeline: the fragments of the NEXT 32-deep k-step are read from LDS while the MFMAs of the
-    // current one issue (two fragment sets ping-pong), so no ds_read latency is exposed after the single barrier per
-    // K-tile; the LDS-DMA of tile kt+2 is issued right after that barrier and has a whole tile of MFMAs to land.
-    bf16x8 af0[MT], wf0[NTL], af1[MT], wf1[NTL];
-    auto load_set = [&](bf16x8* af, bf16x8* wf, int stage, int kk) {
-        const char* As = smem + stage * STAGE + (wm * WTM) * ROWB;
-        const char* Bs = smem + stage * STAGE + BM * ROWB + (wn * WTN) * ROWB;
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) wf[j] = *(const bf16x8*)(Bs + j * 16 * ROWB + foff[kk]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(As + i * 16 * ROWB + foff[kk]);
-    };
-    auto mma_set = [&](const bf16x8* af, const bf16x8* wf) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    };
-    auto interleave = [&]() {
-        // one LDS fragment read between consecutive MFMAs while reads remain, then the rest of the MFMAs
-#pragma unroll
-        for (int g2 = 0; g2 < MT + NTL; ++g2) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, MT * NTL - (MT + NTL), 0);
-    };
-    stage_tile(0, 0, nk == 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nk > 1) stage_tile(1, 1, nk == 2);
-    load_set(af0, wf0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        // phase A: prefetch (kt, kk=1), multiply (kt, kk=0)
-        load_set(af1, wf1, st, 1);
-        mma_set(af0, wf0);
-        interleave();
-        // my reads of stage st are complete, my DMA of tile kt+1 has landed; after the barrier that holds for everyone
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // phase B: refill stage st with tile kt+2, prefetch (kt+1, kk=0), multiply (kt, kk=1)
-        if (kt + 2 < nk) stage_tile(st, kt + 2, kt + 3 == nk);
-        if (kt + 1 < nk) load_set(af0, wf0, st ^ 1, 0);
-        mma_set(af1, wf1);
-        interleave();
     }
     }
     __syncthreads();  // all waves done with the last stage: LDS is free for the epilogue staging
@@ -1070,9 +1022,6 @@ static int pick_tile(int M, int N, int forced) {
 template <int ACT, bool OUT_F32>
 static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
     switch (tile) {
-        case 0: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 1>(a, st);
-        case 1: return launch_cfg<256, 128, 2, 4, ACT, OUT_F32, 1>(a, st);
-        case 2: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 1>(a, st);
         case 3: return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 4:  // 128x320: N = 1280 (ViT proj / fc2) at M = 8192 is exactly 256 tiles; 5 n-tiles per wave, so no SwiGLU pairs
             if constexpr (ACT != ACT_SWIGLU) return launch_cfg<128, 320, 2, 4, ACT, OUT_F32, 0>(a, st);
@@ -1121,7 +1070,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile >= -1 && tile <= 22, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 12) || (tile >= 20 && tile <= 22), "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;
