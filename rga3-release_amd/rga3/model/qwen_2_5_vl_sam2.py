@@ -72,6 +72,39 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
         if not config.train_mask_decoder:  # inference mode (reference :111-115)
             self.initialize_sam_modules(config)
 
+    @classmethod
+    def from_pretrained(cls, path, config=None, torch_dtype=None, device=None, strict=True, **unused):
+        """HF-style constructor used by the reference's entry points (train_joint.py:176-184, evaluation/*/inference_*.py):
+        builds the model from `config` (or <path>/config.json) directly in `torch_dtype` on `device`, then copies the checkpoint under
+        `path` shard by shard (rga3.utils.checkpoint).  Keyword arguments that only steer HF internals (attn_implementation,
+        low_cpu_mem_usage, device_map, use_cache, ...) are accepted and ignored: attention is this library's own kernel."""
+        from ..utils import checkpoint as CK
+
+        cfg = config if config is not None else UniGRConfig.from_pretrained(path)
+        old = torch.get_default_dtype()
+        if torch_dtype is not None:
+            torch.set_default_dtype(torch_dtype)
+        try:
+            with torch.device(device if device is not None else "cpu"):
+                model = cls(cfg)
+        finally:
+            torch.set_default_dtype(old)
+        CK.load_checkpoint(model, path, strict=strict)
+        return model
+
+    def save_pretrained(self, path, state_dict=None, max_shard_size=5 * 2**30, **unused):
+        """HF layout (sharded safetensors + index + config.json); `state_dict=` as merge_lora_weights_and_save_hf_model.py:134 passes it."""
+        from ..utils import checkpoint as CK
+
+        CK.save_checkpoint(state_dict if state_dict is not None else self, path, max_shard_bytes=max_shard_size, config=self.config)
+
+    def merge_and_unload(self):
+        """PEFT's call on the wrapped model (merge_lora_weights_and_save_hf_model.py:133): fold the LoRA factors into q_proj / v_proj."""
+        from ..utils import checkpoint as CK
+
+        CK.merge_lora_(self)
+        return self
+
     def initialize_sam_modules(self, config):
         """reference :117-140"""
         self.grounding_encoder = SAM2(ckpt_path=config.sam_pretrained, **(getattr(config, "sam_config", None) or {}))
