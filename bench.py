@@ -274,7 +274,8 @@ def main():
         from rga3.model.qwen_train import add_lora
         from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
 
-        add_lora(model, r=128, alpha=256, exclude=("sam_model", "grounding_encoder", "visual", "text_hidden_fcs"))
+        add_lora(model, r=128, alpha=256, dropout=0.05, exclude=("sam_model", "grounding_encoder", "visual", "text_hidden_fcs"))  # reference defaults (train_joint.py)
+        model.train()   # LoRA dropout active (the LoRALinear modules are created in training mode by add_lora on a train() model)
         full = args.mode == "train_full"
         for n, p in model.named_parameters():   # trainable set of reference train_joint.py:237-251
             p.requires_grad_(("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight") or (full and ("sam_mask_decoder" in n or "text_hidden_fcs" in n)))
@@ -397,7 +398,7 @@ def main():
                 "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": ("BASELINE.json configs[2] per GPU: " if args.mode == "train_full" else "") +
-                                       "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd with per-layer recompute, LoRA r128 q/v + lm_head + embed_tokens "
+                                       "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd with per-layer recompute, LoRA r128 (alpha 256, dropout 0.05) q/v + lm_head + embed_tokens "
                                        "trainable, AdamW step, bucketed RCCL all-reduce; 16 frames 448x448, S=2112, 1 sample/GPU" +
                                        (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)"
                                         if args.mode == "train_full" else ""), "per_gpu_batch": 1,

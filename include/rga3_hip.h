@@ -165,6 +165,10 @@ int rga3_gemm_stream_k_timeouts(void);
 /* dx = d rmsnorm(x; weight)/dx . dy (+ add): backward of HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:74-79) w.r.t. x */
 int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim, float eps,
                      void* stream);
+/* y = (accumulate ? y : 0) + dropout(x): n bf16 elements (multiple of 8), keep probability 1 - round(p * 65536) / 65536, scale 1 / keep;
+ * the mask is a counter hash of (seed, element index), so a recompute with the same seed reproduces it.  nn.Dropout(lora_dropout) on the
+ * LoRA branch input (PEFT LoraLayer; reference train_joint.py:193-232) and its backward (accumulate = 1 into the input gradient). */
+int rga3_dropout_bf16(const void* x, void* y, int64_t n, float p, int64_t seed, int accumulate, void* stream);
 /* backward of silu(gate)*up on the interleaved [T, 2I] pre-activation layout of RGA3_ACT_SWIGLU: dgu from da [T, I] */
 int rga3_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t T, int64_t I, void* stream);
 /* out[c, r] = in[r, c] (16-bit): operand layout for dW = dY^T X through the NT GEMM */

@@ -82,3 +82,27 @@ def ce_rows_ref(logits, labels):
     logits = logits.float()
     loss = F.cross_entropy(logits, labels, ignore_index=-100, reduction="none")
     return loss
+
+
+def dropout_mask_ref(n: int, p: float, seed: int):
+    """Keep mask (bool [n]) and scale of rga3_dropout_bf16: element e of 8-element group g keeps iff the 16-bit half (e & 1) of
+    hash(seed, 4g + e // 2) is >= round(p * 65536); scale = 1 / (1 - thr / 65536) (fp32).  This RNG is the build's own (torch's Philox
+    stream on the reference side is not reproducible across devices either); the oracle restates it for exact mask parity."""
+    import numpy as np
+
+    assert n % 8 == 0
+    seed &= 0x7FFFFFFFFFFFFFFF
+    thr = np.uint32(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
+    ctr = np.arange(n // 2, dtype=np.uint64)             # one hash per element pair
+    M = np.uint64(0xFFFFFFFF)
+    x = ((ctr & M) ^ np.uint64(seed & 0xFFFFFFFF)).astype(np.uint32)
+    y = ((ctr >> np.uint64(32)) ^ np.uint64(seed >> 32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = x * np.uint32(0xcc9e2d51); x = (x << np.uint32(15)) | (x >> np.uint32(17)); x = x * np.uint32(0x1b873593)
+        y = y ^ x; y = (y << np.uint32(13)) | (y >> np.uint32(19)); y = y * np.uint32(5) + np.uint32(0xe6546b64)
+        y ^= y >> np.uint32(16); y = y * np.uint32(0x85ebca6b); y ^= y >> np.uint32(13); y = y * np.uint32(0xc2b2ae35); y ^= y >> np.uint32(16)
+    keep = np.empty(n, dtype=bool)
+    keep[0::2] = (y & np.uint32(0xffff)) >= thr
+    keep[1::2] = (y >> np.uint32(16)) >= thr
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(thr) / np.float32(65536.0))
+    return keep, float(scale)

@@ -197,7 +197,12 @@ def _lin(x, P, name):
     y = F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
     a = P.get(name + ".lora_A.default.weight")
     if a is not None:
-        y = y + P["lora_scaling"] * F.linear(F.linear(x, a), P[name + ".lora_B.default.weight"])
+        xin = x
+        dm = P.get("lora_dropout_masks")   # {<name>: (keep mask broadcastable to x, scale)}: PEFT's nn.Dropout on the lora_A input, with a
+        if dm is not None and name in dm:  # GIVEN mask (tests pass the mask the build's counter hash produced)
+            keep, scale = dm[name]
+            xin = x * keep.to(x.dtype).reshape(x.shape) * scale
+        y = y + P["lora_scaling"] * F.linear(F.linear(xin, a), P[name + ".lora_B.default.weight"])
     return y
 
 

@@ -163,6 +163,37 @@ static inline unsigned g1(long total, long cap = 256L * 32) {
     return (unsigned)(b > cap ? cap : b);
 }
 
+// ------------------------------------------------------------------------------------------------ dropout (LoRA branch)
+// PEFT applies nn.Dropout(lora_dropout) to the INPUT of lora_A only (peft LoraLayer: result + lora_B(lora_A(dropout(x))) * scaling;
+// reference train_joint.py:193-232 with lora_dropout = 0.05).  The mask is a pure function of (seed, element index) - a counter
+// hash, not a stream - so the per-layer recompute in backward regenerates it bit for bit from the seed alone.
+// y = (accumulate ? y : 0) + keep(x) / (1 - p); element e of 8-element group g keeps iff bits16(hash(seed, 4g + e/2), e & 1) >= p * 65536.
+__device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsigned long long ctr) {
+    unsigned x = (unsigned)ctr ^ (unsigned)seed, y = (unsigned)(ctr >> 32) ^ (unsigned)(seed >> 32);
+    x *= 0xcc9e2d51u; x = (x << 15) | (x >> 17); x *= 0x1b873593u;
+    y ^= x; y = (y << 13) | (y >> 19); y = y * 5u + 0xe6546b64u;
+    y ^= y >> 16; y *= 0x85ebca6bu; y ^= y >> 13; y *= 0xc2b2ae35u; y ^= y >> 16;
+    return y;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, long n8, unsigned thr,
+                                                      float inv_keep, unsigned long long seed, int accumulate) {
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long)gridDim.x * 256) {
+        const u32x4 v = *(const u32x4*)(x + g * 8);
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (accumulate) o = *(const u32x4*)(y + g * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned h = dropout_hash(seed, (unsigned long long)g * 4 + j);
+            const float lo = ((h & 0xffffu) >= thr) ? __uint_as_float(v[j] << 16) * inv_keep : 0.f;
+            const float hi = ((h >> 16) >= thr) ? __uint_as_float(v[j] & 0xffff0000u) * inv_keep : 0.f;
+            const float alo = accumulate ? __uint_as_float(o[j] << 16) : 0.f, ahi = accumulate ? __uint_as_float(o[j] & 0xffff0000u) : 0.f;
+            o[j] = pack_bf2(alo + lo, ahi + hi);
+        }
+        *(u32x4*)(y + g * 8) = o;
+    }
+}
+
 }  // namespace rga3
 
 using namespace rga3;
@@ -178,6 +209,19 @@ extern "C" int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* d
     else if (dim <= 4096) hipLaunchKernelGGL(rmsnorm_bwd_kernel<8>, grid, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (cus)add, (us)dx, (long)rows, (int)dim, eps);
     else hipLaunchKernelGGL(rmsnorm_bwd_kernel<16>, grid, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (cus)add, (us)dx, (long)rows, (int)dim, eps);
     RGA3_CHECK_LAUNCH("rmsnorm_bwd");
+    return 0;
+}
+
+extern "C" int rga3_dropout_bf16(const void* x, void* y, int64_t n, float p, int64_t seed, int accumulate, void* stream) {
+    RGA3_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "dropout: n=%ld must be a positive multiple of 8", (long)n);
+    RGA3_CHECK_ARG(p >= 0.f && p < 1.f, "dropout: p=%f", p);
+    const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
+    const float inv_keep = 1.0f / (1.0f - (float)thr / 65536.0f);   // exactly the keep probability the 16-bit threshold realises
+    long blocks = cdiv(n / 8, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, (long)(n / 8),
+                       thr, inv_keep, (unsigned long long)seed, accumulate);
+    RGA3_CHECK_LAUNCH("dropout_kernel");
     return 0;
 }
 

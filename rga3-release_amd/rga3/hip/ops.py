@@ -372,6 +372,19 @@ def rmsnorm_bwd(x, weight, dy, eps: float, add=None):
     return dx
 
 
+def dropout(x, p: float, seed: int, out=None, accumulate: bool = False):
+    """out = (accumulate ? out : 0) + dropout(x) with the counter-hash mask of (seed, element index); x bf16 contiguous, numel % 8 == 0."""
+    _need_cuda(x, out)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.shape == x.shape and out.dtype == torch.bfloat16
+    _lib.check(_lib.load().rga3_dropout_bf16(x.data_ptr(), out.data_ptr(), x.numel(), float(p), int(seed) & 0x7FFFFFFFFFFFFFFF, int(bool(accumulate)), _stream()),
+               "dropout")
+    return out
+
+
 def swiglu_bwd(gu, da):
     _need_cuda(gu, da)
     assert gu.is_contiguous() and da.is_contiguous() and gu.shape[1] == 2 * da.shape[1]

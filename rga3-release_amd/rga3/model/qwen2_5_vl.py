@@ -370,7 +370,7 @@ class DecoderAttention(nn.Module):
             qkv = ops.gemm(h, w, b).view(T, Hq + 2 * Hk, D)
         elif all(type(m).__name__ in ("Linear", "LoRALinear") and type(m).__module__.startswith("rga3.") for m in (self.q_proj, self.k_proj, self.v_proj)):
             from .qwen_train import qkv_with_lora  # native LoRA: fused projection + in-place low-rank updates
-            qkv = qkv_with_lora(self, h)[0].view(T, Hq + 2 * Hk, D)
+            qkv = qkv_with_lora(self, h, seeds=getattr(self, "_lora_drop_seeds", None))[0].view(T, Hq + 2 * Hk, D)
         else:  # foreign wrappers (e.g. PEFT): honour them, then assemble the fused buffer
             qkv = torch.cat([self.q_proj(h), self.k_proj(h), self.v_proj(h)], dim=-1).view(T, Hq + 2 * Hk, D)
         ops.rope_(qkv, cos, sin, 0, Hq + Hk)

@@ -39,12 +39,16 @@ class LoRALinear(Linear):
         nn.init.zeros_(self.lora_B["default"].weight)
         self.scaling = alpha / r
         self.r = r
-        if dropout != 0.0:
-            raise NotImplementedError("LoRA dropout > 0 is not implemented on the HIP training path yet (reference uses 0.05)")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"lora dropout {dropout}")
+        self.dropout_p = float(dropout)   # nn.Dropout on the input of lora_A only, training mode only (PEFT LoraLayer)
 
     def forward(self, x, residual=None, act="none"):
         y = super().forward(x, residual=residual, act=act)
-        t = self.lora_A["default"](x.reshape(-1, x.shape[-1]))
+        xin = x.reshape(-1, x.shape[-1])
+        if self.training and self.dropout_p > 0.0:
+            xin = ops.dropout(xin.contiguous(), self.dropout_p, next_dropout_seed(0, 3))
+        t = self.lora_A["default"](xin)
         bs = (self.lora_B["default"].weight.detach() * self.scaling).to(t.dtype)
         y2 = y.view(-1, y.shape[-1])
         ops.gemm(t, bs, residual=y2, out=y2)
@@ -85,31 +89,76 @@ def _lora_parts(lin):
     return None
 
 
-def qkv_with_lora(at, h1):
-    """Fused q/k/v projection (+ LoRA updates on q and v accumulated in place); returns (qkv2 [T, (Hq+2Hk)D], tq, tv)."""
+_drop_state = {"step": 0}
+
+
+def next_dropout_seed(layer_idx: int, which: int, advance: bool = True) -> int:
+    """63-bit seed of one dropout mask: (torch's global seed, forward-pass counter, layer, projection).  The mask itself is a counter
+    hash of (seed, element index) inside the kernel, so storing the seed is storing the mask."""
+    if advance:
+        _drop_state["step"] += 1
+    base = torch.initial_seed() & 0xFFFFFF
+    return ((base << 39) ^ (_drop_state["step"] << 12) ^ (layer_idx << 2) ^ which) & 0x7FFFFFFFFFFFFFFF
+
+
+def preview_dropout_seeds(n_layers: int):
+    """The (seed_q, seed_v) pairs the NEXT lm_train_forward will use for layers 0..n_layers-1 (tests reproduce the masks from them)."""
+    saved = _drop_state["step"]
+    try:
+        return [(next_dropout_seed(li, 0), next_dropout_seed(li, 1, advance=False)) for li in range(n_layers)]
+    finally:
+        _drop_state["step"] = saved
+
+
+def _lora_dropout(at):
+    """(p_q, p_v) active dropout probabilities of the two LoRA branches (0 outside training mode)."""
+    pq = at.q_proj.dropout_p if isinstance(at.q_proj, LoRALinear) and at.q_proj.training else 0.0
+    pv = at.v_proj.dropout_p if isinstance(at.v_proj, LoRALinear) and at.v_proj.training else 0.0
+    return pq, pv
+
+
+def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
+    """Fused q/k/v projection (+ LoRA updates on q and v accumulated in place); returns (qkv2 [T, (Hq+2Hk)D], tq, tv[, hq, hv]).
+    seeds = (seed_q, seed_v) of the LoRA-branch dropout masks (None: fresh seeds when dropout is active); hq / hv are the (dropped)
+    inputs of lora_A, which the backward needs for dA."""
     Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
     wqkv, bqkv = at._packed()
     qkv2 = ops.gemm(h1, wqkv, bqkv)
     lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
+    pq, pv = _lora_dropout(at)
+    if seeds is None and (pq > 0.0 or pv > 0.0):
+        lid = getattr(at, "layer_idx", 0) or 0
+        seeds = (next_dropout_seed(lid, 0), next_dropout_seed(lid, 1, advance=False))
     tq = tv = None
+    hq = hv = h1
     if lq is not None:
-        tq = ops.gemm(h1, lq[0])
+        if pq > 0.0:
+            hq = ops.dropout(h1, pq, seeds[0])
+        tq = ops.gemm(hq, lq[0])
         oq = qkv2[:, : Hq * D]
         ops.gemm(tq, (lq[1].detach() * lq[2]).to(tq.dtype), residual=oq, out=oq)
     if lv is not None:
-        tv = ops.gemm(h1, lv[0])
+        if pv > 0.0:
+            hv = ops.dropout(h1, pv, seeds[1])
+        tv = ops.gemm(hv, lv[0])
         ov = qkv2[:, (Hq + Hk) * D:]
         ops.gemm(tv, (lv[1].detach() * lv[2]).to(tv.dtype), residual=ov, out=ov)
-    return qkv2, tq, tv
+    return (qkv2, tq, tv, hq, hv) if want_inputs else (qkv2, tq, tv)
 
 
 class DecoderLayerFn(torch.autograd.Function):
     """y = DecoderLayer(x); saves x only, recomputes in backward."""
 
     @staticmethod
-    def forward(ctx, x, aq, bq, av, bv, layer, cos, sin, cu, max_len):
-        with torch.no_grad():
-            y = layer(x, cos, sin, cu, max_len, None)
+    def forward(ctx, x, aq, bq, av, bv, layer, cos, sin, cu, max_len, seeds):
+        at0 = layer.self_attn
+        at0._lora_drop_seeds = seeds          # read by DecoderAttention's native-LoRA path (qwen2_5_vl.py) for this call only
+        try:
+            with torch.no_grad():
+                y = layer(x, cos, sin, cu, max_len, None)
+        finally:
+            at0._lora_drop_seeds = None
+        ctx.seeds = seeds
         ctx.layer, ctx.cos, ctx.sin, ctx.cu, ctx.max_len = layer, cos, sin, cu, max_len
         ctx.save_for_backward(x)
         return y
@@ -128,7 +177,8 @@ class DecoderLayerFn(torch.autograd.Function):
             h1 = ops.rmsnorm(x, w1.weight, w1.variance_epsilon)
             wqkv, bqkv = at._packed()
             lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
-            qkv2, tq, tv = qkv_with_lora(at, h1)
+            qkv2, tq, tv, hq_in, hv_in = qkv_with_lora(at, h1, seeds=ctx.seeds, want_inputs=True)
+            pq, pv = _lora_dropout(at)
             qkv = qkv2.view(T, Hq + 2 * Hk, D)
             ops.rope_(qkv, cos, sin, 0, Hq + Hk)
             q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
@@ -159,7 +209,7 @@ class DecoderLayerFn(torch.autograd.Function):
             grads = [None, None, None, None]
             if lq is not None or lv is not None:
                 h1_t = ops.transpose(h1)                                                # [H, T]
-                for slot, lp, t_, cols in ((0, lq, tq, (0, Hq * D)), (2, lv, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D))):
+                for slot, lp, t_, cols, pdrop, hin, sd in ((0, lq, tq, (0, Hq * D), pq, hq_in, 0), (2, lv, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D), pv, hv_in, 1)):
                     if lp is None:
                         continue
                     A, B, s = lp
@@ -173,14 +223,17 @@ class DecoderLayerFn(torch.autograd.Function):
                     dB = (dB.float() * s).to(B.dtype)
                     dt = ops.gemm(dsl, (ops.transpose(B.detach()) * s).to(B.dtype))     # [T, r] = s * dsl B
                     dt_t = ops.transpose(dt)
-                    h1_tp = h1_t
+                    h1_tp = h1_t if pdrop == 0.0 else ops.transpose(hin)                # lora_A saw the dropped input
                     if Tp != T:
-                        dt_t, h1_tp = ops.pad_cols(dt_t, Tp), ops.pad_cols(h1_t, Tp)
-                    dA = ops.gemm(dt_t, h1_tp)                                          # [r, H] = dt^T h1
-                    ops.gemm(dt, ops.transpose(A.detach()), residual=dh1, out=dh1)      # dh1 += dt A
+                        dt_t, h1_tp = ops.pad_cols(dt_t, Tp), ops.pad_cols(h1_tp, Tp)
+                    dA = ops.gemm(dt_t, h1_tp)                                          # [r, H] = dt^T dropout(h1)
+                    if pdrop == 0.0:
+                        ops.gemm(dt, ops.transpose(A.detach()), residual=dh1, out=dh1)  # dh1 += dt A
+                    else:                                                               # dh1 += mask / keep * (dt A): same seed, same mask
+                        ops.dropout(ops.gemm(dt, ops.transpose(A.detach())), pdrop, ctx.seeds[sd], out=dh1, accumulate=True)
                     grads[slot], grads[slot + 1] = dA, dB
             dx = ops.rmsnorm_bwd(x, w1.weight, dh1, w1.variance_epsilon, add=dx1)
-        return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None)
+        return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None, None)
 
 
 class EmbedFn(torch.autograd.Function):
@@ -254,11 +307,13 @@ def lm_train_forward(model, x, pos3, cu, max_len, labels_np, am_cur, flat_keep, 
     """Decoder + LM head + CE with autograd nodes; x [T, H] packed embeddings (requires_grad if embed_tokens is trainable)."""
     tm = model.model
     cos, sin = tm.mrope_tables(pos3)
-    for layer in tm.layers:
+    for li, layer in enumerate(tm.layers):
         at = layer.self_attn
         lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
+        pq, pv = _lora_dropout(at)
+        seeds = (next_dropout_seed(li, 0), next_dropout_seed(li, 1, advance=False)) if (pq > 0.0 or pv > 0.0) else None
         x = DecoderLayerFn.apply(x, lq[0] if lq else None, lq[1] if lq else None, lv[0] if lv else None, lv[1] if lv else None, layer, cos, sin,
-                                 cu, max_len)
+                                 cu, max_len, seeds)
     B, S = labels_np.shape
     nxt = np.full((B, S), -100, dtype=np.int64)
     nxt[:, :-1] = labels_np[:, 1:]
