@@ -212,6 +212,14 @@ int rga3_sam_preprocess_u8(const void* frames, int64_t T, int H, int W, int out_
                            int ksize_h, const int32_t* bv, const int32_t* kv, int ksize_v, void* tmp, void* dst_u8, void* dst_bf16,
                            const float* mean3, const float* std3, void* stream);
 
+/* ---- FP8 (OCP e4m3) path for the frozen-weight GEMMs of the LoRA fine-tune step (BASELINE.json configs[4]).
+ * q[r, :] = e4m3(x[r, :] / scales[r]), scales[r] = max|x[r, :]| / 448 (1 for a zero row); x bf16 [rows, K], K % 8 == 0; ldx / ldq in elements / bytes */
+int rga3_quant_fp8_rows(const void* x, void* q, float* scales, int64_t rows, int64_t K, int64_t ldx, int64_t ldq, void* stream);
+/* C[M,N] (bf16) = (Aq[M,K] . Wq[N,K]^T) * sa[m] * sw[n] (+ bias[n]) (+ residual[m,n]) with v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 MFMA
+ * rate); K % 128 == 0; lda / ldw in bytes.  Replaces the frozen nn.Linear contractions (HF modeling_qwen2_5_vl.py:602-757) when fp8 is enabled. */
+int rga3_gemm_fp8(const void* Aq, const void* Wq, const float* sa, const float* sw, const void* bias, const void* residual, void* C, int64_t M,
+                  int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,3 +106,22 @@ def dropout_mask_ref(n: int, p: float, seed: int):
     keep[1::2] = (y >> np.uint32(16)) >= thr
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(thr) / np.float32(65536.0))
     return keep, float(scale)
+
+
+def quant_fp8_rows_ref(x):
+    """(q float8_e4m3fn [rows, K], scale f32 [rows]) of rga3_quant_fp8_rows: scale = amax / 448 (1 for a zero row), q = e4m3(x / scale) (fp32 divide, RNE)."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (xf / scale[:, None]).to(torch.float8_e4m3fn), scale
+
+
+def gemm_fp8_ref(qa, sa, qw, sw, bias=None, residual=None):
+    """fp32 value of rga3_gemm_fp8 before the bf16 rounding(s): products of e4m3 values are exact in fp32, only the summation order differs."""
+    y = (qa.float() @ qw.float().t()) * sa[:, None] * sw[None, :]
+    if bias is not None:
+        y = y + bias.float()
+    y = y.to(torch.bfloat16).float()
+    if residual is not None:
+        y = (y + residual.float()).to(torch.bfloat16).float()
+    return y

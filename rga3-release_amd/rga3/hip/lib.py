@@ -42,6 +42,8 @@ SIGNATURES = {
     "rga3_bce_dice_sums": [_p, _p, _p, _i64, _i64, _p],
     "rga3_attn_varlen_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _p, _f, _i, _p, _i64, _p],
     "rga3_gemm_stream_k_timeouts": [],
+    "rga3_quant_fp8_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "rga3_gemm_fp8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "rga3_im2col3x3s2": [_p, _p, _i64, _i, _i, _i, _p],
     "rga3_pil_bicubic_coeffs": [_i, _i, _p, _p, _i64, _p],
     "rga3_sam_preprocess_u8": [_p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],

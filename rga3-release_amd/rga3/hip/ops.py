@@ -372,6 +372,31 @@ def rmsnorm_bwd(x, weight, dy, eps: float, add=None):
     return dx
 
 
+def quant_fp8_rows(x):
+    """bf16 [rows, K] (row stride free, K % 8 == 0) -> (uint8 [rows, K] holding OCP e4m3, f32 scales [rows]): q = e4m3(x / scale), scale = amax / 448."""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rga3_quant_fp8_rows(x.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, K, x.stride(0), q.stride(0), _stream()), "quant_fp8_rows")
+    return q, sc
+
+
+def gemm_fp8(aq, sa, wq, sw, bias=None, residual=None, out=None):
+    """(aq [M,K] e4m3 as uint8, sa [M]) x (wq [N,K], sw [N]) -> bf16 [M,N] = (aq . wq^T) * sa * sw (+ bias) (+ residual); K % 128 == 0."""
+    _need_cuda(aq, wq, sa, sw, bias, residual)
+    assert aq.dtype == torch.uint8 and wq.dtype == torch.uint8 and aq.stride(1) == 1 and wq.stride(1) == 1 and aq.shape[1] == wq.shape[1]
+    M, K = aq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=aq.device)
+    assert out.dtype == torch.bfloat16 and out.stride(1) == 1 and sa.dtype == torch.float32 and sw.dtype == torch.float32
+    _lib.check(_lib.load().rga3_gemm_fp8(aq.data_ptr(), wq.data_ptr(), sa.data_ptr(), sw.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K,
+                                         aq.stride(0), wq.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0, _stream()), "gemm_fp8")
+    return out
+
+
 def dropout(x, p: float, seed: int, out=None, accumulate: bool = False):
     """out = (accumulate ? out : 0) + dropout(x) with the counter-hash mask of (seed, element index); x bf16 contiguous, numel % 8 == 0."""
     _need_cuda(x, out)

@@ -232,3 +232,27 @@ def test_cross_entropy(dev, dtype):
     lf = logits.float().cpu().requires_grad_(True)
     (torch.nn.functional.cross_entropy(lf, labels, ignore_index=-100, reduction="sum") * 0.5).backward()
     assert _rel_l2(dl, lf.grad) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (2112, 4608, 3584), (2112, 3584, 18944), (17, 24, 128)])
+def test_fp8_quant_and_gemm(dev, M, N, K):
+    """e4m3 row quantiser bit-exact against torch's float8_e4m3fn cast; fp8 GEMM equal to the fp32 product of the quantised operands up to
+    summation order; and the end-to-end error against the unquantised bf16 GEMM at the level per-row e4m3 quantisation implies."""
+    from rga3.hip import ops
+
+    a, w = _rand((M, K), dev, seed=21), _rand((N, K), dev, 0.05, seed=22)
+    a[3, :] = 0                                  # a zero row: scale 1, all-zero codes
+    a[5, 7] = 40.0                               # an outlier sets that row's scale
+    qa, sa = ops.quant_fp8_rows(a)
+    qw, sw = ops.quant_fp8_rows(w)
+    ra, rsa = R.quant_fp8_rows_ref(a.cpu())
+    assert torch.equal(sa.cpu(), rsa)
+    assert torch.equal(qa.cpu().view(torch.float8_e4m3fn).float(), ra.float())
+    rw, rsw = R.quant_fp8_rows_ref(w.cpu())
+    bias, res = _rand((N,), dev, 0.5, seed=23), _rand((M, N), dev, seed=24)
+    out = ops.gemm_fp8(qa, sa, qw, sw, bias=bias, residual=res)
+    ref = R.gemm_fp8_ref(ra, rsa, rw, rsw, bias.cpu(), res.cpu())
+    assert _rel_l2(out, ref) < 4e-3, (M, N, K)
+    plain = ops.gemm_fp8(qa, sa, qw, sw)
+    full = R.linear_ref(a.cpu(), w.cpu())
+    assert _rel_l2(plain, full) < 6e-2           # two e4m3 operands: ~2^-4 relative per element, averaged over K
