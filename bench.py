@@ -66,6 +66,18 @@ def make_inputs(cfg, dev, seed=0):
                 video_grid_thw=torch.tensor([[8, 32, 32]]), second_per_grid_ts=torch.tensor([1.0]))
 
 
+def make_inputs_32f(cfg, dev, seed=0):
+    """32 frames 448x448 -> grid [[16,32,32]], 16 384 patches, 4096 video tokens + 64 others = S 4160."""
+    g = torch.Generator().manual_seed(seed)
+    px = torch.randn(16384, 1176, generator=g).clamp_(-1.8, 2.2).to(torch.bfloat16).to(dev)
+    text = torch.randint(0, 151643, (64,), generator=g)
+    ids = torch.cat([text[:14], torch.tensor([cfg.vision_start_token_id]), torch.full((4096,), cfg.video_token_id),
+                     torch.tensor([cfg.vision_end_token_id]), text[16:]])[None]
+    assert ids.shape[1] == 4160
+    return dict(input_ids=ids.to(dev), attention_mask=torch.ones_like(ids).to(dev), pixel_values_videos=px,
+                video_grid_thw=torch.tensor([[16, 32, 32]]), second_per_grid_ts=torch.tensor([1.0]))
+
+
 def build_full(dev, rank, sam_frames):
     """UniGRModel at 7B + SAM2-L (random init) and one synthetic training sample (SURVEY.md 8(d) config 3, B = 1 per GPU)."""
     from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
@@ -240,11 +252,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["forward", "train", "train_full", "sam2_stream"], default="forward",
+    ap.add_argument("--mode", choices=["forward", "train", "train_full", "sam2_stream", "lora_fp8"], default="forward",
                     help="forward = BASELINE configs[1] (default, the driver's metric); train = LLM fwd+bwd LoRA step with DDP gradient exchange; "
                          "train_full = BASELINE configs[2] per GPU: full RGA3 (Qwen2.5-VL-7B + SAM2-L, 16 SAM frames) fwd+bwd + AdamW; "
+                         "lora_fp8 = BASELINE configs[4]: LoRA step, 32 frames 448x448 (S = 4160), grad-accum 4, e4m3 GEMMs for the frozen decoder weights; "
                          "sam2_stream = BASELINE configs[3]: SAM2-L memory-attention mask-decoder stream over 32 frames 1024x1024, prompt on frame 0")
     ap.add_argument("--stream-frames", type=int, default=32)
+    ap.add_argument("--grad-accum", type=int, default=4)
+    ap.add_argument("--no-fp8", action="store_true", help="lora_fp8 mode with bf16 GEMMs (A/B)")
     ap.add_argument("--sam-frames", type=int, default=16)
     args = ap.parse_args()
 
@@ -268,9 +283,10 @@ def main():
         model, cfg, inputs = build_full(dev, rank, args.sam_frames)
     else:
         model, cfg = build_model(dev)
-        inputs = make_inputs(cfg, dev, seed=rank)
+        inputs = make_inputs_32f(cfg, dev, seed=rank) if args.mode == "lora_fp8" else make_inputs(cfg, dev, seed=rank)
 
-    if args.mode in ("train", "train_full"):
+    accum = args.grad_accum if args.mode == "lora_fp8" else 1
+    if args.mode in ("train", "train_full", "lora_fp8"):
         from rga3.model.qwen_train import add_lora
         from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
 
@@ -294,13 +310,22 @@ def main():
         class _Out:
             pass
 
+        if args.mode == "lora_fp8" and not args.no_fp8:
+            from rga3.model.qwen_train import set_fp8_frozen_gemms
+            set_fp8_frozen_gemms(True)
+
         def step():
             reducer.begin_step()
-            reducer.begin_micro_step()
-            out = model(**inputs)
-            if isinstance(out, dict):
-                out = type("O", (), {"loss": out["loss"]})()
-            out.loss.backward()
+            for mi in range(accum):   # gradient accumulation: gradients are exchanged once per optimizer step (DDP no_sync)
+                reducer.begin_micro_step()
+                out = model(**inputs)
+                if isinstance(out, dict):
+                    out = type("O", (), {"loss": out["loss"]})()
+                if mi + 1 < accum:
+                    with reducer.no_sync():
+                        (out.loss / accum).backward()
+                else:
+                    (out.loss / accum).backward()
             reducer.finish()
             opt.step(reducer.grad_view)
             o = _Out()
@@ -332,7 +357,7 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(out.logits.float()).all(), "non-finite logits"
     ms = elapsed / args.steps * 1e3
-    value = world / (elapsed / args.steps)
+    value = world * accum / (elapsed / args.steps)
 
     # ---- instrumented pass: HIP events around every GEMM launch on the launch stream
     roof = None
@@ -388,7 +413,25 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.mode == "forward":
         cpu = cpu_baseline()
 
-    if rank == 0 and args.mode in ("train", "train_full"):
+    if rank == 0 and args.mode == "lora_fp8":
+        n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        fl = accum * (21.6 + 62.6 - 4.6 + 57.9 + 57.9) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + recompute + dX at S = 4160
+        line = {"metric": "video-QA samples/sec (fwd+bwd) at 7B/32-frame -- LoRA fine-tune step, grad-accum %d, %s GEMMs for the frozen decoder weights" % (
+                    accum, "bf16" if args.no_fp8 else "fp8 e4m3"), "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16" if args.no_fp8 else "fp8(e4m3)+bf16", "data": "synthetic",
+                "config": {"workload": "BASELINE.json configs[4] per GPU: Qwen2.5-VL-7B, 32 frames 448x448 (grid [16,32,32], S = 4160), ViT fwd bf16 (frozen), decoder "
+                                       "fwd + per-layer recompute + bwd with the frozen qkv / o / gate-up / down contractions in e4m3 (per-token / per-row scales), "
+                                       "LoRA r128 (dropout 0.05) + lm_head + embed_tokens + norms + attention in bf16, %d micro-steps per optimizer step, "
+                                       "one bucketed RCCL all-reduce per optimizer step, AdamW" % accum,
+                           "per_gpu_batch": 1, "grad_accum": accum, "seq_len": 4160, "parallelism": f"dp{world}", "trainable_params": n_train,
+                           "approx_flops_per_step": fl},
+                "roofline": {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": 2 * PEAK_BF16 / 1e12 if not args.no_fp8 else PEAK_BF16 / 1e12,
+                             "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / (2 * PEAK_BF16 if not args.no_fp8 else PEAK_BF16), 4), "traffic": None,
+                             "note": "whole-step algorithmic FLOPs / step time against the dense fp8 (5 PF) or bf16 (2.5 PF) MFMA peak"},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    elif rank == 0 and args.mode in ("train", "train_full"):
         n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
         fl = (10.8 + 30.8 - 2.3 + 28.5 + 28.5) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + recompute + dX
         if args.mode == "train_full":

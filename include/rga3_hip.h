@@ -169,6 +169,8 @@ int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const vo
  * the mask is a counter hash of (seed, element index), so a recompute with the same seed reproduces it.  nn.Dropout(lora_dropout) on the
  * LoRA branch input (PEFT LoraLayer; reference train_joint.py:193-232) and its backward (accumulate = 1 into the input gradient). */
 int rga3_dropout_bf16(const void* x, void* y, int64_t n, float p, int64_t seed, int accumulate, void* stream);
+/* a [T, I] = silu(gate) * up from the interleaved [T, 2I] pre-activations of RGA3_ACT_SWIGLU's weight packing (un-fused form, used after rga3_gemm_fp8) */
+int rga3_swiglu_fwd(const void* gu, void* a, int64_t T, int64_t I, void* stream);
 /* backward of silu(gate)*up on the interleaved [T, 2I] pre-activation layout of RGA3_ACT_SWIGLU: dgu from da [T, I] */
 int rga3_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t T, int64_t I, void* stream);
 /* out[c, r] = in[r, c] (16-bit): operand layout for dW = dY^T X through the NT GEMM */

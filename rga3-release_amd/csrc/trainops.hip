@@ -92,6 +92,27 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const unsigned short* _
     }
 }
 
+// a [T, I] = silu(gate) * up from gu [T, 2I] pre-activations in 16-column blocks (gate | up): the un-fused form of the GEMM's SwiGLU
+// epilogue (same roundings: gate / up are bf16 already, silu rounded to bf16 before the product), used after the fp8 GEMM
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ a, long T, long I) {
+    const long nch = I / 8;
+    const long total = T * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long ch = i % nch, t = i / nch;
+        const long blk = ch / 2, half = ch % 2;
+        const long goff = t * 2 * I + blk * 32 + half * 8;
+        float g[8], u[8], o[8];
+        un8(*(const u32x4*)(gu + goff), g);
+        un8(*(const u32x4*)(gu + goff + 16), u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float silu = g[e] / (1.f + __expf(-g[e]));
+            o[e] = __uint_as_float(((unsigned)f2bf(silu)) << 16) * u[e];
+        }
+        *(u32x4*)(a + t * I + ch * 8) = pk8_(o);
+    }
+}
+
 // out[c, r] = in[r, c] for 16-bit elements, 64x64 tiles through LDS (padded rows)
 __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, long R, long C,
                                                           long ldi, long ldo) {
@@ -229,6 +250,13 @@ extern "C" int rga3_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_
     RGA3_CHECK_ARG(gu && da && dgu && T > 0 && I > 0 && I % 16 == 0, "swiglu_bwd: bad args");
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(g1(T * (I / 8))), dim3(256), 0, (hipStream_t)stream, (cus)gu, (cus)da, (us)dgu, (long)T, (long)I);
     RGA3_CHECK_LAUNCH("swiglu_bwd");
+    return 0;
+}
+
+extern "C" int rga3_swiglu_fwd(const void* gu, void* a, int64_t T, int64_t I, void* stream) {
+    RGA3_CHECK_ARG(gu && a && T > 0 && I > 0 && I % 16 == 0, "swiglu_fwd: bad args");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(g1(T * (I / 8))), dim3(256), 0, (hipStream_t)stream, (cus)gu, (us)a, (long)T, (long)I);
+    RGA3_CHECK_LAUNCH("swiglu_fwd");
     return 0;
 }
 

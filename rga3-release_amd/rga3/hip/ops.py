@@ -410,6 +410,15 @@ def dropout(x, p: float, seed: int, out=None, accumulate: bool = False):
     return out
 
 
+def swiglu_fwd(gu):
+    """silu(gate) * up from interleaved pre-activations gu [T, 2I] -> [T, I]."""
+    _need_cuda(gu)
+    assert gu.dtype == torch.bfloat16 and gu.is_contiguous() and gu.shape[1] % 32 == 0
+    a = torch.empty((gu.shape[0], gu.shape[1] // 2), dtype=torch.bfloat16, device=gu.device)
+    _lib.check(_lib.load().rga3_swiglu_fwd(gu.data_ptr(), a.data_ptr(), gu.shape[0], gu.shape[1] // 2, _stream()), "swiglu_fwd")
+    return a
+
+
 def swiglu_bwd(gu, da):
     _need_cuda(gu, da)
     assert gu.is_contiguous() and da.is_contiguous() and gu.shape[1] == 2 * da.shape[1]

@@ -83,6 +83,40 @@ def _wt(owner, key, *srcs, build):
     return cache[key][1]
 
 
+# ------------------------------------------------------------------------------------------------ fp8 frozen-weight GEMMs (config 5)
+_fp8 = {"on": False}
+
+
+def set_fp8_frozen_gemms(on: bool):
+    """Run the decoder's frozen-weight contractions (qkv / o / gate-up / down and their transposes in backward) through the e4m3 GEMM
+    (BASELINE.json configs[4]).  Activations are quantised per token on the fly, weights per output row once (cached per weight version);
+    LoRA factors, lm_head, embeddings, norms, attention and the ViT stay bf16."""
+    _fp8["on"] = bool(on)
+
+
+def fp8_frozen_gemms() -> bool:
+    return _fp8["on"]
+
+
+def _fp8_pack(owner, key, *srcs, build):
+    """(q uint8 [N, K], scale f32 [N]) of the weight matrix `build()` returns, cached like _wt (the bf16 matrix is not kept)."""
+    def mk():
+        w = build()
+        q, sc = ops.quant_fp8_rows(w.contiguous())
+        return (q, sc)
+    return _wt(owner, "fp8:" + key, *srcs, build=mk)
+
+
+def _fgemm(x, owner, key, srcs, build, bias=None, residual=None, out=None):
+    """x [M, K] @ build()^T for a FROZEN weight: e4m3 when enabled and K % 128 == 0, else the bf16 GEMM on the cached bf16 matrix."""
+    if _fp8["on"] and x.shape[1] % 128 == 0:
+        q, sc = _fp8_pack(owner, key, *srcs, build=build)
+        xq, xs = ops.quant_fp8_rows(x)
+        return ops.gemm_fp8(xq, xs, q, sc, bias=bias, residual=residual, out=out)
+    w = _wt(owner, key, *srcs, build=build)
+    return ops.gemm(x, w, bias, residual=residual, out=out)
+
+
 def _lora_parts(lin):
     if isinstance(lin, LoRALinear):
         return lin.lora_A["default"].weight, lin.lora_B["default"].weight, lin.scaling
@@ -123,7 +157,10 @@ def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
     inputs of lora_A, which the backward needs for dA."""
     Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
     wqkv, bqkv = at._packed()
-    qkv2 = ops.gemm(h1, wqkv, bqkv)
+    if _fp8["on"] and h1.shape[1] % 128 == 0:
+        qkv2 = _fgemm(h1, at, "wqkv", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: wqkv, bias=bqkv)
+    else:
+        qkv2 = ops.gemm(h1, wqkv, bqkv)
     lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
     pq, pv = _lora_dropout(at)
     if seeds is None and (pq > 0.0 or pv > 0.0):
@@ -146,18 +183,42 @@ def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
     return (qkv2, tq, tv, hq, hv) if want_inputs else (qkv2, tq, tv)
 
 
+def _layer_forward_fp8(layer, x, cos, sin, cu, max_len, seeds):
+    """Decoder layer forward with the frozen contractions in e4m3 (same operation order as the recompute in DecoderLayerFn.backward)."""
+    at, mlp = layer.self_attn, layer.mlp
+    Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
+    T = x.shape[0]
+    w1, w2 = layer.input_layernorm, layer.post_attention_layernorm
+    h1 = ops.rmsnorm(x, w1.weight, w1.variance_epsilon)
+    qkv2 = qkv_with_lora(at, h1, seeds=seeds)[0]
+    qkv = qkv2.view(T, Hq + 2 * Hk, D)
+    ops.rope_(qkv, cos, sin, 0, Hq + Hk)
+    att = ops.attn_varlen(qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:], cu, cu, max_len, D ** -0.5, causal=True)
+    x1 = _fgemm(att.view(T, Hq * D), at, "wo", (at.o_proj.weight,), lambda: at.o_proj.weight.detach(), residual=x)
+    h2 = ops.rmsnorm(x1, w2.weight, w2.variance_epsilon)
+    wgu, bgu, wd = mlp._packed()
+    gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)
+    a = ops.swiglu_fwd(gu)
+    del gu
+    return _fgemm(a, mlp, "wd", (mlp.down_proj.weight,), lambda: wd, bias=mlp.down_proj.bias, residual=x1)
+
+
 class DecoderLayerFn(torch.autograd.Function):
     """y = DecoderLayer(x); saves x only, recomputes in backward."""
 
     @staticmethod
     def forward(ctx, x, aq, bq, av, bv, layer, cos, sin, cu, max_len, seeds):
         at0 = layer.self_attn
-        at0._lora_drop_seeds = seeds          # read by DecoderAttention's native-LoRA path (qwen2_5_vl.py) for this call only
-        try:
+        if _fp8["on"]:
             with torch.no_grad():
-                y = layer(x, cos, sin, cu, max_len, None)
-        finally:
-            at0._lora_drop_seeds = None
+                y = _layer_forward_fp8(layer, x, cos, sin, cu, max_len, seeds)
+        else:
+            at0._lora_drop_seeds = seeds          # read by DecoderAttention's native-LoRA path (qwen2_5_vl.py) for this call only
+            try:
+                with torch.no_grad():
+                    y = layer(x, cos, sin, cu, max_len, None)
+            finally:
+                at0._lora_drop_seeds = None
         ctx.seeds = seeds
         ctx.layer, ctx.cos, ctx.sin, ctx.cu, ctx.max_len = layer, cos, sin, cu, max_len
         ctx.save_for_backward(x)
@@ -183,29 +244,25 @@ class DecoderLayerFn(torch.autograd.Function):
             ops.rope_(qkv, cos, sin, 0, Hq + Hk)
             q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
             att, lse = ops.attn_varlen(q, k, v, cu, cu, max_len, D ** -0.5, causal=True, return_lse=True)
-            x1 = ops.gemm(att.view(T, Hq * D), at.o_proj.weight, residual=x)
+            x1 = _fgemm(att.view(T, Hq * D), at, "wo", (at.o_proj.weight,), lambda: at.o_proj.weight.detach(), residual=x)
             h2 = ops.rmsnorm(x1, w2.weight, w2.variance_epsilon)
             wgu, bgu, wd = mlp._packed()
-            gu = ops.gemm(h2, wgu, bgu)                                   # pre-activations, interleaved [T, 2*Ip]
+            gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)   # pre-activations, interleaved [T, 2*Ip]
             # ---- MLP backward
-            wd_t = _wt(mlp, "wd_t", mlp.down_proj.weight, build=lambda: ops.transpose(wd))            # [Ip, H]
-            wgu_t = _wt(mlp, "wgu_t", mlp.gate_proj.weight, mlp.up_proj.weight, build=lambda: ops.transpose(wgu))  # [H, 2Ip]
-            da = ops.gemm(dy, wd_t)
+            da = _fgemm(dy, mlp, "wd_t", (mlp.down_proj.weight,), lambda: ops.transpose(wd))                                   # [T, Ip]
             dgu = ops.swiglu_bwd(gu, da)
             del gu, da
-            dh2 = ops.gemm(dgu, wgu_t)
+            dh2 = _fgemm(dgu, mlp, "wgu_t", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: ops.transpose(wgu))            # [T, H]
             del dgu
             dx1 = ops.rmsnorm_bwd(x1, w2.weight, dh2, w2.variance_epsilon, add=dy)
             # ---- attention backward
-            wo_t = _wt(at, "wo_t", at.o_proj.weight, build=lambda: ops.transpose(at.o_proj.weight.detach()))   # [HqD, H]
-            datt = ops.gemm(dx1, wo_t).view(T, Hq, D)
+            datt = _fgemm(dx1, at, "wo_t", (at.o_proj.weight,), lambda: ops.transpose(at.o_proj.weight.detach())).view(T, Hq, D)
             dqkv = torch.empty_like(qkv)
             ops.attn_varlen_bwd(q, k, v, att, datt, lse, cu, cu, max_len, max_len, D ** -0.5, True, dq=dqkv[:, :Hq], dk=dqkv[:, Hq:Hq + Hk],
                                 dv=dqkv[:, Hq + Hk:])
             ops.rope_(dqkv, cos, (-sin).contiguous(), 0, Hq + Hk)   # inverse rotation (cos/sin tables are symmetric in the two halves)
             dqkv2 = dqkv.view(T, (Hq + 2 * Hk) * D)
-            wqkv_t = _wt(at, "wqkv_t", at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, build=lambda: ops.transpose(wqkv))   # [H, (Hq+2Hk)D]
-            dh1 = ops.gemm(dqkv2, wqkv_t)
+            dh1 = _fgemm(dqkv2, at, "wqkv_t", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: ops.transpose(wqkv))   # [T, H]
             grads = [None, None, None, None]
             if lq is not None or lv is not None:
                 h1_t = ops.transpose(h1)                                                # [H, T]

@@ -201,3 +201,58 @@ def test_llm_training_step_gradients_with_lora_dropout(dev):
     Pn = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in P.items() if k != "lora_dropout_masks"}
     ref_eval = Q.forward(Pn, oracle_cfg(), ids, am, labels=labels, pixel_values_videos=px.float(), video_grid_thw=G["full_grid"], second_per_grid_ts=np.array([1.0, 1.0]))
     assert abs(l_eval.item() - ref_eval["loss"].item()) / ref_eval["loss"].item() < 1e-2
+
+
+def test_fp8_frozen_gemm_training_step_close_to_bf16(dev):
+    """Config 5 path: the same LoRA training step with the frozen decoder contractions in e4m3 vs bf16 (dims chosen so every K is a
+    multiple of 128 and the fp8 kernels are the ones that run).  The kernels are pinned against the oracle in test_kernels_gpu.py; here the
+    integration is checked: loss within 2 %, gradients within the e4m3 quantisation noise of the bf16 step, same trainable set."""
+    from rga3.model import qwen_train as QT
+    from rga3.model.qwen2_5_vl import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+
+    kw = product_cfg_kwargs()
+    kw.update(hidden_size=256, intermediate_size=512, num_attention_heads=2, num_key_value_heads=1, vocab_size=640, num_hidden_layers=2,
+              rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]})
+    kw["vision_config"] = dict(kw["vision_config"], out_hidden_size=256)
+    torch.manual_seed(3)
+    m = Qwen2_5_VLForConditionalGeneration(Qwen2_5_VLConfig(**kw))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0, 0.05)
+            elif "norm" in n:
+                p.fill_(1.0)
+    QT.add_lora(m, r=8, alpha=16, dropout=0.0)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0, 0.05)
+    m = m.to(torch.bfloat16).to(dev).train()
+    for n, p in m.named_parameters():
+        p.requires_grad_(("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight"))
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(1, 300, (2, 200), generator=g)
+    labels = ids.clone()
+    labels[:, :150] = -100
+    am = torch.ones_like(ids)
+
+    def step(fp8):
+        QT.set_fp8_frozen_gemms(fp8)
+        try:
+            for p in m.parameters():
+                p.grad = None
+            out = m(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev))
+            out.loss.backward()
+            return out.loss.item(), {n: p.grad.float().cpu().clone() for n, p in m.named_parameters() if p.requires_grad}
+        finally:
+            QT.set_fp8_frozen_gemms(False)
+
+    l16, g16 = step(False)
+    l8, g8 = step(True)
+    assert any(k.startswith("fp8:") for layer in m.model.layers for k in layer.mlp.__dict__.get("_wt_cache", {})), "fp8 weight packs were not built"
+    assert abs(l8 - l16) / l16 < 2e-2, (l8, l16)
+    assert set(g8) == set(g16)
+    errs = {k: rel_l2(g8[k], g16[k]) for k in g16}
+    # each e4m3 x e4m3 contraction carries ~5 % relative noise (3 mantissa bits, two operands, random-sign terms do not average it out);
+    # eight of them sit on the path from the loss to a LoRA factor
+    assert max(errs.values()) < 0.3 and float(np.median(list(errs.values()))) < 0.2, errs
