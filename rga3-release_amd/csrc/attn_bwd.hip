@@ -12,6 +12,9 @@
 // Call sites replaced: the autograd of flash_attn_varlen_func / SDPA under train_joint.py:534 (model.backward).
 #include "common.h"
 
+#include <mutex>
+#include <set>
+
 namespace rga3 {
 
 struct AttnBwdArgs {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------- dQ
-template <int DP, int QT, int NWAVE>
+template <int DP, int QT, int NWAVE, bool PAIR>
 __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     constexpr int NT = 64 * NWAVE;
     constexpr int BLOCK_M = NWAVE * QT * 16;
@@ -75,9 +78,23 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) 
     const int hk = hq / (p.Hq / p.Hkv);
     const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
     const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
-    const int qb0 = blockIdx.x * BLOCK_M;
-    if (qb0 >= Lq) return;
     const int shift = Lk - Lq;
+    // causal launches pair query block i with n-1-i (as the forward does): every workgroup walks the same number of key tiles
+    const int nqb = (Lq + BLOCK_M - 1) / BLOCK_M;
+    int qb_first = blockIdx.x, qb_second = -1;
+    if constexpr (PAIR) {
+        qb_first = nqb - 1 - (int)blockIdx.x;
+        qb_second = (int)blockIdx.x;
+        if (qb_second > qb_first) return;
+        if (qb_second == qb_first) qb_second = -1;
+    } else if (qb_first >= nqb) {
+        return;
+    }
+    for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+    const int qbi = pass == 0 ? qb_first : qb_second;
+    if (qbi < 0) break;
+    if (pass == 1) __syncthreads();
+    const int qb0 = qbi * BLOCK_M;
     const int qw0 = qb0 + wid * (QT * 16);
 
     // Q and dO fragments ("B" operands): lane (c, g) holds row q = c, d = 32*ds + 8g .. +7
@@ -216,13 +233,14 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) 
             }
         }
     }
+    }  // pass
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
 // SPLIT (GQA with a workspace): grid.y runs over the QUERY heads; each workgroup handles one head of the group and writes f32
 // partial sums, attn_dkv_reduce_kernel adds the group in a fixed order (still no atomics, still bitwise reproducible).  Without
 // it one workgroup loops all heads of the group: 33 x 4 = 132 workgroups for the decoder at S = 2112, 0.97 ms per layer.
-template <int DP, int NWAVE, bool SPLIT>
+template <int DP, int NWAVE, bool SPLIT, bool PAIR>
 __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     constexpr int NT = 64 * NWAVE;
     constexpr int BLOCK_N = NWAVE * 16;  // keys per workgroup (one 16-key tile per wave)
@@ -246,9 +264,22 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
     const int hh0 = SPLIT ? (int)blockIdx.y % group : 0, hh1 = SPLIT ? hh0 + 1 : group;
     const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
     const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
-    const int kb0 = blockIdx.x * BLOCK_N;
-    if (kb0 >= Lk) return;
     const int shift = Lk - Lq;
+    const int nkb = (Lk + BLOCK_N - 1) / BLOCK_N;
+    int kb_first = blockIdx.x, kb_second = -1;
+    if constexpr (PAIR) {   // causal: key block j sees query tiles j..n-1; pair j with n-1-j
+        kb_first = (int)blockIdx.x;                 // the long one (early keys) first
+        kb_second = nkb - 1 - (int)blockIdx.x;
+        if (kb_first > kb_second) return;
+        if (kb_second == kb_first) kb_second = -1;
+    } else if (kb_first >= nkb) {
+        return;
+    }
+    for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+    const int kbi = pass == 0 ? kb_first : kb_second;
+    if (kbi < 0) break;
+    if (pass == 1) __syncthreads();
+    const int kb0 = kbi * BLOCK_N;
     const int key = kb0 + wid * 16 + c;  // this lane's key
 
     // K and V fragments ("B" operands): lane holds key row `key`, d = 32*ds + 8g .. +7
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
                 }
             }
         }
-        return;
+        continue;
     }
     if (key < Lk) {
         unsigned short* rk = p.dk + (long)(ks + key) * p.dk_st + (long)hk * p.dk_sh;
@@ -380,6 +411,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
             }
         }
     }
+    }  // pass
 }
 
 // dK / dV = sum over the query heads of a GQA group of the f32 partials, in head order (thread = 4 consecutive d of one (key, kv head))
@@ -413,35 +445,57 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
     constexpr int BLOCK_M = 4 * QT * 16;
     constexpr int LDS_DQ = 2 * BT * (DP * 2 + 32);
     constexpr int LDS_DKV = 2 * BT * (DP * 2 + 32) + 2 * BT * 4;
-    auto kq = attn_bwd_dq_kernel<DP, QT, 4>;
-    auto kk = attn_bwd_dkv_kernel<DP, 4, false>;
-    static bool attr_done = false;
-    if (!attr_done && LDS_DKV > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+    auto prep = [](const void* k, int lds) -> int {   // once per kernel instantiation
+        if (lds <= 48 * 1024) return 0;
+        static std::mutex mu;
+        static std::set<const void*> done;
+        std::lock_guard<std::mutex> lk(mu);
+        if (done.count(k)) return 0;
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(-(int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+        done.insert(k);
+        return 0;
+    };
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(a.total_q * a.Hq, 4)), dim3(256), 0, st, a);
     RGA3_CHECK_LAUNCH("attn_delta_kernel");
-    hipLaunchKernelGGL(kq, dim3((unsigned)cdiv(max_q, BLOCK_M), (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DQ, st, a);
+    const unsigned nqb = (unsigned)cdiv(max_q, BLOCK_M), nkb = (unsigned)cdiv(max_k, 64);
+    const bool pair = a.causal && nqb >= 4 && nkb >= 4;   // balanced causal rows (see the kernels)
+    if (pair) {
+        auto kq = attn_bwd_dq_kernel<DP, QT, 4, true>;
+        if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
+        hipLaunchKernelGGL(kq, dim3((nqb + 1) / 2, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DQ, st, a);
+    } else {
+        auto kq = attn_bwd_dq_kernel<DP, QT, 4, false>;
+        if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
+        hipLaunchKernelGGL(kq, dim3(nqb, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DQ, st, a);
+    }
     RGA3_CHECK_LAUNCH("attn_bwd_dq_kernel");
+    const unsigned gx = pair ? (nkb + 1) / 2 : nkb;
     if (a.dkv_ws && a.Hq > a.Hkv) {
-        auto ks_ = attn_bwd_dkv_kernel<DP, 4, true>;
-        static bool attr2 = false;
-        if (!attr2 && LDS_DKV > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)ks_, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
-            if (e != hipSuccess) return fail(-(int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr2 = true;
+        if (pair) {
+            auto ks_ = attn_bwd_dkv_kernel<DP, 4, true, true>;
+            if (int rc = prep((const void*)ks_, LDS_DKV)) return rc;
+            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+        } else {
+            auto ks_ = attn_bwd_dkv_kernel<DP, 4, true, false>;
+            if (int rc = prep((const void*)ks_, LDS_DKV)) return rc;
+            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
         }
-        hipLaunchKernelGGL(ks_, dim3((unsigned)cdiv(max_k, 64), (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
         RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel<split>");
         const long rows = a.total_k * a.Hkv;
         hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)cdiv(rows * (a.D / 4), 256)), dim3(256), 0, st, a);
         RGA3_CHECK_LAUNCH("attn_dkv_reduce_kernel");
         return 0;
     }
-    hipLaunchKernelGGL(kk, dim3((unsigned)cdiv(max_k, 64), (unsigned)a.Hkv, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+    if (pair) {
+        auto kk = attn_bwd_dkv_kernel<DP, 4, false, true>;
+        if (int rc = prep((const void*)kk, LDS_DKV)) return rc;
+        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+    } else {
+        auto kk = attn_bwd_dkv_kernel<DP, 4, false, false>;
+        if (int rc = prep((const void*)kk, LDS_DKV)) return rc;
+        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+    }
     RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel");
     return 0;
 }

