@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) 
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int j = 2 * ss + (u >> 2), r = u & 3;
-                    float pr = exp2f(s[j][r] * p.scale_log2 - lse2[t]);
+                    float pr = __builtin_amdgcn_exp2f(s[j][r] * p.scale_log2 - lse2[t]);  // raw v_exp_f32: p <= 1, tiny values may flush
                     if (need_mask) {
                         const int key = k0 + j * 16 + 4 * g + r;
                         const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
                     const int j = 2 * ss + (u >> 2), r = u & 3;
                     const int ql = j * 16 + 4 * g + r;   // query index inside the tile
                     const int qi = q0 + ql;
-                    float pr = exp2f(s[j][r] * p.scale_log2 - Ls[ql]);
+                    float pr = __builtin_amdgcn_exp2f(s[j][r] * p.scale_log2 - Ls[ql]);
                     const bool ok = (qi < Lq) && (key < Lk) && (!p.causal || key <= qi + shift);
                     pr = ok ? pr : 0.f;
                     e[u] = pr;
@@ -442,7 +442,9 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
 template <int DP>
 static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipStream_t st) {
     constexpr int QT = (DP >= 128) ? 1 : 2;
-    constexpr int BLOCK_M = 4 * QT * 16;
+    // 8 waves per workgroup at D = 128 (the decoder): a K/V (resp. Q/dO) tile staged once serves twice the rows
+    constexpr int NW = (DP == 128) ? 8 : 4;
+    constexpr int BLOCK_M = NW * QT * 16;
     constexpr int LDS_DQ = 2 * BT * (DP * 2 + 32);
     constexpr int LDS_DKV = 2 * BT * (DP * 2 + 32) + 2 * BT * 4;
     auto prep = [](const void* k, int lds) -> int {   // once per kernel instantiation
@@ -458,28 +460,28 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
     };
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(a.total_q * a.Hq, 4)), dim3(256), 0, st, a);
     RGA3_CHECK_LAUNCH("attn_delta_kernel");
-    const unsigned nqb = (unsigned)cdiv(max_q, BLOCK_M), nkb = (unsigned)cdiv(max_k, 64);
+    const unsigned nqb = (unsigned)cdiv(max_q, BLOCK_M), nkb = (unsigned)cdiv(max_k, 16 * NW);
     const bool pair = a.causal && nqb >= 4 && nkb >= 4;   // balanced causal rows (see the kernels)
     if (pair) {
-        auto kq = attn_bwd_dq_kernel<DP, QT, 4, true>;
+        auto kq = attn_bwd_dq_kernel<DP, QT, NW, true>;
         if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
-        hipLaunchKernelGGL(kq, dim3((nqb + 1) / 2, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DQ, st, a);
+        hipLaunchKernelGGL(kq, dim3((nqb + 1) / 2, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
     } else {
-        auto kq = attn_bwd_dq_kernel<DP, QT, 4, false>;
+        auto kq = attn_bwd_dq_kernel<DP, QT, NW, false>;
         if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
-        hipLaunchKernelGGL(kq, dim3(nqb, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DQ, st, a);
+        hipLaunchKernelGGL(kq, dim3(nqb, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
     }
     RGA3_CHECK_LAUNCH("attn_bwd_dq_kernel");
     const unsigned gx = pair ? (nkb + 1) / 2 : nkb;
     if (a.dkv_ws && a.Hq > a.Hkv) {
         if (pair) {
-            auto ks_ = attn_bwd_dkv_kernel<DP, 4, true, true>;
+            auto ks_ = attn_bwd_dkv_kernel<DP, NW, true, true>;
             if (int rc = prep((const void*)ks_, LDS_DKV)) return rc;
-            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
         } else {
-            auto ks_ = attn_bwd_dkv_kernel<DP, 4, true, false>;
+            auto ks_ = attn_bwd_dkv_kernel<DP, NW, true, false>;
             if (int rc = prep((const void*)ks_, LDS_DKV)) return rc;
-            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
         }
         RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel<split>");
         const long rows = a.total_k * a.Hkv;
@@ -488,13 +490,13 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
         return 0;
     }
     if (pair) {
-        auto kk = attn_bwd_dkv_kernel<DP, 4, false, true>;
+        auto kk = attn_bwd_dkv_kernel<DP, NW, false, true>;
         if (int rc = prep((const void*)kk, LDS_DKV)) return rc;
-        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
     } else {
-        auto kk = attn_bwd_dkv_kernel<DP, 4, false, false>;
+        auto kk = attn_bwd_dkv_kernel<DP, NW, false, false>;
         if (int rc = prep((const void*)kk, LDS_DKV)) return rc;
-        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(256), LDS_DKV, st, a);
+        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
     }
     RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel");
     return 0;
