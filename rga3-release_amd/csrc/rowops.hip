@@ -188,6 +188,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
     }
 }
 
+// Narrow rows (dim < 8 or not a multiple of 8, <= 16): one thread per row, scalar bf16 loads.  The 4-channel LayerNorm2d + GELU of the
+// memory encoder's first mask-downsampler stage (reference model/sam2.py:611-643) runs 4 x 512 x 512 rows per frame through this.
+__global__ __launch_bounds__(256) void layernorm_tiny_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                             const unsigned short* __restrict__ b, unsigned short* __restrict__ y, long rows, int dim, long ldx,
+                                                             long ldy, float eps, int act) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float f[16];
+    float s1 = 0.f;
+    for (int e = 0; e < dim; ++e) { f[e] = bf2f(x[row * ldx + e]); s1 += f[e]; }
+    const float mean = s1 / (float)dim;
+    float s2 = 0.f;
+    for (int e = 0; e < dim; ++e) { const float d = f[e] - mean; s2 += d * d; }
+    const float rinv = rsqrtf(s2 / (float)dim + eps);
+    for (int e = 0; e < dim; ++e) {
+        float v = (f[e] - mean) * rinv * bf2f(w[e]) + (b ? bf2f(b[e]) : 0.f);
+        if (act == 1) { const float t = bf2f(f2bf(v)); v = 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); }
+        y[row * ldy + e] = f2bf(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ rotary
 // thread = (token, group of HG heads, 8-wide chunk of the first half): the cos / sin values (4 x 8 floats, the bulk of this kernel's
 // load instructions when fetched per head) are read once and reused for the HG heads; each head rotates the chunk and its partner
@@ -394,8 +415,14 @@ extern "C" int rga3_rmsnorm_fwd(const void* x, const void* add, const void* weig
 extern "C" int rga3_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int64_t dim,
                                   int64_t ldx, int64_t ldy, float eps, int act, void* stream) {
     RGA3_CHECK_ARG(x && weight && y, "layernorm: null pointer");
-    RGA3_CHECK_ARG(rows > 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && dim <= 8192, "layernorm: rows=%ld dim=%ld", (long)rows, (long)dim);
     hipStream_t st = (hipStream_t)stream;
+    if (rows > 0 && dim > 0 && dim <= 16 && (dim % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0)) {
+        hipLaunchKernelGGL(layernorm_tiny_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, st, (const unsigned short*)x, (const unsigned short*)weight,
+                           (const unsigned short*)bias, (unsigned short*)y, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+        RGA3_CHECK_LAUNCH("layernorm_tiny_kernel");
+        return 0;
+    }
+    RGA3_CHECK_ARG(rows > 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && dim <= 8192, "layernorm: rows=%ld dim=%ld", (long)rows, (long)dim);
     dim3 grid((unsigned)cdiv(rows, 4));
     const unsigned short *xp = (const unsigned short*)x, *wp = (const unsigned short*)weight, *bp = (const unsigned short*)bias;
     unsigned short* yp = (unsigned short*)y;

@@ -621,14 +621,7 @@ class MemoryEncoder(nn.Module):
             else:
                 x = ops.conv3x3s2(x, conv.weight, conv.bias, Fn, H, H)
             H //= 2
-            if x.shape[1] % 8 == 0:
-                x = norm(x, act="gelu")
-            else:  # 4-channel stage: LayerNorm2d + GELU over 4 values per pixel (row kernel needs dim % 8 == 0)
-                xf = x.float()
-                u = xf.mean(1, keepdim=True)
-                s = (xf - u).pow(2).mean(1, keepdim=True)
-                xf = (xf - u) / torch.sqrt(s + norm.eps) * norm.weight.float() + norm.bias.float()
-                x = F.gelu(xf.to(x.dtype).float()).to(x.dtype)
+            x = norm(x, act="gelu")   # incl. the 4-channel stage (narrow-row LayerNorm kernel)
         last = enc[3 * self.mask_downsampler.n_down]
         m = ops.gemm(x, last.as_linear(), last.bias)
         y = ops.gemm(pix_tokens, self.pix_feat_proj.as_linear(), self.pix_feat_proj.bias, residual=m)

@@ -130,3 +130,17 @@ def test_bce_dice_sums(dev):
     p = torch.sigmoid(x)
     ref = torch.stack([bce, (p * t).flatten(1).sum(1), p.flatten(1).sum(1), t.flatten(1).sum(1)], 1)
     assert ((out - ref).abs() / ref.abs().clamp_min(1)).max().item() < 1e-4
+
+
+def test_layernorm_narrow_rows(dev):
+    """LayerNorm2d(+GELU) on 4 / 12 / 6 channels (memory encoder's first mask-downsampler stage, reference model/sam2.py:611-643)."""
+    from rga3.hip import ops
+
+    for dim in (4, 12, 6):
+        x = rnd((1000, dim), dev, seed=dim)
+        w, b = rnd((dim,), dev, 0.5, seed=dim + 1), rnd((dim,), dev, 0.2, seed=dim + 2)
+        xf = x.float().cpu()
+        ref = F.layer_norm(xf, (dim,), w.float().cpu(), b.float().cpu(), 1e-6)
+        assert rel(ops.layernorm(x, w, b, 1e-6), ref) < 6e-3, dim
+        refg = F.gelu(ref.to(torch.bfloat16).float())
+        assert rel(ops.layernorm(x, w, b, 1e-6, act="gelu"), refg) < 8e-3, dim
