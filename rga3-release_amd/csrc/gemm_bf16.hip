@@ -579,6 +579,7 @@ struct SkArgs {
     int P_sk;         // workgroups that take part in the stream-K tail
     int t_dp;         // tiles [0, t_dp) are data-parallel (t_dp % P == 0 or sk_tiles == 0)
     int sk_tiles;     // tiles [t_dp, t_dp + sk_tiles) are split
+    int all_partial;  // split-K mode (tile 25): every slice only writes its slab; gemm_slab_reduce_kernel sums them afterwards
 };
 
 template <int ACT, bool OUT_F32>
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             --i;
         }
         if (i < n_dp) { tile = w + i * sk.P; kb = 0; ke = nk; kind = 0; return; }
-        tile = ow_tile; kb = ow_kb; ke = nk; kind = (ow_kb > 0) ? 2 : 0;
+        tile = ow_tile; kb = ow_kb; ke = nk; kind = sk.all_partial ? 1 : ((ow_kb > 0) ? 2 : 0);
     };
 
     unsigned soff[4][2];
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) {
+            if (tid == 0 && !sk.all_partial) {   // split-K mode hands over at the kernel boundary instead
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(sk.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -854,6 +855,46 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
         if constexpr (!PREFETCH) {
             if (has_next) prologue_issue(kb, ke);
         }
+    }
+}
+
+// Split-K for few-tile / huge-K products (tile 25; weight gradients dW = dY^T X over 10^6 tokens are ONE 256x256 tile with K = 16 384
+// K-tiles: 1.9 ms on one CU): every tile is cut into S equal K-slices, one workgroup each (gemm_nt_sk_kernel with all_partial), and this
+// kernel adds the S slabs of a tile in slice order and writes C (bias optional, bf16 or f32).  Thread = one accumulator quad.
+struct SlabReduceArgs {
+    const float* slabs;
+    void* C;
+    const unsigned short* bias;
+    int M, N, ntm, ntn, group_m, S, out_f32;
+    long ldc;
+};
+
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(SlabReduceArgs p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // ((tile * 8 + wave) * 32 + quad) * 64 + lane
+    const long total = (long)p.ntm * p.ntn * 8 * 32 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), quad = (int)((idx >> 6) & 31), wave = (int)((idx >> 11) & 7);
+    const unsigned t = (unsigned)(idx >> 14);
+    const unsigned GROUP_M = (unsigned)p.group_m;
+    const unsigned per_group = GROUP_M * p.ntn;
+    const unsigned group = t / per_group;
+    const unsigned first_m = group * GROUP_M;
+    const unsigned gsz = min((unsigned)p.ntm - first_m, GROUP_M);
+    const int m0 = (int)(first_m + (t % per_group) % gsz) * 256, n0 = (int)((t % per_group) / gsz) * 256;
+    const float* src = p.slabs + (((size_t)t * p.S) * (512 * 32) + (size_t)wave * (32 * 64) + (size_t)quad * 64 + lane) * 4;
+    f32x4 acc = *(const f32x4*)src;
+    for (int s = 1; s < p.S; ++s) acc += *(const f32x4*)(src + (size_t)s * (512 * 32) * 4);
+    const int i = quad >> 2, j = quad & 3, g = lane >> 4, c = lane & 15;
+    const int row = m0 + (wave >> 2) * 128 + i * 16 + c;
+    const int col = n0 + (wave & 3) * 64 + j * 16 + 4 * g;
+    if (row >= p.M) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (col + r >= p.N) break;
+        float v = acc[r];
+        if (p.bias) v += bf2f(p.bias[col + r]);
+        if (p.out_f32) ((float*)p.C)[(long)row * p.ldc + col + r] = v;
+        else ((unsigned short*)p.C)[(long)row * p.ldc + col + r] = f2bf(v);
     }
 }
 
@@ -931,6 +972,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.t_dp = T;
         sk.sk_tiles = 0;
         sk.P_sk = 0;
+        sk.all_partial = 0;
     } else {
         // slices per split tile <= 3 (owner + two contributors: the kernel's accumulator init reads at most two slabs)
         // <=> run length >= nk / 2 <=> P_sk <= 2 * sk_tiles; and no slice shorter than MIN_SEG K-iterations
@@ -944,6 +986,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         if (want > ws.P) want = ws.P;
         if (want < rem) want = rem;
         sk.P_sk = (int)want;
+        sk.all_partial = 0;
     }
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_sk_kernel<ACT, OUT_F32>;
@@ -955,6 +998,44 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)sk.P), dim3(512), LDS, st, a, sk);
     RGA3_CHECK_LAUNCH("gemm_nt_sk_kernel");
+    return 0;
+}
+
+// tile 25: falls back to the persistent kernel when the product does not have few tiles and a long K
+template <int ACT, bool OUT_F32>
+static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
+    a.ntm = (int)cdiv(a.M, 256);
+    a.ntn = (int)cdiv(a.N, 256);
+    a.group_m = pick_group_m(a.ntm, 256);
+    const int T = a.ntm * a.ntn;
+    const int nk = (int)cdiv(a.K, 64);
+    SkWorkspace ws;
+    if (ACT != ACT_NONE || a.res || a.colscale || a.K % 64 != 0) return launch_sk<ACT, OUT_F32>(a0, false, st);
+    int rc = sk_workspace(st, ws);
+    if (rc == 1) return launch_pp<ACT, OUT_F32>(a0, st);
+    if (rc) return rc;
+    int S = ws.P / T;
+    if (S > nk / 4) S = nk / 4;          // at least 4 K-tiles per slice
+    if (S < 2) return launch_sk<ACT, OUT_F32>(a0, false, st);
+    SkArgs sk;
+    sk.slabs = ws.slabs; sk.flags = ws.flags; sk.tmo = ws.flags + ws.P;
+    sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1;
+    constexpr int LDS = 2 * 4 * 128 * 128;
+    auto kern = gemm_nt_sk_kernel<ACT_NONE, false>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)sk.P), dim3(512), LDS, st, a, sk);
+    RGA3_CHECK_LAUNCH("gemm_nt_sk_kernel<split-K>");
+    SlabReduceArgs r;
+    r.slabs = ws.slabs; r.C = a.C; r.bias = a.bias; r.M = a.M; r.N = a.N; r.ntm = a.ntm; r.ntn = a.ntn; r.group_m = a.group_m; r.S = S;
+    r.out_f32 = OUT_F32 ? 1 : 0; r.ldc = a.ldc;
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)cdiv((long)T * 8 * 32 * 64, 256)), dim3(256), 0, st, r);
+    RGA3_CHECK_LAUNCH("gemm_slab_reduce_kernel");
     return 0;
 }
 
@@ -1030,6 +1111,7 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 20: return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
         case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
+        case 25: return launch_splitk<ACT, OUT_F32>(a, st);
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);
     }
 }
@@ -1070,7 +1152,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 12) || (tile >= 20 && tile <= 22), "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 12) || (tile >= 20 && tile <= 22) || tile == 25, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;

@@ -74,7 +74,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
                       out.stride(0), ldr, ACT[act], odt, t, _stream()), "gemm_bf16")
 
     if tile == -1 and M * N * K >= (1 << 24) and not (residual is not None and residual.data_ptr() == out.data_ptr()):
-        tile = _tuner.pick(_tuner.key_of(M, N, K, act, odt, bias is not None, residual is not None), run)
+        # few output tiles over a very long K (weight gradients dW = dY^T X): also try the split-K form
+        extra = (25,) if (M * N <= (1 << 20) and K >= 4096 and act == "none" and residual is None and colscale is None) else ()
+        tile = _tuner.pick(_tuner.key_of(M, N, K, act, odt, bias is not None, residual is not None), run, extra)
     run(tile)
     return out
 

@@ -19,7 +19,7 @@ def key_of(M, N, K, act, out_f32, has_bias, has_res):
     return ((M + 255) // 256, N, K, act, out_f32, has_bias, has_res)
 
 
-def pick(key, run):
+def pick(key, run, extra=()):
     """run(tile) launches the GEMM once with that tiling.  Returns the cached / measured best tile id."""
     if not _enabled:
         return -1
@@ -30,7 +30,7 @@ def pick(key, run):
         return -1
     best, best_ms = -1, float("inf")
     _times[key] = {}
-    for tile in CANDIDATES:
+    for tile in tuple(CANDIDATES) + tuple(extra):
         run(tile)  # warm (also sets the func attribute for large dynamic LDS)
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record()

@@ -256,3 +256,20 @@ def test_fp8_quant_and_gemm(dev, M, N, K):
     plain = ops.gemm_fp8(qa, sa, qw, sw)
     full = R.linear_ref(a.cpu(), w.cpu())
     assert _rel_l2(plain, full) < 6e-2           # two e4m3 operands: ~2^-4 relative per element, averaged over K
+
+
+@pytest.mark.parametrize("M,N,K,f32", [(256, 256, 65536, False), (32, 256, 131072, True), (300, 520, 16384, False), (64, 64, 4096, False), (700, 256, 2048, False)])
+def test_gemm_split_k_small_outputs(dev, M, N, K, f32):
+    """Tile 25 (few tiles, huge K: the weight-gradient products): slices summed in f32 slabs by the reduce kernel; with bias and f32 output."""
+    from rga3.hip import ops
+
+    a, w = _rand((M, K), dev, 0.1, seed=31), _rand((N, K), dev, 0.1, seed=32)
+    bias = _rand((N,), dev, 0.5, seed=33)
+    odt = torch.float32 if f32 else torch.bfloat16
+    out = ops.gemm(a, w, bias=bias, out_dtype=odt, tile=25)
+    again = ops.gemm(a, w, bias=bias, out_dtype=odt, tile=25)
+    assert torch.equal(out, again)
+    ref = (a.float().cpu().double() @ w.float().cpu().double().t() + bias.float().cpu().double()).float()
+    if not f32:
+        ref = ref.to(torch.bfloat16).float()
+    assert _rel_l2(out, ref) < (1e-4 if f32 else 5e-3), (M, N, K)
