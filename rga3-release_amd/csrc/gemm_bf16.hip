@@ -1080,8 +1080,10 @@ static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
 }
 
 // tile choice: fill the 256 CUs.  score = useful fraction of the last wave of tiles x a per-config prior.
-static int pick_tile(int M, int N, int forced) {
+static int pick_tile(int M, int N, int K, bool plain, int forced) {
     if (forced >= 0) return forced;
+    // a handful of output tiles over a very long K (per-frame mask products, weight gradients): split K over the CUs
+    if (plain && K >= 8192 && cdiv(M, 256) * cdiv(N, 256) <= 4 && K % 64 == 0) return 25;
     struct Cfg { int bm, bn, slots; double prior; };
     // slots = resident workgroups per CU (LDS-limited)
     static const Cfg cfgs[3] = {{256, 256, 1, 1.00}, {256, 128, 1, 0.90}, {128, 128, 2, 0.78}};
@@ -1166,7 +1168,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     static const int dbg_flags = [] { const char* e = getenv("RGA3_GEMM_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg_flags;
     hipStream_t st = (hipStream_t)stream;
-    int tl = pick_tile((int)M, (int)N, tile);
+    int tl = pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
     if (out_dtype == RGA3_F32) return launch_act<ACT_NONE, true>(a, tl, st);
     switch (act) {
         case ACT_NONE: return launch_act<ACT_NONE, false>(a, tl, st);

@@ -17,3 +17,7 @@ for it in range(4):
     for p in model.parameters():
         p.grad = None
 print(json.dumps({"forward_ms": round((t1 - t0) * 1e3, 1), "mask_path_backward_ms": round((t2 - t1) * 1e3, 1)}))
+from rga3.hip import tuner
+for k, v in tuner.timings().items():
+    if k[0] <= 1 and k[2] >= 4096:
+        print("TUNE", k, tuner.table().get(k), {t: round(ms * 1e3, 1) for t, ms in v.items()})
