@@ -51,6 +51,7 @@ int rga3_last_error(char* buf, size_t n);
  * the same bits except 22, whose stream-K split changes the f32 summation order of the split tiles, reproducibly):
  *   20 = 256x256 ping-pong, one tile per workgroup;  21 = the same, persistent (one workgroup per CU);
  *   22 = persistent + stream-K tail (keeps a per-stream f32 workspace of 256 KiB per CU inside the library);
+ *   25 = split-K for few output tiles over a very long K (same workspace; falls back to 21 when it does not apply);
  *   11 / 12 / 3 / 4 = single-phase 256x128 / 128x128 / 128x256 / 128x320;  10 = single-phase 256x256 (first generation, kept for A/B). */
 int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, int out_dtype, int tile,

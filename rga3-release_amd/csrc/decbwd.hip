@@ -115,6 +115,82 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     }
 }
 
+// Narrow rows (LayerNorm2d on 16..128 channels over 10^5..10^6 pixels: the mask decoder's upscaling path, reference model/sam2.py:1976-1986):
+// G = dim / 8 lanes per row, 64 / G rows per wave pass; row statistics by xor-shuffles inside the lane group; dw / db accumulate per lane
+// over the rows it sees, are folded across the groups of the wave by shuffles and leave by one atomic per (wave, column).  The
+// wave-per-row form above keeps 4 of 64 lanes busy at 32 channels (3.2 ms for 2^20 rows).
+template <int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                                   const unsigned short* __restrict__ dy, unsigned short* __restrict__ dx,
+                                                                   float* __restrict__ dw, float* __restrict__ db, long rows, float eps, int rows_per_wg) {
+    constexpr int DIM = G * 8, RPW = 64 / G;   // rows per wave pass
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ch = lane % G, sub = lane / G;
+    float fw[8], aw[8], ab[8];
+    u8_(*(const u32x4*)(w + ch * 8), fw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { aw[e] = 0.f; ab[e] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_wg;
+    const long r1 = min(rows, r0 + rows_per_wg);
+    for (long base = r0 + wv * RPW; base < r1; base += 4 * RPW) {
+        const long row = base + sub;
+        const bool ok = row < r1;
+        float fx[8], fd[8];
+        u32x4 vx = {0u, 0u, 0u, 0u}, vd = {0u, 0u, 0u, 0u};
+        if (ok) {
+            vx = *(const u32x4*)(x + row * DIM + ch * 8);
+            vd = *(const u32x4*)(dy + row * DIM + ch * 8);
+        }
+        u8_(vx, fx);
+        u8_(vd, fd);
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += fx[e];
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mean = s1 / (float)DIM;
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = fx[e] - mean; s2 += d * d; }
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) s2 += __shfl_xor(s2, o, 64);
+        const float r = rsqrtf(s2 / (float)DIM + eps);
+        float sg = 0.f, sgx = 0.f, xh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xh[e] = (fx[e] - mean) * r;
+            const float g = fd[e] * fw[e];
+            sg += g;
+            sgx += g * xh[e];
+            if (ok) { aw[e] += fd[e] * xh[e]; ab[e] += fd[e]; }
+        }
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
+        sg /= (float)DIM;
+        sgx /= (float)DIM;
+        if (ok) {
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = r * (fd[e] * fw[e] - sg - xh[e] * sgx);
+            *(u32x4*)(dx + row * DIM + ch * 8) = p8_(o8);
+        }
+    }
+    if (dw) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) { aw[e] += __shfl_xor(aw[e], o, 64); ab[e] += __shfl_xor(ab[e], o, 64); }
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(dw + ch * 8 + e, aw[e]);
+                atomicAdd(db + ch * 8 + e, ab[e]);
+            }
+        }
+    }
+}
+
 // out[c] += sum_r x[r, c]  (bf16 in, f32 atomics out); workgroup = 256 columns x rows_per_wg rows
 __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out, long rows, long cols, long ld,
                                                      int rows_per_wg) {
@@ -215,9 +291,21 @@ extern "C" int rga3_layernorm_bwd(const void* x, const void* weight, const void*
                                   float eps, void* stream) {
     RGA3_CHECK_ARG(x && weight && dy && dx && rows > 0 && dim > 0 && dim % 8 == 0 && dim <= 2048, "layernorm_bwd: bad args (dim <= 2048)");
     RGA3_CHECK_ARG((dweight == nullptr) == (dbias == nullptr), "layernorm_bwd: dweight and dbias go together");
+    hipStream_t st = (hipStream_t)stream;
+    if (dim == 16 || dim == 32 || dim == 64 || dim == 128) {   // narrow rows: several rows per wave
+        const int rpn = 1024;
+        dim3 gn((unsigned)cdiv(rows, rpn));
+#define RGA3_LNB(G) hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<G>, gn, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (us)dx, dweight, dbias, (long)rows, eps, rpn)
+        if (dim == 16) RGA3_LNB(2);
+        else if (dim == 32) RGA3_LNB(4);
+        else if (dim == 64) RGA3_LNB(8);
+        else RGA3_LNB(16);
+#undef RGA3_LNB
+        RGA3_CHECK_LAUNCH("layernorm_bwd_narrow");
+        return 0;
+    }
     const int rpw = 64;
     dim3 grid((unsigned)cdiv(rows, rpw));
-    hipStream_t st = (hipStream_t)stream;
     if (dim <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (us)dx, dweight, dbias, (long)rows, (int)dim, eps, rpw);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(256), 0, st, (cus)x, (cus)weight, (cus)dy, (us)dx, dweight, dbias, (long)rows, (int)dim, eps, rpw);
     RGA3_CHECK_LAUNCH("layernorm_bwd");

@@ -144,3 +144,18 @@ def test_layernorm_narrow_rows(dev):
         assert rel(ops.layernorm(x, w, b, 1e-6), ref) < 6e-3, dim
         refg = F.gelu(ref.to(torch.bfloat16).float())
         assert rel(ops.layernorm(x, w, b, 1e-6, act="gelu"), refg) < 8e-3, dim
+
+
+@pytest.mark.parametrize("rows,dim", [(5000, 32), (4097, 64), (1000, 16), (3000, 128), (700, 256)])
+def test_layernorm_backward(dev, rows, dim):
+    """dx, dw, db of LayerNorm vs fp32 autograd (narrow-row kernel for 16..128 channels, wave-per-row above)."""
+    from rga3.hip import ops
+
+    x, dy = rnd((rows, dim), dev, seed=1), rnd((rows, dim), dev, seed=2)
+    w = (rnd((dim,), dev, 0.3, seed=3).float() + 1).to(torch.bfloat16)
+    dx, dw, db = ops.layernorm_bwd(x, w, dy, 1e-6)
+    xr = x.float().cpu().requires_grad_(True)
+    wr = w.float().cpu().requires_grad_(True)
+    br = torch.zeros(dim, requires_grad=True)
+    F.layer_norm(xr, (dim,), wr, br, 1e-6).backward(dy.float().cpu())
+    assert rel(dx, xr.grad) < 8e-3 and rel(dw, wr.grad) < 5e-3 and rel(db, br.grad) < 5e-3, (rows, dim)
