@@ -50,12 +50,16 @@ int rga3_last_error(char* buf, size_t n);
  * K, lda, ldw must be multiples of 8 (16-byte rows); tile = -1 lets the library choose.  Explicit tilings (all give
  * the same bits except 22, whose stream-K split changes the f32 summation order of the split tiles, reproducibly):
  *   20 = 256x256 ping-pong, one tile per workgroup;  21 = the same, persistent (one workgroup per CU);
- *   22 = persistent + stream-K tail (keeps a per-stream f32 workspace of 256 KiB per CU inside the library);
+ *   22 = persistent + stream-K tail (needs the caller workspace below);
  *   25 = split-K for few output tiles over a very long K (same workspace; falls back to 21 when it does not apply);
  *   11 / 12 / 3 / 4 = single-phase 256x128 / 128x128 / 128x256 / 128x320;  10 = single-phase 256x256 (first generation, kept for A/B). */
 int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, int out_dtype, int tile,
-                   void* stream);
+                   void* workspace, int64_t workspace_bytes, void* stream);
+/* bytes of caller workspace tiles 22 / 25 want on the current device (4 KiB of flags + 256 KiB per CU; 0 on error).  The workspace is
+ * zeroed ONCE by the caller and then kept for the calls of one stream (the kernels leave the flag words zero again); without it (NULL / too
+ * small) those tilings run as 21 / 20. */
+int64_t rga3_gemm_workspace_bytes(void);
 
 /* Variable-length fused attention forward (online softmax, fp32 statistics), bf16 in/out.
  *   q: [total_q, Hq, D], k/v: [total_k, Hkv, D] addressed through (token, head) element strides so the
@@ -161,8 +165,9 @@ int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
                          void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
                          int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale, int causal,
                          float* dkv_ws, int64_t total_k, void* stream);
-/* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up so far (expected 0; < 0 = HIP error) */
-int rga3_gemm_stream_k_timeouts(void);
+/* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up in launches that used this workspace (expected 0;
+ * < 0 = error); synchronises the device */
+int rga3_gemm_stream_k_timeouts(const void* workspace);
 /* dx = d rmsnorm(x; weight)/dx . dy (+ add): backward of HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:74-79) w.r.t. x */
 int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim, float eps,
                      void* stream);

@@ -19,8 +19,6 @@
 //  * 1-D grid with a bijective XCD remap + grouped tile order so neighbouring tiles share an L2.
 #include "common.h"
 #include <cstdlib>
-#include <map>
-#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -41,6 +39,8 @@ struct GemmArgs {
     long lda, ldw, ldc, ldr;
     int ntm, ntn;
     int group_m;  // tile rows per group of the tile order (see launchers)
+    void* ws;     // caller workspace for the stream-K / split-K tilings (may be null)
+    long ws_bytes;
     int dbg;  // RGA3_GEMM_DBG (timing ablations only): bit0 = skip the global stores, bit1 = skip the whole epilogue
 };
 
@@ -912,37 +912,33 @@ static int pick_group_m(int ntm, int tile_m) {
 
 struct SkWorkspace { float* slabs; unsigned* flags; int P; };
 
-// one workspace per (device, stream): kernels on a stream serialize; different streams must not share slabs, and the null stream
-// handle is the same value on every device of a multi-GPU process
-static std::mutex g_sk_mu;
-static std::map<std::pair<int, hipStream_t>, SkWorkspace> g_sk_table;
+// The stream-K / split-K tilings need f32 slabs (256 KiB per CU) and one flag word per CU.  The CALLER owns that memory (SURVEY.md 8(b):
+// the library allocates nothing): rga3_gemm_bf16 takes it as (workspace, workspace_bytes); layout = [4 KiB of flags, zeroed once by the
+// caller and kept between calls on the same stream][slabs].  Without a large enough workspace tiles 22 / 25 run as 21 / 20.
+constexpr size_t kSkFlagBytes = 4096;
 
-static int sk_workspace(hipStream_t st, SkWorkspace& out) {
-    auto& table = g_sk_table;
-    std::lock_guard<std::mutex> lk(g_sk_mu);
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return fail(-(int)e, "gemm: hipGetDevice: %s", hipGetErrorString(e));
-    const auto key = std::make_pair(dev, st);
-    auto f = table.find(key);
-    if (f != table.end()) { out = f->second; return 0; }
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 1;  // cannot allocate while capturing
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess || cus <= 0) return fail(-(int)e, "gemm: cannot query CU count: %s", hipGetErrorString(e));
-    SkWorkspace ws;
-    ws.P = cus;
-    const size_t slab_bytes = (size_t)cus * 512 * 32 * 16;
-    const size_t flag_bytes = ((size_t)(cus + 4) * 4 + 255) / 256 * 256;
-    char* base = nullptr;
-    e = hipMalloc((void**)&base, flag_bytes + slab_bytes);
-    if (e != hipSuccess) return fail(-(int)e, "gemm: stream-K workspace hipMalloc(%zu): %s", flag_bytes + slab_bytes, hipGetErrorString(e));
-    e = hipMemset(base, 0, flag_bytes);
-    if (e != hipSuccess) return fail(-(int)e, "gemm: stream-K workspace memset: %s", hipGetErrorString(e));
-    ws.flags = (unsigned*)base;
-    ws.slabs = (float*)(base + flag_bytes);
-    table[key] = ws;
-    out = ws;
+static int g_cu_count[16] = {0};
+
+static int cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (g_cu_count[dev] == 0) {   // read-only per-device cache, filled on first use
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+        g_cu_count[dev] = cus;
+    }
+    return g_cu_count[dev];
+}
+
+// 0: workspace usable (out filled); 1: not usable (caller falls back to a tiling without workspace)
+static int sk_workspace(void* ws, int64_t ws_bytes, SkWorkspace& out) {
+    const int cus = cu_count();
+    if (!ws || cus <= 0 || cus * 4 + 16 > (int)kSkFlagBytes) return 1;
+    const size_t need = kSkFlagBytes + (size_t)cus * 512 * 32 * 16;
+    if ((size_t)ws_bytes < need || (((uintptr_t)ws) & 15)) return 1;
+    out.P = cus;
+    out.flags = (unsigned*)ws;
+    out.slabs = (float*)((char*)ws + kSkFlagBytes);
     return 0;
 }
 
@@ -951,21 +947,24 @@ static int launch_pp(const GemmArgs& a0, hipStream_t st);
 
 template <int ACT, bool OUT_F32>
 static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
+    void* ws_ptr = a0.ws; const int64_t ws_bytes = a0.ws_bytes;
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.group_m = pick_group_m(a.ntm, 256);
     SkWorkspace ws;
     if (a.K % 64 != 0) return launch_pp<ACT, OUT_F32>(a0, st);  // ragged K: zero-source tail lives in the one-tile kernel
-    int rc = sk_workspace(st, ws);
-    if (rc == 1) return launch_pp<ACT, OUT_F32>(a0, st);  // graph capture before the first eager call on this stream
-    if (rc) return rc;
+    ws.P = cu_count();
+    ws.slabs = nullptr;
+    ws.flags = nullptr;
+    if (ws.P <= 0) return launch_pp<ACT, OUT_F32>(a0, st);
+    if (split && sk_workspace(ws_ptr, ws_bytes, ws)) split = false;   // no (or too small a) caller workspace: persistent without the stream-K tail
     const int T = a.ntm * a.ntn;
     const int nk = (int)cdiv(a.K, 64);
     SkArgs sk;
     sk.slabs = ws.slabs;
     sk.flags = ws.flags;
-    sk.tmo = ws.flags + ws.P;
+    sk.tmo = ws.flags ? ws.flags + ws.P : nullptr;
     const int rem = T % ws.P;
     if (!split || rem == 0) {
         sk.P = T < ws.P ? T : ws.P;
@@ -1012,9 +1011,7 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     const int nk = (int)cdiv(a.K, 64);
     SkWorkspace ws;
     if (ACT != ACT_NONE || a.res || a.colscale || a.K % 64 != 0) return launch_sk<ACT, OUT_F32>(a0, false, st);
-    int rc = sk_workspace(st, ws);
-    if (rc == 1) return launch_pp<ACT, OUT_F32>(a0, st);
-    if (rc) return rc;
+    if (sk_workspace(a0.ws, a0.ws_bytes, ws)) return launch_pp<ACT, OUT_F32>(a0, st);
     int S = ws.P / T;
     if (S > nk / 4) S = nk / 4;          // at least 4 K-tiles per slice
     if (S < 2) return launch_sk<ACT, OUT_F32>(a0, false, st);
@@ -1122,29 +1119,24 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
 
 using namespace rga3;
 
-// Diagnostic: number of bounded spins that gave up in stream-K launches so far (0 unless a contributor workgroup never ran).
-// Synchronises the devices that own a workspace.
-extern "C" int rga3_gemm_stream_k_timeouts(void) {
-    std::lock_guard<std::mutex> lk(g_sk_mu);
-    int cur = 0;
-    if (hipGetDevice(&cur) != hipSuccess) return -1;
-    long total = 0;
-    for (auto& kv : g_sk_table) {
-        unsigned v = 0;
-        if (hipSetDevice(kv.first.first) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-            hipMemcpy(&v, kv.second.flags + kv.second.P, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
-            total = -1;
-            break;
-        }
-        total += v;
-    }
-    (void)hipSetDevice(cur);
-    return (int)(total > 0x7fffffff ? 0x7fffffff : total);
+// Bytes of workspace rga3_gemm_bf16 wants on the current device for tiles 22 / 25 (0 on error).
+extern "C" int64_t rga3_gemm_workspace_bytes(void) {
+    const int cus = cu_count();
+    return cus > 0 ? (int64_t)(kSkFlagBytes + (size_t)cus * 512 * 32 * 16) : 0;
+}
+
+// Diagnostic: number of bounded spins that gave up in stream-K launches that used this workspace (expected 0).  Synchronises the device.
+extern "C" int rga3_gemm_stream_k_timeouts(const void* workspace) {
+    SkWorkspace ws;
+    if (sk_workspace((void*)workspace, (int64_t)1 << 40, ws)) return -1;
+    unsigned v = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, ws.flags + ws.P, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
 }
 
 extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
                               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
-                              int act, int out_dtype, int tile, void* stream) {
+                              int act, int out_dtype, int tile, void* workspace, int64_t workspace_bytes, void* stream) {
     RGA3_CHECK_ARG(A && W && C, "gemm: null pointer");
     RGA3_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     RGA3_CHECK_ARG(K % 8 == 0, "gemm: K=%ld must be a multiple of 8 (16-byte staging chunks)", (long)K);
@@ -1165,6 +1157,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.colscale = (const unsigned short*)colscale;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.ws = workspace; a.ws_bytes = workspace_bytes;
     static const int dbg_flags = [] { const char* e = getenv("RGA3_GEMM_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg_flags;
     hipStream_t st = (hipStream_t)stream;

@@ -18,7 +18,8 @@ _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "rga3_version": [],
     "rga3_last_error": [C.c_char_p, _sz],
-    "rga3_gemm_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _p],
+    "rga3_gemm_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _p, _i64, _p],
+    "rga3_gemm_workspace_bytes": [],
     "rga3_attn_varlen_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
                              _i64, _i64, _f, _i, _i, _p, _i64, _i, _p],
     "rga3_rmsnorm_fwd": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p],
@@ -41,7 +42,7 @@ SIGNATURES = {
     "rga3_pixel_shuffle2x": [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "rga3_bce_dice_sums": [_p, _p, _p, _i64, _i64, _p],
     "rga3_attn_varlen_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _p, _f, _i, _p, _i64, _p],
-    "rga3_gemm_stream_k_timeouts": [],
+    "rga3_gemm_stream_k_timeouts": [_p],
     "rga3_quant_fp8_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "rga3_gemm_fp8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "rga3_im2col3x3s2": [_p, _p, _i64, _i, _i, _i, _p],
@@ -91,7 +92,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name == "rga3_gemm_workspace_bytes" else C.c_int
     _lib = lib
     return lib
 

@@ -38,6 +38,33 @@ def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:
     return out
 
 
+_gemm_ws = {}
+
+
+def gemm_workspace(device) -> torch.Tensor:
+    """The caller-owned workspace of the stream-K / split-K GEMM tilings for (device, current stream): allocated from PyTorch's caching
+    allocator on first use, zeroed once (the flag words; the kernels leave them zero), then kept for the life of the process."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    t = _gemm_ws.get(key)
+    if t is None:
+        with torch.cuda.device(device):
+            n = int(_lib.load().rga3_gemm_workspace_bytes())
+        if n <= 0:
+            raise _lib.Rga3Error("rga3_gemm_workspace_bytes failed: " + _lib.last_error())
+        t = _gemm_ws[key] = torch.zeros(n, dtype=torch.uint8, device=device)
+    return t
+
+
+def gemm_stream_k_timeouts(device=None) -> int:
+    """Sum of the bounded-spin give-ups recorded in this process's GEMM workspaces (diagnostic; expected 0)."""
+    tot = 0
+    for (dev, _), t in _gemm_ws.items():
+        if device is None or dev == (device.index if device.index is not None else torch.cuda.current_device()):
+            with torch.cuda.device(dev):
+                tot += int(_lib.load().rga3_gemm_stream_k_timeouts(t.data_ptr()))
+    return tot
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = "none", out_dtype=torch.bfloat16,
          out=None, tile: int = -1, colscale=None) -> torch.Tensor:
     """out = residual + colscale * act(a @ w.T + bias).  a [M,K], w [N,K] (nn.Linear layout), bf16."""
@@ -68,10 +95,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
         assert colscale.dtype == torch.bfloat16 and colscale.numel() == n_out and colscale.is_contiguous()
     fn = _lib.load().rga3_gemm_bf16
     odt = BF16 if out_dtype == torch.bfloat16 else F32
+    ws = gemm_workspace(a.device)
 
     def run(t):
         _lib.check(fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(colscale), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
-                      out.stride(0), ldr, ACT[act], odt, t, _stream()), "gemm_bf16")
+                      out.stride(0), ldr, ACT[act], odt, t, ws.data_ptr(), ws.numel(), _stream()), "gemm_bf16")
 
     if tile == -1 and M * N * K >= (1 << 24) and not (residual is not None and residual.data_ptr() == out.data_ptr()):
         # few output tiles over a very long K (weight gradients dW = dY^T X): also try the split-K form

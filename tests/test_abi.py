@@ -10,7 +10,7 @@ def header_decls():
     src = open(os.path.join(ROOT, "include", "rga3_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\bint\s+(rga3_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\bint(?:64_t)?\s+(rga3_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         decls[m.group(1)] = args
     return decls

@@ -58,7 +58,7 @@ def test_gemm_stream_k_split_shapes(dev):
             o2 = ops.gemm(a, w, tile=tl)
             assert torch.equal(o1, o2), (M, N, K, tl)
             assert _rel_l2(o1, ref.float().cpu()) < 1e-3, (M, N, K, tl)
-    assert lib.load().rga3_gemm_stream_k_timeouts() == 0
+    assert ops.gemm_stream_k_timeouts() == 0
 
 
 @pytest.mark.parametrize("act", ["none", "gelu", "relu", "swiglu"])
