@@ -220,6 +220,19 @@ int rga3_sam_preprocess_u8(const void* frames, int64_t T, int H, int W, int out_
                            int ksize_h, const int32_t* bv, const int32_t* kv, int ksize_v, void* tmp, void* dst_u8, void* dst_bf16,
                            const float* mean3, const float* std3, void* stream);
 
+/* ---- Qwen-side input pipeline: replaces qwen_vl_utils.process_vision_info (list-of-frames branch: PIL bicubic to the
+ * smart_resize size; reference call sites evaluation/mevis_val_u/inference_mevis.py:196-216, utils/dataset.py:41-87) + the HF video processor
+ * (rescale, CLIP-normalise, patchify; installed transformers models/qwen2_vl/video_processing_qwen2_vl.py:236-336).  The resize is
+ * rga3_sam_preprocess_u8 with dst_u8; the tail is a byte gather through a 3x256 table.
+ * rga3_qwen_norm_lut is HOST-ONLY: lut768[c*256+b] = normalised value of byte b in channel c; fused = 0: transformers 4.49 order
+ * (float32(b/255.) then (x-mean)/std), fused = 1: 5.x fast path ((b - 255*mean) / (255*std)). */
+int rga3_qwen_norm_lut(const float* mean3, const float* std3, int fused, float* lut768);
+/* frames u8 [T,h,w,3] -> out [ceil(T/tpatch)*(h/patch)*(w/patch), 3*tpatch*patch*patch] bf16 (out_dtype 0) / fp32 (1); rows ordered
+ * (t, h/(patch*merge), w/(patch*merge), merge, merge), columns (C, tpatch, patch, patch); the last frame repeats if tpatch does not divide T;
+ * lut768: device copy of the table above. */
+int rga3_qwen_patchify_u8(const void* frames, int64_t T, int h, int w, const float* lut768, void* out, int out_dtype, int patch, int tpatch,
+                          int merge, void* stream);
+
 /* ---- FP8 (OCP e4m3) path for the frozen-weight GEMMs of the LoRA fine-tune step (BASELINE.json configs[4]).
  * q[r, :] = e4m3(x[r, :] / scales[r]), scales[r] = max|x[r, :]| / 448 (1 for a zero row); x bf16 [rows, K], K % 8 == 0; ldx / ldq in elements / bytes */
 int rga3_quant_fp8_rows(const void* x, void* q, float* scales, int64_t rows, int64_t K, int64_t ldx, int64_t ldq, void* stream);

@@ -106,3 +106,84 @@ def sam_preprocess(frames_u8: np.ndarray, size: int = 1024):
     mean = torch.tensor(SAM_MEAN).view(-1, 1, 1)
     std = torch.tensor(SAM_STD).view(-1, 1, 1)
     return res, (x - mean) / std
+
+
+# ------------------------------------------------------------------------------------------------ Qwen side of the row
+# Reference call path (evaluation/mevis_val_u/inference_mevis.py:196-216, same in the other inference scripts; training:
+# utils/dataset.py:41-87): messages carry {"type": "video", "video": [PIL frames], "max_pixels": P};
+#   1. qwen_vl_utils.process_vision_info (third party, pinned ==0.0.8 by the reference's requirements, ABSENT from this image),
+#      list-of-frames branch of fetch_video: every frame -> fetch_image: convert("RGB"), smart_resize(h, w, factor=28,
+#      min_pixels = ele.get("min_pixels", 4*28*28), max_pixels = ele.get("max_pixels", 16384*28*28)), PIL image.resize((w', h'))
+#      (default filter BICUBIC); the list is padded to an even length by repeating the last frame.  Restated from the published
+#      source -- this glue is PARITY UNPINNED; its two arithmetic pieces are pinned: smart_resize against the identical function in
+#      the installed transformers (models/qwen2_vl/video_processing_qwen2_vl.py:39-66) and the resize against Pillow itself.
+#   2. the HF processor: smart_resize again with the processor's own bounds (identity for frames already sized in step 1 unless
+#      they fall outside them), rescale 1/255, CLIP normalise, patchify (video_processing_qwen2_vl.py:236-336).  patchify is pinned
+#      against the installed method; the normalise order has two published forms (4.49 slow path / 5.x fused), both restated.
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # transformers image_utils.OPENAI_CLIP_MEAN
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)   # transformers image_utils.OPENAI_CLIP_STD
+QVU_MIN_PIXELS = 4 * 28 * 28          # qwen_vl_utils.vision_process.MIN_PIXELS
+QVU_MAX_PIXELS = 16384 * 28 * 28      # qwen_vl_utils.vision_process.MAX_PIXELS
+HF_MIN_PIXELS = 56 * 56               # Qwen2.5-VL preprocessor_config.json min_pixels (3136)
+HF_MAX_PIXELS = 12845056              # Qwen2.5-VL preprocessor_config.json max_pixels
+
+
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280):
+    """video_processing_qwen2_vl.py:39-66 (== qwen_vl_utils.smart_resize): both sides multiples of factor, area within bounds."""
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError("absolute aspect ratio must be smaller than 200")
+    h_bar = round(height / factor) * factor
+    w_bar = round(width / factor) * factor
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = max(factor, math.floor(height / beta / factor) * factor)
+        w_bar = max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar = math.ceil(height * beta / factor) * factor
+        w_bar = math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def qwen_norm_lut(mean=CLIP_MEAN, std=CLIP_STD, fused: bool = False) -> np.ndarray:
+    """[3, 256] fp32: the normalised value of every byte per channel.
+    fused=False: transformers 4.49 image_transforms.rescale (float64 product cast to float32) then normalize ((x - mean) / std, float32);
+    fused=True : installed 5.x image_processing_backends.py:298-337 (mean, std pre-multiplied by 255 in float32)."""
+    b = np.arange(256)
+    m = np.asarray(mean, np.float32)[:, None]
+    s = np.asarray(std, np.float32)[:, None]
+    if fused:
+        m255 = (m * np.float32(1.0 / (1 / 255)))
+        s255 = (s * np.float32(1.0 / (1 / 255)))
+        return ((b.astype(np.float32)[None] - m255) / s255).astype(np.float32)
+    x = (b.astype(np.float64) * (1 / 255)).astype(np.float32)[None]
+    return ((x - m) / s).astype(np.float32)
+
+
+def qwen_patchify(video: np.ndarray, patch: int = 14, tpatch: int = 2, merge: int = 2):
+    """video [T, C, h, w] -> ([gt*gh*gw, C*tpatch*patch*patch], (gt, gh, gw)); video_processing_qwen2_vl.py:236-274."""
+    T, C, h, w = video.shape
+    if T % tpatch:
+        video = np.concatenate([video, np.repeat(video[-1:], tpatch - T % tpatch, 0)], 0)
+        T = video.shape[0]
+    gt, gh, gw = T // tpatch, h // patch, w // patch
+    x = video.reshape(gt, tpatch, C, gh // merge, merge, patch, gw // merge, merge, patch)
+    x = x.transpose(0, 3, 6, 4, 7, 2, 1, 5, 8)
+    return np.ascontiguousarray(x).reshape(gt * gh * gw, C * tpatch * patch * patch), (gt, gh, gw)
+
+
+def qwen_video_preprocess(frames_u8, min_pixels: int = QVU_MIN_PIXELS, max_pixels: int = QVU_MAX_PIXELS, hf_min_pixels: int = HF_MIN_PIXELS,
+                          hf_max_pixels: int = HF_MAX_PIXELS, fused: bool = False, patch: int = 14, tpatch: int = 2, merge: int = 2):
+    """frames uint8 [T, H, W, 3] -> (pixel_values_videos fp32 [N, 1176], grid (t, h, w), resized uint8 [T, h', w', 3])."""
+    T, H, W, _ = frames_u8.shape
+    f = patch * merge
+    h1, w1 = smart_resize(H, W, f, min_pixels, max_pixels)
+    res = np.stack([resize_bicubic_u8(fr, h1, w1) for fr in frames_u8])
+    h2, w2 = smart_resize(h1, w1, f, hf_min_pixels, hf_max_pixels)
+    if (h2, w2) != (h1, w1):
+        res = np.stack([resize_bicubic_u8(fr, h2, w2) for fr in res])
+    lut = qwen_norm_lut(fused=fused)
+    chw = res.transpose(0, 3, 1, 2)
+    norm = np.stack([lut[c][chw[:, c]] for c in range(3)], 1)
+    pv, grid = qwen_patchify(norm, patch, tpatch, merge)
+    return pv, grid, res

@@ -116,6 +116,53 @@ __global__ __launch_bounds__(256) void resample_v_kernel(ResampleArgs p) {
     }
 }
 
+
+// Qwen-side tail: resized uint8 frames [T, h, w, 3] -> pixel_values_videos [gt*gh*gw, 3*tp*ps*ps], the HF video
+// processor's rescale + normalise + patchify (installed transformers models/qwen2_vl/video_processing_qwen2_vl.py:236-274:
+// view (gt, tp, C, gh/m, m, ps, gw/m, m, ps) -> permute (gt, gh/m, gw/m, m, m, C, tp, ps, ps)).  A normalised value depends only on
+// (channel, byte): the host builds the 3x256 fp32 table in the reference's own operation order (rga3_qwen_norm_lut) and the kernel
+// is a byte gather + table lookup + coalesced store; a frame count not divisible by tp repeats the last frame (:242-246).
+struct PatchifyArgs {
+    const unsigned char* src;
+    void* dst;
+    const float* lut;
+    long T, rows;
+    int h, w, gh, gw, ps, tp, m, out_f32;
+};
+
+// one wave per output row, lanes walk the row in element pairs (ps is even, so a pair never crosses a patch line)
+__global__ __launch_bounds__(256) void qwen_patchify_kernel(PatchifyArgs p) {
+    __shared__ float lut[768];
+    for (int i = threadIdx.x; i < 768; i += 256) lut[i] = p.lut[i];
+    __syncthreads();
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int lane = threadIdx.x & 63;
+    const int m2 = p.m * p.m;
+    const int mi = (int)(row % m2);
+    const long blk = row / m2;
+    const int bw = (int)(blk % (p.gw / p.m));
+    const int bh = (int)((blk / (p.gw / p.m)) % (p.gh / p.m));
+    const long gt = blk / ((long)(p.gw / p.m) * (p.gh / p.m));
+    const int y0 = (bh * p.m + mi / p.m) * p.ps, x0 = (bw * p.m + mi % p.m) * p.ps;
+    const int pp = p.ps * p.ps, per_c = p.tp * pp, width = 3 * per_c;
+    for (int e = lane * 2; e < width; e += 128) {
+        const int c = e / per_c, r = e % per_c;
+        const int tpi = r / pp, py = (r % pp) / p.ps, px = r % p.ps;
+        long f = gt * p.tp + tpi;
+        if (f > p.T - 1) f = p.T - 1;
+        const unsigned char* s = p.src + ((f * p.h + y0 + py) * (long)p.w + x0 + px) * 3 + c;
+        const float v0 = lut[c * 256 + s[0]], v1 = lut[c * 256 + s[3]];
+        if (p.out_f32) {
+            float* o = (float*)p.dst + row * width + e;
+            o[0] = v0;
+            o[1] = v1;
+        } else {
+            *(uint32_t*)((unsigned short*)p.dst + row * width + e) = pack_bf2(v0, v1);
+        }
+    }
+}
+
 }  // namespace rga3
 
 using namespace rga3;
@@ -194,5 +241,45 @@ extern "C" int rga3_sam_preprocess_u8(const void* frames, int64_t T, int H, int 
     const long total = T * (long)out_h * (out_w / 4);
     hipLaunchKernelGGL(resample_v_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, a);
     RGA3_CHECK_LAUNCH("resample_v_kernel");
+    return 0;
+}
+
+// Host-only: the 3 x 256 table of normalised values, lut[c*256 + b], in the reference's fp32 operation order.
+//   fused == 0: transformers 4.49 (the reference's pin, requirements.txt:26) image_transforms: rescale = float32(float64(b) * (1/255)),
+//               then (x - mean) / std in float32;
+//   fused == 1: the installed 5.x fast path (image_processing_backends.py:298-337): (float32(b) - mean*255) / (std*255) with the
+//               products formed in float32.
+extern "C" int rga3_qwen_norm_lut(const float* mean3, const float* std3, int fused, float* lut768) {
+#pragma clang fp contract(off)
+    RGA3_CHECK_ARG(mean3 && std3 && lut768, "norm_lut: null argument");
+    for (int c = 0; c < 3; ++c)
+        for (int b = 0; b < 256; ++b) {
+            float v;
+            if (fused) {
+                const float m = mean3[c] * 255.0f, s = std3[c] * 255.0f;
+                v = ((float)b - m) / s;
+            } else {
+                const float x = (float)((double)b * (1.0 / 255.0));
+                v = (x - mean3[c]) / std3[c];
+            }
+            lut768[c * 256 + b] = v;
+        }
+    return 0;
+}
+
+// frames u8 [T, h, w, 3] (device; h, w multiples of patch*merge) -> out [ceil(T/tpatch) * (h/patch) * (w/patch), 3*tpatch*patch*patch]
+// bf16 (out_dtype 0) or fp32 (1); lut768 = DEVICE copy of rga3_qwen_norm_lut's table.
+extern "C" int rga3_qwen_patchify_u8(const void* frames, int64_t T, int h, int w, const float* lut768, void* out, int out_dtype, int patch,
+                                     int tpatch, int merge, void* stream) {
+    RGA3_CHECK_ARG(frames && lut768 && out && T > 0, "patchify: null argument");
+    RGA3_CHECK_ARG(patch > 0 && patch % 2 == 0 && tpatch > 0 && merge > 0, "patchify: patch %d (even), tpatch %d, merge %d", patch, tpatch, merge);
+    RGA3_CHECK_ARG(h > 0 && w > 0 && h % (patch * merge) == 0 && w % (patch * merge) == 0, "patchify: %dx%d not a multiple of %d", h, w, patch * merge);
+    RGA3_CHECK_ARG(out_dtype == 0 || out_dtype == 1, "patchify: out_dtype %d", out_dtype);
+    PatchifyArgs a;
+    a.src = (const unsigned char*)frames; a.dst = out; a.lut = lut768; a.T = T; a.h = h; a.w = w; a.gh = h / patch; a.gw = w / patch;
+    a.ps = patch; a.tp = tpatch; a.m = merge; a.out_f32 = out_dtype;
+    a.rows = cdiv(T, (int64_t)tpatch) * a.gh * a.gw;
+    hipLaunchKernelGGL(qwen_patchify_kernel, dim3((unsigned)cdiv(a.rows, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    RGA3_CHECK_LAUNCH("qwen_patchify_kernel");
     return 0;
 }

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rga3_im2col3x3s2": [_p, _p, _i64, _i, _i, _i, _p],
     "rga3_pil_bicubic_coeffs": [_i, _i, _p, _p, _i64, _p],
     "rga3_sam_preprocess_u8": [_p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "rga3_qwen_norm_lut": [_p, _p, _i, _p],
+    "rga3_qwen_patchify_u8": [_p, _i64, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "rga3_rmsnorm_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _f, _p],
     "rga3_dropout_bf16": [_p, _p, _i64, _f, _i64, _i, _p],
     "rga3_swiglu_fwd": [_p, _p, _i64, _i64, _p],

@@ -44,3 +44,36 @@ def test_fixture_from_reference_recipe():
         assert np.array_equal(res[0], G[f"res{i}"])
         got = norm[0].to(torch.bfloat16).float().numpy()
         assert np.array_equal(got[:, ::4, ::4], G[f"norm_bf16_sub{i}"])
+
+
+# ---------------------------------------------------------------------------------------------- Qwen side
+def _qg():
+    return np.load(os.path.join(ROOT, "tests", "golden", "qwen_preproc.npz"))
+
+
+def test_smart_resize_matches_transformers_table():
+    """400 (h, w, min, max) -> (h', w') rows produced by the installed transformers' smart_resize (make_qwen_preproc_fixtures.py)."""
+    tab = _qg()["smart_resize"]
+    for h, w, mn, mx, oh, ow in tab.tolist():
+        assert P.smart_resize(h, w, 28, mn, mx) == (oh, ow), (h, w, mn, mx)
+    with pytest.raises(ValueError):
+        P.smart_resize(10, 2100)
+
+
+def test_qwen_video_recipe_matches_fixture():
+    """Pillow resize + HF patchify + both normalisation orders, incl. an odd frame count and the second (processor-side) resize."""
+    G = _qg()
+    for i in range(int(G["n"])):
+        for fused, key in ((False, "pv49_"), (True, "pv5_")):
+            pv, grid, res = P.qwen_video_preprocess(G[f"frames{i}"], max_pixels=int(G[f"max_pixels{i}"]), fused=fused)
+            assert np.array_equal(res, G[f"res{i}"]), i
+            assert list(grid) == G[f"grid{i}"].tolist()
+            assert pv.dtype == np.float32 and np.array_equal(pv, G[f"{key}{i}"]), (i, fused)
+
+
+def test_normalisation_orders_agree_in_bf16():
+    """The reference casts pixel_values_videos to bf16 (inference_mevis.py:214, train_joint.py:516-519): the 4.49 and 5.x orders differ by
+    a few fp32 ulps before the cast (<= 2.4e-7 absolute) and on NONE of the 768 (channel, byte) values after it."""
+    a, b = torch.from_numpy(P.qwen_norm_lut(fused=False)), torch.from_numpy(P.qwen_norm_lut(fused=True))
+    assert float((a - b).abs().max()) <= 5e-7 and not torch.equal(a, b)
+    assert torch.equal(a.bfloat16(), b.bfloat16())

@@ -14,3 +14,19 @@ def test_coeff_tables_match_oracle(sizes):
     assert k.shape[1] == ks
     assert np.array_equal(b.numpy(), ob)
     assert np.array_equal(k.numpy(), ok_)
+
+
+def test_host_smart_resize_and_lut_match_oracle():
+    """Host logic of the Qwen-side pipeline: smart_resize over the transformers-made table; the C ABI's byte table in both orders."""
+    import os
+
+    import torch
+
+    from rga3.utils import preproc as H
+
+    tab = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "qwen_preproc.npz"))["smart_resize"]
+    for h, w, mn, mx, oh, ow in tab.tolist():
+        assert H.smart_resize(h, w, 28, mn, mx) == (oh, ow)
+    for fused in (False, True):
+        lut = H.qwen_norm_lut(torch.device("cpu"), fused=fused)
+        assert np.array_equal(lut.numpy(), P.qwen_norm_lut(fused=fused)), fused
