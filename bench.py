@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--stream-frames", type=int, default=32)
     ap.add_argument("--grad-accum", type=int, default=4)
     ap.add_argument("--no-fp8", action="store_true", help="lora_fp8 mode with bf16 GEMMs (A/B)")
+    ap.add_argument("--no-refine", action="store_true", help="skip the in-situ tile refinement (A/B)")
     ap.add_argument("--sam-frames", type=int, default=16)
     args = ap.parse_args()
 
@@ -335,6 +336,16 @@ def main():
         def step():
             with torch.no_grad():
                 return model(**inputs)
+
+    # in-situ tile refinement (untimed, before the warmup): every GEMM shape's tiling is re-decided by the time of the WHOLE step
+    # (rga3.hip.tuner.refine).  Skipped where ranks exchange gradients inside the step: each rank decides from its own timings, and
+    # the number of trial steps -- hence of collectives -- would differ between ranks.
+    if not args.no_refine and args.mode != "lora_fp8" and (args.mode == "forward" or world == 1):
+        from rga3.hip import tuner
+        rw, rr = (os.environ.get("RGA3_REFINE", "1.5,5").split(",") + ["5"])[:2]
+        ch = tuner.refine(step, reps=int(rr) if args.mode == "forward" else 3, within=float(rw))
+        if rank == 0 and ch:
+            print("tuner.refine changed %d shape(s): %s" % (len(ch), {str(k[:3]): v for k, v in ch.items()}), file=sys.stderr)
 
     for _ in range(args.warmup):
         step()

@@ -1,7 +1,13 @@
 """Per-shape tile selection for the bf16 GEMM, measured on the device it runs on (MI355X boards differ by >10 % on the same
 binary: MI355X_MICROARCH.md 'DVFS give-back' item 5).  First call of a (M-bucket, N, K, epilogue) shape times the candidate
 tilings with HIP events on the launch stream and caches the winner for the process; RGA3_GEMM_TUNE=0 falls back to the
-library's static heuristic (tile = -1)."""
+library's static heuristic (tile = -1).
+
+``refine(step)`` re-decides every shape IN SITU: a product measured alone re-reads operands that sit in the 256-MiB Infinity Cache
+and runs at the clock of a short burst, while inside the model its weights stream from HBM and its neighbours set the clock and
+the cache state -- the single-phase tilings lose 10-20 % on cold weights, the ping-pong ones do not (tools/gemm_cold.py), so the
+stand-alone winner is not always the winner in place.  refine times the caller's whole step with each close candidate of each
+shape and keeps what makes the STEP fastest."""
 from __future__ import annotations
 
 import os
@@ -44,6 +50,50 @@ def pick(key, run, extra=()):
             best, best_ms = tile, ms
     _cache[key] = best
     return best
+
+
+def _time_step(step, reps):
+    ts = []
+    for _ in range(reps):
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        step()
+        en.record()
+        en.synchronize()
+        ts.append(st.elapsed_time(en))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def refine(step, reps: int = 5, within: float = 1.5, min_gain: float = 0.002, verbose=None):
+    """Re-pick the tiling of every GEMM shape ``step()`` launches by the time of the whole step (median of ``reps`` runs per candidate).
+    Only candidates whose stand-alone time is within ``within`` x the stand-alone best are tried; a change must win ``min_gain`` of the
+    step.  Returns {key: (old tile, new tile)} for the shapes that changed.  Call it once after the first (tuning) step."""
+    if not _enabled:
+        return {}
+    step()                                   # make sure every shape has its stand-alone table
+    torch.cuda.synchronize()
+    changed = {}
+    base = _time_step(step, reps)
+    for key in list(_cache):
+        tm = _times.get(key)
+        if not tm:
+            continue
+        cur = _cache[key]
+        lim = min(tm.values()) * within
+        best_t, best_ms = cur, base
+        for cand in sorted((t for t in tm if t != cur and tm[t] <= lim), key=lambda t: tm[t]):
+            _cache[key] = cand
+            ms = _time_step(step, reps)
+            if ms < best_ms * (1.0 - min_gain):
+                best_t, best_ms = cand, ms
+        _cache[key] = best_t
+        if best_t != cur:
+            changed[key] = (cur, best_t)
+            base = best_ms
+            if verbose:
+                verbose(f"tuner.refine: {key} tile {cur} -> {best_t}: step {best_ms:.3f} ms")
+    return changed
 
 
 def table():

@@ -53,3 +53,25 @@ def test_rope_index_text_only_and_images():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     t = QI.rope_index(np.array([[1, 2, 3, 4]]), 301, 302, 2, 2)
     assert np.array_equal(t[0][:, 0], np.tile(np.arange(4), (3, 1)))
+
+
+def test_tuner_refine_keeps_what_makes_the_step_fastest(monkeypatch):
+    """Host logic of the in-situ tile refinement (rga3/hip/tuner.py::refine) with a fake clock: a candidate that is slower stand-alone but
+    makes the step faster is adopted; candidates far off the stand-alone best are not tried; a gain under the threshold changes nothing."""
+    from rga3.hip import tuner
+
+    monkeypatch.setattr(tuner, "_enabled", True)
+    monkeypatch.setattr(tuner, "_cache", {"a": 3, "b": 21, "c": 4})
+    monkeypatch.setattr(tuner, "_times", {"a": {3: 1.0, 11: 1.1, 22: 9.0}, "b": {21: 2.0, 20: 2.05}, "c": {4: 1.0, 12: 1.2}})
+    cost = {("a", 3): 5.0, ("a", 11): 4.0, ("a", 22): 1.0, ("b", 21): 7.0, ("b", 20): 7.2, ("c", 4): 3.0, ("c", 12): 2.999}
+    tried = []
+
+    def fake_time(step, reps):
+        tried.append(dict(tuner._cache))
+        return sum(cost[(k, t)] for k, t in tuner._cache.items())
+
+    monkeypatch.setattr(tuner, "_time_step", fake_time)
+    monkeypatch.setattr(tuner.torch.cuda, "synchronize", lambda: None)
+    ch = tuner.refine(lambda: None, reps=1, within=1.5, min_gain=0.002)
+    assert ch == {"a": (3, 11)} and tuner._cache == {"a": 11, "b": 21, "c": 4}
+    assert all(t["a"] != 22 for t in tried)          # 9x the stand-alone best: never tried, although it would have won
