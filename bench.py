@@ -260,7 +260,8 @@ def main():
     ap.add_argument("--stream-frames", type=int, default=32)
     ap.add_argument("--grad-accum", type=int, default=4)
     ap.add_argument("--no-fp8", action="store_true", help="lora_fp8 mode with bf16 GEMMs (A/B)")
-    ap.add_argument("--no-refine", action="store_true", help="skip the in-situ tile refinement (A/B)")
+    ap.add_argument("--no-refine", action="store_true", help="forward mode: skip the in-situ tile refinement (A/B)")
+    ap.add_argument("--refine", action="store_true", help="training modes, 1 GPU: run the in-situ tile refinement before the warmup")
     ap.add_argument("--sam-frames", type=int, default=16)
     args = ap.parse_args()
 
@@ -338,9 +339,10 @@ def main():
                 return model(**inputs)
 
     # in-situ tile refinement (untimed, before the warmup): every GEMM shape's tiling is re-decided by the time of the WHOLE step
-    # (rga3.hip.tuner.refine).  Skipped where ranks exchange gradients inside the step: each rank decides from its own timings, and
-    # the number of trial steps -- hence of collectives -- would differ between ranks.
-    if not args.no_refine and args.mode != "lora_fp8" and (args.mode == "forward" or world == 1):
+    # (rga3.hip.tuner.refine).  Default for the forward bench; the training modes launch ~60 shapes per step, so there it is opt-in
+    # (--refine, single GPU only: each rank decides from its own timings and the number of trial steps -- hence of gradient
+    # collectives -- would differ between ranks).
+    if (args.mode == "forward" and not args.no_refine) or (args.refine and world == 1 and args.mode != "sam2_stream"):
         from rga3.hip import tuner
         rw, rr = (os.environ.get("RGA3_REFINE", "1.5,5").split(",") + ["5"])[:2]
         ch = tuner.refine(step, reps=int(rr) if args.mode == "forward" else 3, within=float(rw))
