@@ -355,317 +355,6 @@ __global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnArgs p) {
     if (p.lse && lane == 0) p.lse[(long)hq * p.total_q + tq] = wsum > 0.f ? (m + log2f(wsum)) * 0.6931471805599453f : -INFINITY;
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Ping-pong form of the 8-wave kernel (D = 64 / 128, 16 query rows per wave).  The plain kernel above runs all eight waves in
-// lockstep (two workgroup barriers per key tile around the shared K/V image), so every SIMD alternates between a phase in which
-// both of its waves want the matrix pipe (QK^T, PV) and a phase in which both want the vector ALU (softmax: ~3.5 VALU per MFMA at
-// D = 128, as many issue cycles as the MFMAs themselves) -- measured 680 TFLOP/s at best, 27 % MFMA-busy at S = 2112.
-// Here the waves form two groups of four (one wave of each per SIMD) that run the SAME two-phase loop one phase apart:
-//      phase M(i): S_i^T = K_i . Q^T   and   O^T += V_{i-1}^T . P_{i-1}^T      (32 MFMAs, fragment reads from LDS)
-//      phase V(i): online softmax of S_i -> P_i, rescale O, write this wave's share of the next K / V tiles to LDS, refill the ring
-// separated by raw s_barriers; group 1 takes one extra barrier up front and group 0 one at the end, so while one group is in M the
-// other is in V and the matrix pipe and the vector ALU of every SIMD are busy at the same time.  K and V tiles are double-buffered
-// in LDS (4 x 18 KiB at D = 128).  Who writes what, with tile shares loaded HBM -> registers three tiles ahead:
-//      group 0 in V(i): K_{i+1}, V_i          group 1 in V(i): K_{i+2}, V_{i+1}
-// (group 1's V(i) runs after group 0's M(i+1) has started, so it stages one tile further ahead; its ring slot s holds tile s+1 mod 3
-// where group 0's holds tile s mod 3: same registers, the group only enters the addresses).  Every buffer is rewritten only after
-// both groups have passed the phase that read it (see the slot table in DESIGN.md section 4).
-template <int DP, bool PAIR>
-__global__ __launch_bounds__(512) void attn_fwd_pp_kernel(AttnArgs p) {
-    constexpr int NT = 512, BLOCK_M = 128;
-    constexpr int CH = DP / 8;
-    constexpr int STRIDE = DP * 2 + 32;
-    constexpr int DS = DP / 32, DT = DP / 16;
-    constexpr int LOADS = (KV_TILE * CH) / NT;
-    static_assert((KV_TILE * CH) % NT == 0 && LOADS >= 1, "tile chunks must divide evenly over 512 threads");
-    constexpr int TILE_B = KV_TILE * STRIDE;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Kb = smem;               // K tile t in Kb + (t & 1) * TILE_B
-    char* Vb = smem + 2 * TILE_B;  // V tile t in Vb + (t & 1) * TILE_B
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wid >> 2;  // 0: leads, 1: runs one phase behind
-    const int g = lane >> 4, c = lane & 15;
-
-    const int seg = blockIdx.z, hq = blockIdx.y;
-    const int hk = hq / (p.Hq / p.Hkv);
-    const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
-    const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
-    const int shift = Lk - Lq;
-    const int nqb = (Lq + BLOCK_M - 1) / BLOCK_M;
-    int qb_first = (int)blockIdx.x, qb_second = -1;
-    if constexpr (PAIR) {
-        qb_first = nqb - 1 - (int)blockIdx.x;
-        qb_second = (int)blockIdx.x;
-        if (qb_second > qb_first) return;
-        if (qb_second == qb_first) qb_second = -1;
-    } else if (qb_first >= nqb) {
-        return;
-    }
-    const unsigned short* kbase = p.k + (long)ks * p.k_st + (long)hk * p.k_sh;
-    const unsigned short* vbase = p.v + (long)ks * p.v_st + (long)hk * p.v_sh;
-    int koff0[LOADS], voff0[LOADS], lds_off[LOADS];
-#pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-        const int idx = tid + i * NT;
-        const int r = idx / CH, ch = idx % CH;
-        koff0[i] = (int)(r * p.k_st + ch * 8);
-        voff0[i] = (int)(r * p.v_st + ch * 8);
-        lds_off[i] = r * STRIDE + ch * 16;
-    }
-
-    for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
-    const int qbi = pass == 0 ? qb_first : qb_second;
-    if (qbi < 0) break;
-    if (pass == 1) __syncthreads();  // group 1 may still be in its last PV of the previous block
-    const int qb0 = qbi * BLOCK_M;
-    const int qw0 = qb0 + wid * 16;
-    const int qi = qw0 + c;
-
-    bf16x8 qf[DS];
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) {
-        const int d = ds * 32 + g * 8;
-        u32x4 z = {0u, 0u, 0u, 0u};
-        if (qi < Lq && d < p.D) z = *(const u32x4*)(p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh + d);
-        qf[ds] = __builtin_bit_cast(bf16x8, z);
-    }
-    f32x4 oacc[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-
-    int kv_end = Lk;
-    if (p.causal) kv_end = min(Lk, qb0 + BLOCK_M + shift);
-    if (kv_end < 0) kv_end = 0;
-    const int ntiles = (kv_end + KV_TILE - 1) / KV_TILE;
-
-    u32x4 kreg[4][LOADS], vreg[4][LOADS];   // ring slots 0..2, slot 3 = prologue temporary (compile-time indices only: registers)
-    auto load_share = [&](auto SLOT, int kt) __attribute__((always_inline)) {
-        constexpr int slot = decltype(SLOT)::value;
-        const unsigned short* kt_k = kbase + (long)kt * KV_TILE * p.k_st;
-        const unsigned short* kt_v = vbase + (long)kt * KV_TILE * p.v_st;
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i) {
-            const int idx = tid + i * NT;
-            const int r = idx / CH, ch = idx % CH;
-            const int key = kt * KV_TILE + r;
-            u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
-            if (kt < ntiles && key < Lk && ch * 8 < p.D) {
-                zk = *(const u32x4*)(kt_k + koff0[i]);
-                zv = *(const u32x4*)(kt_v + voff0[i]);
-            }
-            kreg[slot][i] = zk;
-            vreg[slot][i] = zv;
-        }
-    };
-    auto write_k = [&](auto SLOT, char* buf) __attribute__((always_inline)) {
-        constexpr int slot = decltype(SLOT)::value;
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i) *(u32x4*)(buf + lds_off[i]) = kreg[slot][i];
-    };
-    auto write_v = [&](auto SLOT, char* buf) __attribute__((always_inline)) {
-        constexpr int slot = decltype(SLOT)::value;
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i) *(u32x4*)(buf + lds_off[i]) = vreg[slot][i];
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-
-    if (ntiles > 0) {   // uniform over the workgroup
-    // ---- prologue: tile 0 from temporaries (group 1's ring starts at tile 1), ring slots s <- tile s + grp
-    load_share(I3{}, 0);
-    load_share(I0{}, 0 + grp);
-    load_share(I1{}, 1 + grp);
-    load_share(I2{}, 2 + grp);
-    write_k(I3{}, Kb);
-    write_v(I3{}, Vb);
-    if (grp == 1) write_k(I0{}, Kb + TILE_B);  // group 1's "V(-1)": its share of K_1 (V_0 is complete already)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();   // one phase behind from here on
-
-    f32x4 s[4];
-    bf16x8 pf[2];
-    // Fragment reads run one group (four fragments) ahead of the MFMAs that consume them: only ONE wave per SIMD is in this phase,
-    // so nothing else hides the LDS round trip (left to itself the compiler reuses one temporary: read, wait, MFMA, 32 times over).
-    auto read_k4 = [&](bf16x8 (&f)[4], const char* Ks, int ds) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = *(const bf16x8*)(Ks + (j * 16 + c) * STRIDE + ds * 64 + g * 16);
-    };
-    auto read_v4 = [&](bf16x8 (&f)[4], const char* Vs, int ss, int d0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const char* a0 = Vs + (ss * 32 + 4 * g + (c >> 2)) * STRIDE + ((d0 + e) * 16 + 4 * (c & 3)) * 2;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * STRIDE));
-            f[e][0] = lo[0]; f[e][1] = lo[1]; f[e][2] = lo[2]; f[e][3] = lo[3];
-            f[e][4] = hi[0]; f[e][5] = hi[1]; f[e][6] = hi[2]; f[e][7] = hi[3];
-        }
-    };
-    // phase M(i): S_i^T = K_i . Q^T, then (i > 0) O^T += V_{i-1}^T . P_{i-1}^T; fragment groups ping-pong between fa and fb
-    auto m_phase = [&](int i, bool with_qk, bool with_pv) __attribute__((always_inline)) {
-        const char* Ks = Kb + (i & 1) * TILE_B;
-        const char* Vs = Vb + ((i - 1) & 1) * TILE_B;
-        bf16x8 fa[4], fb[4];
-        if (with_qk) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            read_k4(fa, Ks, 0);
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                bf16x8 (&cur)[4] = (ds & 1) ? fb : fa;
-                bf16x8 (&nxt)[4] = (ds & 1) ? fa : fb;
-                if (ds + 1 < DS) read_k4(nxt, Ks, ds + 1);
-                else if (with_pv) read_v4(nxt, Vs, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], qf[ds], s[j], 0, 0, 0);
-            }
-        } else if (with_pv) {
-            read_v4((DS & 1) ? fb : fa, Vs, 0, 0);
-        }
-        if (with_pv) {
-            constexpr int NG = 2 * (DT / 4);   // groups of four d-tiles: (ss, d0)
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                const int par = (DS + gi) & 1;   // the group preloaded above sits in the buffer QK^T would have filled next
-                bf16x8 (&cur)[4] = par ? fb : fa;
-                bf16x8 (&nxt)[4] = par ? fa : fb;
-                if (gi + 1 < NG) read_v4(nxt, Vs, (gi + 1) / (DT / 4), ((gi + 1) % (DT / 4)) * 4);
-                const int ss = gi / (DT / 4), d0 = (gi % (DT / 4)) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) oacc[d0 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[e], pf[ss], oacc[d0 + e], 0, 0, 0);
-            }
-        }
-    };
-    auto softmax_phase = [&](int i) __attribute__((always_inline)) {
-        const int k0 = i * KV_TILE;
-        const bool need_mask = (k0 + KV_TILE > Lk) || (p.causal && (k0 + KV_TILE - 1 > qb0 + shift));
-        auto body = [&](auto masked_tag) __attribute__((always_inline)) {
-            constexpr bool MASKED = decltype(masked_tag)::value;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = s[j][r] * p.scale_log2;
-                    if constexpr (MASKED) {
-                        const int key = k0 + j * 16 + 4 * g + r;
-                        const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
-                        x = ok ? x : -INFINITY;
-                    }
-                    s[j][r] = x;
-                    mx = fmaxf(mx, x);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            m_run = m_new;
-            float ps = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float e = __builtin_amdgcn_exp2f(s[j][r] - m_use);
-                    s[j][r] = e;
-                    ps += e;
-                }
-            l_run = l_run * alpha + ps;
-            if (__any(alpha != 1.0f)) {
-#pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d] *= alpha;
-            }
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                u32x4 pk;
-                pk[0] = pack_bf2(s[2 * ss][0], s[2 * ss][1]);
-                pk[1] = pack_bf2(s[2 * ss][2], s[2 * ss][3]);
-                pk[2] = pack_bf2(s[2 * ss + 1][0], s[2 * ss + 1][1]);
-                pk[3] = pack_bf2(s[2 * ss + 1][2], s[2 * ss + 1][3]);
-                pf[ss] = __builtin_bit_cast(bf16x8, pk);
-            }
-        };
-        if (need_mask) body(std::true_type{});
-        else body(std::false_type{});
-    };
-    // one key tile; R = i mod 3 picks the ring slots at compile time
-    auto tile_body = [&](auto RR, int i) __attribute__((always_inline)) {
-        constexpr int R = decltype(RR)::value;
-        // ---- phase M(i)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        if (i > 0) m_phase(i, true, true);
-        else m_phase(i, true, false);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase V(i)
-        softmax_phase(i);
-        const int tk = i + 1 + grp, tv = i + grp;   // tiles whose shares this wave stages now
-        if (tk < ntiles) write_k(std::integral_constant<int, (R + 1) % 3>{}, Kb + (tk & 1) * TILE_B);
-        if (tv < ntiles) write_v(std::integral_constant<int, R>{}, Vb + (tv & 1) * TILE_B);
-        load_share(std::integral_constant<int, R>{}, tv + 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int i = 0; i < ntiles; i += 3) {
-        tile_body(I0{}, i);
-        if (i + 1 < ntiles) tile_body(I1{}, i + 1);
-        if (i + 2 < ntiles) tile_body(I2{}, i + 2);
-    }
-    m_phase(ntiles, false, true);
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last V-phase barrier
-    }  // ntiles > 0
-
-    // ---- finalize
-    {
-        float l = l_run;
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = (l > 0.f) ? 1.f / l : 0.f;
-        if (qi < Lq) {
-            unsigned short* orow = p.o + (long)(qs + qi) * p.o_st + (long)hq * p.o_sh;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                const int dd = d * 16 + 4 * g;
-                if (dd < p.D) {
-                    u32x2 pk;
-                    pk[0] = pack_bf2(oacc[d][0] * inv, oacc[d][1] * inv);
-                    pk[1] = pack_bf2(oacc[d][2] * inv, oacc[d][3] * inv);
-                    *(u32x2*)(orow + dd) = pk;
-                }
-            }
-            if (p.lse && g == 0) p.lse[(long)hq * p.total_q + qs + qi] = (l > 0.f) ? (m_run * 0.6931471805599453f + logf(l)) : -INFINITY;
-        }
-    }
-    }  // pass
-}
-
-template <int DP, bool PAIR>
-static int launch_attn_pp(const AttnArgs& a, int nseg, unsigned gx, hipStream_t st) {
-    constexpr int LDS = 4 * KV_TILE * (DP * 2 + 32);
-    auto kern = attn_fwd_pp_kernel<DP, PAIR>;
-    static bool attr_done = false;
-    if (!attr_done && LDS > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(512), LDS, st, a);
-    RGA3_CHECK_LAUNCH("attn_fwd_pp_kernel");
-    return 0;
-}
-
 template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR>
 static int launch_attn_p(const AttnArgs& a, int nseg, unsigned gx, hipStream_t st) {
     constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
@@ -715,11 +404,6 @@ static int launch_dp(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     if constexpr (DP == 128 || DP == 64) {
         // long sequences: 8 waves x 16 query rows keeps the register footprint near 110 VGPRs (4 waves/SIMD) instead of
         // one 300-register wave per SIMD
-        if (max_q > 64 && g_attn_variant == 2 && USE_TR && a.nsplit <= 1) {   // ping-pong form
-            const unsigned nqb = (unsigned)cdiv(max_q, 128);
-            if (a.causal && nqb >= 4) return launch_attn_pp<DP, true>(a, nseg, (nqb + 1) / 2, st);
-            return launch_attn_pp<DP, false>(a, nseg, nqb, st);
-        }
         if (max_q > 64 && g_attn_variant != 1) return launch_attn<DP, 1, 8, USE_TR>(a, nseg, max_q, st);
     }
     if constexpr (DP >= 256) {
@@ -760,8 +444,8 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
-    RGA3_CHECK_ARG(impl >= 0 && impl <= 7, "attn: impl %d", impl);
-    g_attn_variant = (impl & 4) ? 2 : (impl & 2) ? 1 : 0;
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 3, "attn: impl %d", impl);
+    g_attn_variant = (impl & 2) ? 1 : 0;
     impl &= 1;
     AttnArgs a;
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
