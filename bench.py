@@ -329,7 +329,7 @@ def main():
                 else:
                     (out.loss / accum).backward()
             reducer.finish()
-            opt.step(reducer.grad_view)
+            opt.step(reducer.grad_view, reducer.flat_grads())
             o = _Out()
             o.logits = out.loss.detach().reshape(1)
             return o

@@ -53,6 +53,11 @@ class GradBucketReducer:
         bi, off, n = self.slices[p]
         return self.flat[bi][off:off + n].view_as(p)
 
+    def flat_grads(self):
+        """The flat buckets themselves: together they hold exactly the gradients of ``params`` (every element belongs to one slice),
+        so a reduction over all gradients (the clipping norm) can run once per bucket instead of once per tensor."""
+        return list(self.flat)
+
     def _on_grad(self, p):
         bi, off, n = self.slices[p]
         self.flat[bi][off:off + n].add_(p.grad.reshape(-1)) if self._accum_started[bi] else self.flat[bi][off:off + n].copy_(p.grad.reshape(-1))
@@ -107,8 +112,9 @@ class FusedAdamW:
         self.v = [torch.zeros_like(x) for x in self.master]
         self.t = 0
 
-    def step(self, grad_of):
-        """grad_of(p) -> gradient tensor (e.g. GradBucketReducer.grad_view)."""
+    def step(self, grad_of, flat_grads=None):
+        """grad_of(p) -> gradient tensor (e.g. GradBucketReducer.grad_view).  flat_grads: optional list of flat tensors that together
+        hold exactly these gradients (GradBucketReducer.flat_grads()): the clipping norm then takes one launch per bucket."""
         from ..hip import ops
 
         self.t += 1
@@ -116,7 +122,7 @@ class FusedAdamW:
         scale = 1.0
         if self.max_norm is not None:
             acc = torch.zeros(1, dtype=torch.float32, device=self.params[0].device)
-            for g in grads:
+            for g in (flat_grads if flat_grads is not None else grads):
                 ops.sumsq_accum_(g.reshape(-1), acc)
             norm = float(acc.sqrt())
             scale = min(1.0, self.max_norm / (norm + 1e-6))

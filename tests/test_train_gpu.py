@@ -257,3 +257,44 @@ def test_fp8_frozen_gemm_training_step_close_to_bf16(dev):
     # each e4m3 x e4m3 contraction carries ~5 % relative noise (3 mantissa bits, two operands, random-sign terms do not average it out);
     # eight of them sit on the path from the loss to a LoRA factor
     assert max(errs.values()) < 0.3 and float(np.median(list(errs.values()))) < 0.2, errs
+
+
+def test_fused_adamw_with_bucket_norm_matches_torch(dev):
+    """GradBucketReducer (single rank) + FusedAdamW: one optimizer step with global-norm clipping (train_joint.py:300-324: betas (0.9, 0.95),
+    wd 0, clip 1.0) equals torch.optim.AdamW on fp32 copies after clip_grad_norm_; the clipping norm taken over the flat buckets equals the
+    per-tensor form."""
+    from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
+
+    torch.manual_seed(3)
+    shapes = [(64, 40), (130,), (17, 9), (256, 128)]
+
+    def make():
+        torch.manual_seed(4)
+        return [torch.nn.Parameter((torch.randn(*s, device=dev) * 0.3).to(torch.bfloat16)) for s in shapes]
+
+    grads = [(torch.randn(*s, device=dev) * 2.0).to(torch.bfloat16) for s in shapes]
+    outs = []
+    for use_flat in (False, True):
+        ps = make()
+        red = GradBucketReducer(ps, bucket_mb=0.01)   # ~10 KB buckets -> several buckets
+        opt = FusedAdamW(ps, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, max_grad_norm=1.0)
+        red.begin_step()
+        red.begin_micro_step()
+        for p, g in zip(ps, grads):
+            p.grad = g.clone()
+            red._on_grad(p)
+        red.finish()
+        scale = opt.step(red.grad_view, red.flat_grads() if use_flat else None)
+        outs.append(([p.detach().float().clone() for p in ps], scale))
+        red.remove()
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * outs[0][1]
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    ref = [torch.nn.Parameter(p.detach().float().clone()) for p in make()]
+    for p, g in zip(ref, grads):
+        p.grad = g.float().clone()
+    total = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+    assert abs(min(1.0, 1.0 / (float(total) + 1e-6)) - outs[0][1]) < 1e-4
+    torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0).step()
+    for a, r in zip(outs[0][0], ref):
+        assert torch.allclose(a, r.detach().to(torch.bfloat16).float(), atol=1e-2, rtol=2e-2)
