@@ -60,6 +60,11 @@ int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* r
  * zeroed ONCE by the caller and then kept for the calls of one stream (the kernels leave the flag words zero again); without it (NULL / too
  * small) those tilings run as 21 / 20. */
 int64_t rga3_gemm_workspace_bytes(void);
+/* C[M,N] (bf16 / f32) = A^T . B (+ bias[n]); A [K,M], B [K,N] bf16 row-major (K = tokens): the weight-gradient product dW = dY^T X of
+ * nn.Linear / LoRA (autograd under reference train_joint.py:534) without transposing the activations first.  M, N multiples of 8. */
+int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                      int64_t ldc, int out_dtype, void* stream);
+
 
 /* Variable-length fused attention forward (online softmax, fp32 statistics), bf16 in/out.
  *   q: [total_q, Hq, D], k/v: [total_k, Hkv, D] addressed through (token, head) element strides so the

@@ -1076,6 +1076,102 @@ static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// TN product for weight gradients: C[M, N] = A^T . B with A [K, M] and B [K, N] row-major, K = tokens (dW = dY^T X of nn.Linear /
+// LoRA, reference autograd of train_joint.py:534).  The NT kernels above would need both operands transposed first (one extra
+// pass over the activations per product, ~600 launches per RGA3 step); here the [k][m] / [k][n] tiles are staged as they lie
+// and every MFMA fragment is fetched with two ds_read_b64_tr_b16 (the transposing LDS read: lane (g, c) gets, for its row c of the
+// 16-wide tile, the k values 4g..4g+3 and 16+4g..16+4g+3 of the 32-deep step) -- both operands through the SAME recipe, so the
+// k order inside a step is permuted identically on both sides and the contraction is unchanged.  128x128 tile, 4 waves (2x2, 64x64
+// each), BK = 32, register-staged double buffer; rows padded by 32 B (conflict-free transposed reads, as the attention V image).
+struct TnArgs {
+    const unsigned short* A;  // [K, M]
+    const unsigned short* B;  // [K, N]
+    long lda, ldb;
+    int K;
+};
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int STRIDE = BM * 2 + 32;          // bytes per staged k-row (both operands: BM == BN)
+    constexpr int TILE = BK * STRIDE;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [buf][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int g = lane >> 4, c = lane & 15;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // staging: 32 rows x 16 chunks (16 B) per operand tile = 512 chunks, two per thread
+    int srow[2], scol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        srow[i] = idx >> 4;
+        scol[i] = (idx & 15) * 8;
+    }
+    u32x4 ra[2], rb[2];
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = kt * BK + srow[i];
+            u32x4 za = {0u, 0u, 0u, 0u}, zb = {0u, 0u, 0u, 0u};
+            if (k < t.K) {
+                // columns beyond M / N only feed output rows / columns that are never stored: clamp the address instead of branching
+                za = *(const u32x4*)(t.A + (long)k * t.lda + min(m0 + scol[i], p.M - 8));
+                zb = *(const u32x4*)(t.B + (long)k * t.ldb + min(n0 + scol[i], p.N - 8));
+            }
+            ra[i] = za;
+            rb[i] = zb;
+        }
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        char* sa = smem + buf * 2 * TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(u32x4*)(sa + srow[i] * STRIDE + scol[i] * 2) = ra[i];
+            *(u32x4*)(sa + TILE + srow[i] * STRIDE + scol[i] * 2) = rb[i];
+        }
+    };
+    auto frag = [&](const char* base, int col16) __attribute__((always_inline)) -> bf16x8 {
+        const char* a0 = base + (4 * g + (c >> 2)) * STRIDE + (col16 * 16 + 4 * (c & 3)) * 2;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * STRIDE));
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (t.K + BK - 1) / BK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile(kt & 1);
+        __syncthreads();   // tile kt visible; everyone is past the reads of tile kt-1 (the other buffer is free for kt+1)
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* sa = smem + (kt & 1) * 2 * TILE;
+        const char* sb = sa + TILE;
+        bf16x8 af[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = frag(sa, wm * 4 + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = frag(sb, wn * 4 + j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    gemm_epilogue<4, 4, 64, 64, ACT_NONE, OUT_F32>(acc, p, smem, lane, m0, n0, wm, wn);
+}
+
 // tile choice: fill the 256 CUs.  score = useful fraction of the last wave of tiles x a per-config prior.
 static int pick_tile(int M, int N, int K, bool plain, int forced) {
     if (forced >= 0) return forced;
@@ -1169,4 +1265,30 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
         case ACT_SWIGLU: return launch_act<ACT_SWIGLU, false>(a, tl, st);
         default: return launch_act<ACT_RELU, false>(a, tl, st);
     }
+}
+
+// C[M, N] (bf16 or f32) = A^T . B (+ bias[n]) with A [K, M], B [K, N] bf16 row-major: the weight-gradient product dW = dY^T X without
+// transposing either operand first.  M, N multiples of 8; lda / ldb / ldc in elements.
+extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                 int64_t ldb, int64_t ldc, int out_dtype, void* stream) {
+    RGA3_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
+    RGA3_CHECK_ARG(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0, "gemm_tn: bad shape M=%ld N=%ld K=%ld (M, N multiples of 8)", (long)M, (long)N, (long)K);
+    RGA3_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "gemm_tn: lda/ldb must be multiples of 8 elements");
+    RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "gemm_tn: pointers must be 16-byte aligned");
+    RGA3_CHECK_ARG(out_dtype == RGA3_BF16 || out_dtype == RGA3_F32, "gemm_tn: out_dtype %d", out_dtype);
+    RGA3_CHECK_ARG(cdiv(M, 128) <= 65535, "gemm_tn: M too large");
+    GemmArgs a;
+    a.A = nullptr; a.W = nullptr; a.C = C;
+    a.bias = (const unsigned short*)bias; a.res = nullptr; a.colscale = nullptr;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = 0; a.ldw = 0; a.ldc = ldc; a.ldr = 0;
+    a.ntm = (int)cdiv(M, 128); a.ntn = (int)cdiv(N, 128); a.group_m = 1;
+    a.ws = nullptr; a.ws_bytes = 0; a.dbg = 0;
+    TnArgs t;
+    t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
+    dim3 grid((unsigned)a.ntn, (unsigned)a.ntm);
+    if (out_dtype == RGA3_F32) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, t);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, t);
+    RGA3_CHECK_LAUNCH("gemm_tn_kernel");
+    return 0;
 }

@@ -32,7 +32,10 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             da = ops.gemm(dy, ops.transpose(w.detach()))            # [M, K] = dy @ w   (ops.gemm pads ragged reduction dims)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(ops.transpose(dy), ops.transpose(a.detach())).to(w.dtype)   # [N, K] = dy^T @ a
+            if dy.shape[0] <= 16384:
+                dw = ops.gemm_tn(dy, a.detach()).to(w.dtype)                              # [N, K] = dy^T @ a, contraction over rows as they lie
+            else:   # per-pixel products (10^6 rows): transposed operands + the split-K tiling
+                dw = ops.gemm(ops.transpose(dy), ops.transpose(a.detach())).to(w.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy).to(torch.bfloat16)
         return da, dw, db, dres, None, None

@@ -109,6 +109,23 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None) -> torch.Tensor:
+    """out [M, N] = a^T @ b for a [K, M], b [K, N] bf16 (row stride free): dW = dY^T X without transposing either operand."""
+    _need_cuda(a, b, out)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    K, M = a.shape
+    N = b.shape[1]
+    if M % 8 or N % 8 or a.stride(0) % 8 or b.stride(0) % 8:   # ragged widths: the NT kernel pads its reduction dim, which is what these are there
+        return gemm(transpose(a), transpose(b), out_dtype=out_dtype, out=out)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == out_dtype
+    _lib.check(_lib.load().rga3_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                             BF16 if out_dtype == torch.bfloat16 else F32, _stream()), "gemm_tn_bf16")
+    return out
+
+
 def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = False, out=None, return_lse=False,
                 impl: int = 0):
     """softmax(q k^T * scale) v over packed variable-length segments.

@@ -265,25 +265,15 @@ class DecoderLayerFn(torch.autograd.Function):
             dh1 = _fgemm(dqkv2, at, "wqkv_t", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: ops.transpose(wqkv))   # [T, H]
             grads = [None, None, None, None]
             if lq is not None or lv is not None:
-                h1_t = ops.transpose(h1)                                                # [H, T]
                 for slot, lp, t_, cols, pdrop, hin, sd in ((0, lq, tq, (0, Hq * D), pq, hq_in, 0), (2, lv, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D), pv, hv_in, 1)):
                     if lp is None:
                         continue
                     A, B, s = lp
                     dsl = dqkv2[:, cols[0]:cols[1]]                                    # [T, out]
-                    Tp = (T + 7) // 8 * 8
-                    dsl_t = ops.transpose(dsl)                                          # [out, T]
-                    t_t = ops.transpose(t_)                                             # [r, T]
-                    if Tp != T:
-                        dsl_t, t_t = ops.pad_cols(dsl_t, Tp), ops.pad_cols(t_t, Tp)
-                    dB = ops.gemm(dsl_t, t_t)                                           # [out, r] = dsl^T t
+                    dB = ops.gemm_tn(dsl, t_)                                           # [out, r] = dsl^T t  (contraction over tokens, no transposes)
                     dB = (dB.float() * s).to(B.dtype)
                     dt = ops.gemm(dsl, (ops.transpose(B.detach()) * s).to(B.dtype))     # [T, r] = s * dsl B
-                    dt_t = ops.transpose(dt)
-                    h1_tp = h1_t if pdrop == 0.0 else ops.transpose(hin)                # lora_A saw the dropped input
-                    if Tp != T:
-                        dt_t, h1_tp = ops.pad_cols(dt_t, Tp), ops.pad_cols(h1_tp, Tp)
-                    dA = ops.gemm(dt_t, h1_tp)                                          # [r, H] = dt^T dropout(h1)
+                    dA = ops.gemm_tn(dt, h1 if pdrop == 0.0 else hin)                   # [r, H] = dt^T dropout(h1): lora_A saw the dropped input
                     if pdrop == 0.0:
                         ops.gemm(dt, ops.transpose(A.detach()), residual=dh1, out=dh1)  # dh1 += dt A
                     else:                                                               # dh1 += mask / keep * (dt A): same seed, same mask
@@ -346,12 +336,7 @@ class NormHeadCEFn(torch.autograd.Function):
         with torch.no_grad():
             if float(gloss) != 1.0:
                 dlogits = (dlogits.float() * float(gloss)).to(dlogits.dtype)
-            npad = (n + 7) // 8 * 8
-            dl_t = ops.transpose(dlogits)                       # [V, n]
-            hv_t = ops.transpose(hv)                            # [H, n]
-            if npad != n:
-                dl_t, hv_t = ops.pad_cols(dl_t, npad), ops.pad_cols(hv_t, npad)
-            dW = ops.gemm(dl_t, hv_t) if lm_w.requires_grad else None      # [V, H]
+            dW = ops.gemm_tn(dlogits, hv) if lm_w.requires_grad else None    # [V, H] = dlogits^T hv
             dhv = ops.gemm(dlogits, ops.transpose(lm_w.detach()))            # [n, H]
             dhn = ghn.contiguous().clone() if ghn is not None else torch.zeros_like(h)   # gradient arriving through hidden_states[-1]
             dhn_rows = ops.add(ops.gather_rows(dhn, rows), dhv)

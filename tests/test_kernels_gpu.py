@@ -273,3 +273,23 @@ def test_gemm_split_k_small_outputs(dev, M, N, K, f32):
     if not f32:
         ref = ref.to(torch.bfloat16).float()
     assert _rel_l2(out, ref) < (1e-4 if f32 else 5e-3), (M, N, K)
+
+
+@pytest.mark.parametrize("K,M,N", [(2112, 128, 3584), (2112, 3584, 128), (6, 1024, 512), (300, 264, 136), (33, 8, 8), (4096, 512, 4608), (1000, 152064 // 8, 64)])
+@pytest.mark.parametrize("f32", [False, True])
+def test_gemm_tn_weight_gradient_product(dev, K, M, N, f32):
+    """C = A^T B over row-major [K, M] / [K, N] operands (dW = dY^T X) vs fp32 matmul; strided views (column slices of a wider buffer) included."""
+    from rga3.hip import ops
+
+    torch.manual_seed(K + M + N)
+    wide = torch.randn(K, M + 16, device=dev).to(torch.bfloat16)
+    a = wide[:, 8:8 + M]                      # row stride M + 16, 16-byte aligned column offset
+    b = torch.randn(K, N, device=dev).to(torch.bfloat16)
+    got = ops.gemm_tn(a, b, out_dtype=torch.float32 if f32 else torch.bfloat16)
+    want = a.float().T @ b.float()
+    assert got.shape == (M, N)
+    tol = (2e-5 if f32 else 6e-3)
+    assert float((got.float() - want).norm() / want.norm()) < tol
+    assert float((got.float() - want).abs().max()) <= (1e-3 if f32 else 2.0 ** -7) * float(want.abs().max()) + 1e-4
+    again = ops.gemm_tn(a, b, out_dtype=torch.float32 if f32 else torch.bfloat16)
+    assert torch.equal(got, again)
