@@ -582,12 +582,15 @@ struct SkArgs {
     int all_partial;  // split-K mode (tile 25): every slice only writes its slab; gemm_slab_reduce_kernel sums them afterwards
 };
 
-template <int ACT, bool OUT_F32>
+// MH = 16-row m-tiles per A half-tile and wave row: 4 -> 256-row tiles, 3 -> 192-row tiles (M = 2112 = 11 x 192: no padded tile row;
+// the A half-tiles then hold 96 rows in their 128-row LDS regions, and waves 4-7 repeat the second staging piece of waves 0-3 so that
+// every wave still issues two loads per half-tile and the counted vmcnt schedule is the same).
+template <int ACT, bool OUT_F32, int MH = 4>
 __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) {
-    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
+    constexpr int BM = 64 * MH, BN = 256, BK = 64, ROWB = 128;
     constexpr int HALF = 128 * ROWB;
     constexpr int BUF = 4 * HALF;
-    constexpr int MT = 8, NTL = 4;
+    constexpr int MT = 2 * MH, NTL = 4;
     constexpr int EPW = epi_wave_bytes<NTL, ACT, OUT_F32>();
     // epilogue staging lives in the A1 / B1 regions of buffer 0 (waves 0-3 / 4-7) so that the next item's first six
     // half-tiles (buffer 1 complete, A0 + B0 of buffer 0) can be in flight during the epilogue; the f32 epilogue needs
@@ -655,9 +658,12 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (wid + 8 * i) * 8 + (lane >> 3);
+            // A: LDS row ra of a half-tile holds the wave row's (ra / (16 MH)) rows h * 16 MH + ra % (16 MH); with MH = 3 the second piece
+            // of waves 4-7 (rows 96..127 do not exist) repeats the one of waves 0-3
+            const int ra = (MH == 4) ? r : ((i == 0 ? wid : 8 + (wid & 3)) * 8 + (lane >> 3));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int arow = (r >> 6) * 128 + h * 64 + (r & 63);
+                const int arow = (ra / (16 * MH)) * (32 * MH) + h * (16 * MH) + (ra % (16 * MH));
                 const int bcol = (r >> 5) * 64 + h * 32 + (r & 31);
                 soff[h][i] = (unsigned)((long)min(nm0 + arow, p.M - 1) * p.lda + sch * 8);
                 soff[2 + h][i] = (unsigned)((long)min(nn0 + bcol, p.N - 1) * p.ldw + sch * 8);
@@ -668,11 +674,13 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
         constexpr int kind = decltype(KIND)::value;
         const unsigned short* base = ((kind < 2) ? p.A : p.W) + (long)kt * BK;  // scalar part first: saddr + 32-bit voffset form
         char* dst = smem + buf * BUF + kind * HALF + wid * 1024;
+        // second piece: 8 KiB further on; the 96-row A half-tiles (MH = 3) put it at piece 8 + (wid & 3) (waves 4-7 rewrite what waves 0-3 write)
+        const int second = (MH == 3 && kind < 2) ? (8 + (wid & 3) - wid) * 1024 : 8192;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             unsigned o = soff[kind][i];
             asm volatile("" : "+v"(o));  // keep the offsets 32-bit in registers (the compiler otherwise holds 8 zero-extended pairs)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(dst + i * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(dst + i * second), 16, 0, 0);
         }
     };
     using K_A0 = std::integral_constant<int, 0>;
@@ -701,14 +709,14 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     int foff[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + (((kk * 4 + (lane >> 4)) ^ ((lane >> 1) & 7)) << 4);
-    const int a_rd = (wr * 64) * ROWB;
+    const int a_rd = (wr * 16 * MH) * ROWB;
     const int b_rd = 2 * HALF + (wc * 32) * ROWB;
 
     f32x4 acc[MT][NTL];
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    bf16x8 af[MH][2], b0[2][2], b1[2][2];
     auto read_a = [&](const char* cur, int h) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8*)(cur + a_rd + h * HALF + mi * 2048 + foff[kk]);
     };
@@ -728,10 +736,10 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    mfma_inplace(acc[ha * 4 + mi][hb * 2 + ni], bf[ni][kk], af[mi][kk]);
+                    mfma_inplace(acc[ha * MH + mi][hb * 2 + ni], bf[ni][kk], af[mi][kk]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -841,7 +849,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 part1 = (const f32x4*)sk.slabs + (size_t)(w - 1) * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
                 if (two) part2 = part1 - 512 * 32;
             }
-            gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32>(acc, p, est, lane_e, m0, n0, wr, wc, part1, part2);
+            gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32>(acc, p, est, lane_e, m0, n0, wr, wc, part1, part2);
             if (cur_kind == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();  // every wave has consumed its slab values ...
@@ -945,13 +953,13 @@ static int sk_workspace(void* ws, int64_t ws_bytes, SkWorkspace& out) {
 template <int ACT, bool OUT_F32>
 static int launch_pp(const GemmArgs& a0, hipStream_t st);
 
-template <int ACT, bool OUT_F32>
+template <int ACT, bool OUT_F32, int MH = 4>
 static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
     void* ws_ptr = a0.ws; const int64_t ws_bytes = a0.ws_bytes;
     GemmArgs a = a0;
-    a.ntm = (int)cdiv(a.M, 256);
+    a.ntm = (int)cdiv(a.M, 64 * MH);
     a.ntn = (int)cdiv(a.N, 256);
-    a.group_m = pick_group_m(a.ntm, 256);
+    a.group_m = pick_group_m(a.ntm, 64 * MH);
     SkWorkspace ws;
     if (a.K % 64 != 0) return launch_pp<ACT, OUT_F32>(a0, st);  // ragged K: zero-source tail lives in the one-tile kernel
     ws.P = cu_count();
@@ -988,7 +996,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.all_partial = 0;
     }
     constexpr int LDS = 2 * 4 * 128 * 128;
-    auto kern = gemm_nt_sk_kernel<ACT, OUT_F32>;
+    auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, MH>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1206,6 +1214,8 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 20: return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
         case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
+        case 31: return launch_sk<ACT, OUT_F32, 3>(a, false, st);   // 192 x 256 tiles, persistent
+        case 32: return launch_sk<ACT, OUT_F32, 3>(a, true, st);    // ... + stream-K tail
         case 25: return launch_splitk<ACT, OUT_F32>(a, st);
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);
     }
@@ -1242,7 +1252,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 12) || (tile >= 20 && tile <= 22) || tile == 25, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 12) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;

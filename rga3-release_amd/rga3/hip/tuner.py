@@ -14,8 +14,9 @@ import os
 
 import torch
 
-CANDIDATES = (20, 21, 22, 11, 12, 3, 4)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
-                                       # single-phase 256x128, 128x128, 128x256, 128x320
+CANDIDATES = (20, 21, 22, 31, 32, 11, 12, 3, 4)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
+                                               # 192x256 persistent / + stream-K tail (M = 2112 = 11 x 192); single-phase 256x128, 128x128,
+                                               # 128x256, 128x320
 _cache = {}
 _times = {}   # key -> {tile: ms of 3 launches} (diagnostic, see table())
 _enabled = os.environ.get("RGA3_GEMM_TUNE", "1") != "0"

@@ -25,7 +25,7 @@ def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed / mis-mapped C fragment layout."""
     from rga3.hip import ops
 
-    for tile in (3, 4, 10, 11, 12, 20, 21, 22):
+    for tile in (3, 4, 10, 11, 12, 20, 21, 22, 31, 32):
         n, k = 256, 256
         a = torch.eye(k, dtype=torch.bfloat16, device=dev)
         w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(torch.bfloat16).to(dev)
@@ -35,7 +35,7 @@ def test_gemm_identity_asymmetric(dev):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (2112, 512, 3584), (8192, 1280, 1280), (64, 3456, 1280),
                                    (17, 24, 64), (1000, 152064 // 16, 192)])
-@pytest.mark.parametrize("tile", [-1, 3, 4, 10, 11, 12, 20, 21, 22])
+@pytest.mark.parametrize("tile", [-1, 3, 4, 10, 11, 12, 20, 21, 22, 31, 32])
 def test_gemm_plain(dev, M, N, K, tile):
     from rga3.hip import ops
 
@@ -46,14 +46,14 @@ def test_gemm_plain(dev, M, N, K, tile):
 
 
 def test_gemm_stream_k_split_shapes(dev):
-    """Tile 22 on shapes whose last round is split over K (1, 2 contributors per tile, ragged M): equal to the unsplit result up to
+    """Tiles 22 / 32 (256- / 192-row stream-K) on shapes whose last round is split over K (1, 2 contributors per tile, ragged M): equal to the unsplit result up to
     the f32 re-association of the split tiles, reproducible run to run, and no slab wait ever timed out."""
     from rga3.hip import lib, ops
 
     for (M, N, K) in [(2112, 3584, 3584), (2112, 4608, 3584), (2000, 5120, 2048), (8192, 1280, 1280), (300, 70000 // 8 * 8, 512)]:
         a, w = _rand((M, K), dev, seed=11), _rand((N, K), dev, 0.05, seed=12)
         ref = ops.gemm(a, w, tile=20)
-        for tl in (22,):
+        for tl in (22, 32):
             o1 = ops.gemm(a, w, tile=tl)
             o2 = ops.gemm(a, w, tile=tl)
             assert torch.equal(o1, o2), (M, N, K, tl)
@@ -62,7 +62,7 @@ def test_gemm_stream_k_split_shapes(dev):
 
 
 @pytest.mark.parametrize("act", ["none", "gelu", "relu", "swiglu"])
-@pytest.mark.parametrize("tile", [3, 4, 10, 11, 12, 20, 21, 22])
+@pytest.mark.parametrize("tile", [3, 4, 10, 11, 12, 20, 21, 22, 31, 32])
 def test_gemm_epilogues(dev, act, tile):
     from rga3.hip import ops
 

@@ -11,11 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
 from rga3.hip import ops  # noqa: E402
 
-SHAPES = [(8192, 3840, 1280, (21, 4)), (8192, 1280, 1280, (4, 21)), (8192, 6912, 1280, (22, 21)), (8192, 1280, 3456, (4, 22)),
-          (2112, 4608, 3584, (4, 21)), (2112, 3584, 3584, (3, 11, 22)), (2112, 37888, 3584, (22,)), (2112, 3584, 18944, (22,))]
+SHAPES = [(8192, 3840, 1280, (21, 4, 31)), (8192, 1280, 1280, (4, 21)), (8192, 6912, 1280, (22, 21, 32)), (8192, 1280, 3456, (4, 22, 32)),
+          (2112, 4608, 3584, (4, 21, 31, 32)), (2112, 3584, 3584, (3, 11, 22, 31, 32)), (2112, 37888, 3584, (22, 31, 32)), (2112, 3584, 18944, (22, 32)),
+          (2112, 152064, 3584, (21, 31, 32))]
 res = []
 for (M, N, K, tiles) in SHAPES:
-    nbuf = max(2, int(1.2e9 / (N * K * 2)) + 1)
+    nbuf = max(2, min(int(1.2e9 / (N * K * 2)) + 1, 24))
     ws = [(torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16) for _ in range(nbuf)]
     nact = max(2, int(0.6e9 / (M * K * 2)) + 1)
     acts = [torch.randn(M, K, device="cuda").to(torch.bfloat16) for _ in range(nact)]
