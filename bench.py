@@ -133,10 +133,10 @@ def sam2_stream(args, dev, rank, world, dist):
         s0 = VideoSession(m.sam2_model, vid)
         feats = s0._ensure_feats()          # image encoder, once (kept across steps: the timed region is the memory path)
 
-        def step():
+        def step(use_graph=True):
             sess = VideoSession(m.sam2_model, vid, feats=feats)
             sess.add_language_embd(0, emb)
-            return sess, sess.propagate()
+            return sess, sess.propagate(use_graph=use_graph and not args.no_graph)   # steady-state frames (16..) replay one captured hipGraph
 
         for _ in range(args.warmup):
             step()
@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--stream-frames", type=int, default=32)
     ap.add_argument("--grad-accum", type=int, default=4)
     ap.add_argument("--no-fp8", action="store_true", help="lora_fp8 mode with bf16 GEMMs (A/B)")
+    ap.add_argument("--no-graph", action="store_true", help="sam2_stream mode: run every frame eagerly (A/B of the hipGraph replay)")
     ap.add_argument("--no-refine", action="store_true", help="forward mode: skip the in-situ tile refinement (A/B)")
     ap.add_argument("--refine", action="store_true", help="training modes, 1 GPU: run the in-situ tile refinement before the warmup")
     ap.add_argument("--sam-frames", type=int, default=16)

@@ -779,6 +779,8 @@ class VideoSession:
     sam2.py:3771-4132).  Image features are computed once per frame and kept; the memory encoder runs only for frames
     whose memory can be read by a later frame."""
 
+    _uids = 0
+
     def __init__(self, model: SAM2VideoPredictor, images, feats=None, chunk=8):
         self.m, self.images = model, images
         self.num_frames = images.shape[0]
@@ -788,6 +790,8 @@ class VideoSession:
         self.counts = {"enc": 0, "memattn": 0, "memenc": 0, "dec": 0}
         self.feats = feats
         self.chunk = chunk
+        VideoSession._uids += 1
+        self.uid = VideoSession._uids
 
     def _ensure_feats(self):
         if self.feats is None:
@@ -859,15 +863,100 @@ class VideoSession:
         self.counts["memattn"] += 1
         return m.memory_attention(self._frame_tokens(t), self._ensure_feats()["pos"], memory, mpos, n_ptr)
 
-    def propagate(self):
-        """Yields (frame_idx, masks [1, 1, S, S] f32) for every frame from the first conditioning frame on."""
+    # -- frames as hipGraph replays ------------------------------------------------------------------------------------------
+    # With one conditioning frame the bank of frame t depends only on d = t - start: min(d-1, 6) earlier non-conditioning memories, always in
+    # the same slots (slot = age, so the memory positions are constants), and min(d-1, 15) + 1 pointers; from d = 16 on nothing changes
+    # shape any more.  A frame is then a pure function of (its tokens, its two high-resolution feature maps, the bank) made of ~200 short
+    # launches -- 2 % MFMA use, bounded by launch / ramp latency -- so each of the 16 bank states is captured ONCE per model into a graph
+    # over static buffers and replayed for every later frame and stream: per frame the host issues the copies into the static inputs, one
+    # graph launch and the copies out.  The captured launches read the weights through their pointers, so weight updates are seen.
+    def _graph_frame(self, t, start):
+        m, f = self.m, self._ensure_feats()
+        h, w = f["hw"]
+        hw, dev = h * w, f["feat"].device
+        n_mem = m.num_maskmem
+        max_pp = min(self.num_frames, m.max_obj_ptrs_in_encoder) - 1
+        k = m.hidden_dim // m.mem_dim
+        d = t - start
+        n_nc, n_pp = min(d - 1, n_mem - 1), min(d - 1, max_pp)        # earlier non-conditioning memories / pointers in the bank
+        cond = self.cond[start]
+        cache = m.__dict__.setdefault("_frame_graphs", {})
+        if "pool" not in cache:
+            cache["pool"] = torch.cuda.graph_pool_handle()           # the graphs never run concurrently: one private pool for all
+        key = (hw, n_nc, n_pp, str(dev), f["feat"].dtype)
+        ent = cache.get(key)
+        fresh = ent is None
+        if fresh:
+            G = {"tok": torch.empty_like(f["feat"][:hw]), "s0": torch.empty_like(f["feat_s0"][:16 * hw]), "s1": torch.empty_like(f["feat_s1"][:4 * hw]),
+                 "mem": torch.empty(((1 + n_nc) * hw + (1 + n_pp) * k, m.mem_dim), dtype=cond["maskmem_features"].dtype, device=dev),
+                 "pos": torch.empty_like(f["pos"])}
+            G["mem_pos"] = torch.empty_like(G["mem"])
+            ent = cache[key] = {"G": G, "session": -1}
+        G = ent["G"]
+        p0 = (1 + n_nc) * hw                                             # first pointer row
+        if ent["session"] != self.uid:
+            # constant part of the bank for this session: the conditioning frame's memory and pointer, all positions (the memory encoder's
+            # position map is the same for every frame, pointers carry none)
+            G["pos"].copy_(f["pos"])
+            G["mem"][:hw].copy_(cond["maskmem_features"])
+            G["mem"][p0:p0 + k].copy_(cond["obj_ptr"].reshape(-1, m.mem_dim))
+            G["mem_pos"][:hw].copy_(ops.add_bcast(cond["maskmem_pos_enc"], m.maskmem_tpos_enc[n_mem - 1].view(1, -1)))
+            for i in range(n_nc):                                        # slot i holds frame t - n_nc + i, i.e. t_pos = n_mem - n_nc + i
+                t_pos = n_mem - n_nc + i
+                G["mem_pos"][(1 + i) * hw:(2 + i) * hw].copy_(ops.add_bcast(cond["maskmem_pos_enc"], m.maskmem_tpos_enc[n_mem - t_pos - 1].view(1, -1)))
+            G["mem_pos"][p0:].zero_()
+            ent["session"] = self.uid
+        feats1 = {"feat_s0": G["s0"], "feat_s1": G["s1"], "feat": G["tok"], "hw": (h, w), "n": 1, "pos": G["pos"]}
+        S = m.image_size
+
+        def body():
+            pix = m.memory_attention(G["tok"], G["pos"], G["mem"], G["mem_pos"], (1 + n_pp) * k)
+            o = m.forward_sam_heads(pix, feats1, None, frame_slice=(0, 1))
+            mf, _ = m.encode_new_memory(feats1, 0, o["high_res_masks"])
+            pm = o["low_res_masks"]
+            mask = ops.bilinear(pm.reshape(1, *pm.shape[-2:]).float().contiguous(), (S, S)).unsqueeze(0)
+            return pm, o["obj_ptr"], mf, mask
+
+        G["tok"].copy_(f["feat"][t * hw:(t + 1) * hw])
+        G["s0"].copy_(f["feat_s0"][t * 16 * hw:(t + 1) * 16 * hw])
+        G["s1"].copy_(f["feat_s1"][t * 4 * hw:(t + 1) * 4 * hw])
+        if n_nc:
+            torch.cat([self.non_cond[t - n_nc + i]["maskmem_features"] for i in range(n_nc)], dim=0, out=G["mem"][hw:p0])
+        if n_pp:
+            torch.cat([self.non_cond[t - dd]["obj_ptr"].reshape(-1, m.mem_dim) for dd in range(1, n_pp + 1)], dim=0, out=G["mem"][p0 + k:])
+        if fresh:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):      # warm-up on a side stream: tuner picks, workspaces and lazily built tables exist before capture
+                body()
+            torch.cuda.current_stream().wait_stream(side)
+            ent["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent["graph"], pool=cache["pool"]):
+                ent["outs"] = body()
+        ent["graph"].replay()
+        pm, ptr, mf, mask = ent["outs"]
+        return pm.clone(), ptr.clone(), mf.clone(), mask.clone()
+
+    def propagate(self, use_graph: bool = False):
+        """Yields (frame_idx, masks [1, 1, S, S] f32) for every frame from the first conditioning frame on.  use_graph: frames in steady
+        streams with one conditioning frame run every later frame as the replay of a captured hipGraph (one per bank state, kept on the
+        model) -- same kernels, same results."""
         S = self.m.image_size
         all_cond = set(self.temp_cond) | set(self.cond)
         start = min(all_cond)
         need_memory = any(t not in all_cond for t in range(start, self.num_frames))
         self._preflight(need_memory)
         res = []
+        graphed = use_graph and len(self.cond) == 1 and not _ag()
         for t in range(start, self.num_frames):
+            if graphed and t not in self.cond:
+                pm, ptr, mf, mask = self._graph_frame(t, start)
+                self.counts["memattn"] += 1
+                self.counts["dec"] += 1
+                self.counts["memenc"] += 1
+                self.non_cond[t] = {"pred_masks": pm, "obj_ptr": ptr, "maskmem_features": mf, "maskmem_pos_enc": self.cond[start]["maskmem_pos_enc"]}
+                res.append((t, mask))
+                continue
             if t in self.cond:
                 pm = self.cond[t]["pred_masks"]
             else:

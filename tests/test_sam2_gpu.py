@@ -117,3 +117,32 @@ def test_frame0_prompt_propagation(model, dev, P, G):
     masks, rmasks = torch.cat([m for _, m in res]), torch.cat([m for _, m in rres])
     assert rel(masks, rmasks) < 6e-2
     assert np.mean([iou(masks[t] > 0, rmasks[t] > 0) for t in range(5)]) >= 0.98
+
+
+def test_graph_replay_equals_eager_stream(model, dev):
+    """A 24-frame stream prompted on frame 0: every later frame runs as the replay of a captured hipGraph over static buffers (one graph per
+    bank state: 15 growing states, then the steady one); masks, pointers and memories must equal the eager frame-by-frame path bit for bit
+    (same kernels, same inputs), also for a second session that reuses the graphs kept on the model."""
+    from rga3.model.sam2 import VideoSession
+
+    torch.manual_seed(5)
+    T = 24
+    vid = (torch.randn(T, 3, 128, 128) * 0.5).to(torch.bfloat16).to(dev)
+    emb = torch.randn(1, 1, 256).to(torch.bfloat16).to(dev)
+    with torch.no_grad():
+        a = VideoSession(model.sam2_model, vid)
+        a.add_language_embd(0, emb)
+        ra = a.propagate()
+        b = VideoSession(model.sam2_model, vid, feats=a.feats)
+        b.add_language_embd(0, emb)
+        rb = b.propagate(use_graph=True)
+        c = VideoSession(model.sam2_model, vid, feats=a.feats)     # a second session captures its own graph: nothing is shared between them
+        c.add_language_embd(0, emb)
+        rc = c.propagate(use_graph=True)
+    assert len(ra) == len(rb) == len(rc) == T and b.counts["memattn"] == a.counts["memattn"] == T - 1
+    for (ta, ma), (tb, mb), (tc, mc) in zip(ra, rb, rc):
+        assert ta == tb == tc and torch.equal(ma, mb) and torch.equal(ma, mc), ta
+    for t in range(1, T - 1):
+        assert torch.equal(a.non_cond[t]["obj_ptr"], b.non_cond[t]["obj_ptr"]) and torch.equal(a.non_cond[t]["obj_ptr"], c.non_cond[t]["obj_ptr"])
+        assert torch.equal(a.non_cond[t]["maskmem_features"], b.non_cond[t]["maskmem_features"])
+    assert len(model.sam2_model._frame_graphs) == 16 + 1   # 16 bank states + the shared pool handle
