@@ -14,8 +14,8 @@ import os
 
 import torch
 
-CANDIDATES = (20, 21, 22, 31, 32, 11, 12, 3, 4)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
-                                               # 192x256 persistent / + stream-K tail (M = 2112 = 11 x 192); single-phase 256x128, 128x128,
+CANDIDATES = (20, 21, 22, 31, 32, 12, 13, 3, 4)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail;
+                                               # 192x256 persistent / + stream-K tail (M = 2112 = 11 x 192); single-phase 128x128, 64x64,
                                                # 128x256, 128x320
 _cache = {}
 _times = {}   # key -> {tile: ms of 3 launches} (diagnostic, see table())
