@@ -1180,6 +1180,124 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
     gemm_epilogue<4, 4, 64, 64, ACT_NONE, OUT_F32>(acc, p, smem, lane, m0, n0, wm, wn);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Skinny product for the decode step of generate() (reference app.py:308-317): M <= 4 activation rows against a whole weight matrix.
+// Every weight byte is used once, so this is an HBM stream, not an MFMA problem (Qwen2.5-7B: 15.2 GB of weights per token; the tiled
+// kernels above would pad M to 128-256 rows).  One wave owns CW output columns at a time: lane l reads the 16-byte chunks l, l+64, ...
+// of each of its weight rows (coalesced 1 KiB per row and step, CW independent rows in flight) and of the activation rows (L1 / L2
+// resident), accumulates in fp32 and wave-reduces.  Epilogue semantics equal gemm_epilogue's (bias, bf16 rounding before the
+// activation, SwiGLU on the 16/16 interleaved gate/up row blocks, residual), so a decode step rounds exactly like a prefill row.
+struct GemvArgs {
+    const unsigned short* A;   // [M, K]
+    const unsigned short* W;   // [N, K]
+    void* C;
+    const unsigned short* bias;
+    const unsigned short* res;
+    int M, N, K;               // N = weight rows (SwiGLU: 2 x outputs)
+    long lda, ldw, ldc, ldr;
+};
+
+__device__ __forceinline__ float dot8(const u32x4& a, const u32x4& b, float acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        acc = fmaf(__uint_as_float(a[e] << 16), __uint_as_float(b[e] << 16), acc);
+        acc = fmaf(__uint_as_float(a[e] & 0xffff0000u), __uint_as_float(b[e] & 0xffff0000u), acc);
+    }
+    return acc;
+}
+
+template <int MR, int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
+    constexpr int CW = 4;                                   // output columns per wave and pass
+    constexpr int RW = (ACT == ACT_SWIGLU) ? 2 * CW : CW;   // weight rows per wave and pass
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int Nout = (ACT == ACT_SWIGLU) ? p.N / 2 : p.N;
+    const int o0 = wave * CW;
+    if (o0 >= Nout) return;
+    // weight rows of this wave's outputs (SwiGLU packing: 32-row blocks = 16 gate rows, then the 16 up rows of the same outputs)
+    const unsigned short* wrow[RW];
+#pragma unroll
+    for (int cidx = 0; cidx < CW; ++cidx) {
+        const int o = min(o0 + cidx, Nout - 1);
+        if constexpr (ACT == ACT_SWIGLU) {
+            wrow[2 * cidx] = p.W + (long)((o >> 4) * 32 + (o & 15)) * p.ldw;
+            wrow[2 * cidx + 1] = p.W + (long)((o >> 4) * 32 + 16 + (o & 15)) * p.ldw;
+        } else {
+            wrow[cidx] = p.W + (long)o * p.ldw;
+        }
+    }
+    float acc[MR][RW];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[m][r] = 0.f;
+    const int nch = p.K >> 3;
+    for (int ch = lane; ch < nch; ch += 64) {
+        u32x4 w[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) w[r] = *(const u32x4*)(wrow[r] + ch * 8);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const u32x4 x = *(const u32x4*)(p.A + (long)min(m, p.M - 1) * p.lda + ch * 8);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[m][r] = dot8(w[r], x, acc[m][r]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[m][r] = wave_sum(acc[m][r]);
+    if (lane >= CW * MR) return;
+    const int cidx = lane % CW, m = lane / CW;
+    const int o = o0 + cidx;
+    if (o >= Nout || m >= p.M) return;
+    float v = 0.f;
+    // pick this lane's (m, column) out of the fully unrolled accumulator file
+#pragma unroll
+    for (int mm = 0; mm < MR; ++mm)
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc)
+            if (mm == m && cc == cidx) {
+                if constexpr (ACT == ACT_SWIGLU) {
+                    float gt = acc[mm][2 * cc], up = acc[mm][2 * cc + 1];
+                    if (p.bias) {
+                        gt += bf2f(p.bias[(o >> 4) * 32 + (o & 15)]);
+                        up += bf2f(p.bias[(o >> 4) * 32 + 16 + (o & 15)]);
+                    }
+                    gt = bf2f(f2bf(gt));
+                    up = bf2f(f2bf(up));
+                    v = bf2f(f2bf(silu_f(gt))) * up;
+                } else {
+                    float x = acc[mm][cc];
+                    if (p.bias) x += bf2f(p.bias[o]);
+                    if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
+                    if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
+                    v = x;
+                }
+            }
+    if constexpr (OUT_F32) {
+        ((float*)p.C)[(long)m * p.ldc + o] = v;
+    } else {
+        if (p.res) v = bf2f(f2bf(v)) + bf2f(p.res[(long)m * p.ldr + o]);
+        ((unsigned short*)p.C)[(long)m * p.ldc + o] = f2bf(v);
+    }
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_gemv(const GemmArgs& a, hipStream_t st) {
+    GemvArgs g;
+    g.A = a.A; g.W = a.W; g.C = a.C; g.bias = a.bias; g.res = a.res;
+    g.M = a.M; g.N = a.N; g.K = a.K; g.lda = a.lda; g.ldw = a.ldw; g.ldc = a.ldc; g.ldr = a.ldr;
+    const int nout = (ACT == ACT_SWIGLU) ? a.N / 2 : a.N;
+    const unsigned grid = (unsigned)cdiv(nout, 16);
+    if (a.M == 1) hipLaunchKernelGGL((gemv_kernel<1, ACT, OUT_F32>), dim3(grid), dim3(256), 0, st, g);
+    else if (a.M == 2) hipLaunchKernelGGL((gemv_kernel<2, ACT, OUT_F32>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemv_kernel<4, ACT, OUT_F32>), dim3(grid), dim3(256), 0, st, g);
+    RGA3_CHECK_LAUNCH("gemv_kernel");
+    return 0;
+}
+
 // tile choice: fill the 256 CUs.  score = useful fraction of the last wave of tiles x a per-config prior.
 static int pick_tile(int M, int N, int K, bool plain, int forced) {
     if (forced >= 0) return forced;
@@ -1218,6 +1336,7 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 31: return launch_sk<ACT, OUT_F32, 3>(a, false, st);   // 192 x 256 tiles, persistent
         case 32: return launch_sk<ACT, OUT_F32, 3>(a, true, st);    // ... + stream-K tail
         case 25: return launch_splitk<ACT, OUT_F32>(a, st);
+        case 40: return launch_gemv<ACT, OUT_F32>(a, st);   // M <= 4: weight stream (decode step)
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);
     }
 }
@@ -1253,7 +1372,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 13) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 13) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;
@@ -1268,7 +1387,8 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     static const int dbg_flags = [] { const char* e = getenv("RGA3_GEMM_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg_flags;
     hipStream_t st = (hipStream_t)stream;
-    int tl = pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
+    RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
+    int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
     if (out_dtype == RGA3_F32) return launch_act<ACT_NONE, true>(a, tl, st);
     switch (act) {
         case ACT_NONE: return launch_act<ACT_NONE, false>(a, tl, st);

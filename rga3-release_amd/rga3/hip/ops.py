@@ -101,6 +101,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
         _lib.check(fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(colscale), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
                       out.stride(0), ldr, ACT[act], odt, t, ws.data_ptr(), ws.numel(), _stream()), "gemm_bf16")
 
+    if tile == -1 and M <= 4 and colscale is None:
+        tile = 40   # decode step: a weight stream, not a tiled product (gemv_kernel)
     if tile == -1 and M * N * K >= (1 << 24) and not (residual is not None and residual.data_ptr() == out.data_ptr()):
         # few output tiles over a very long K (weight gradients dW = dY^T X): also try the split-K form
         extra = (25,) if (M * N <= (1 << 20) and K >= 4096 and act == "none" and residual is None and colscale is None) else ()

@@ -378,7 +378,8 @@ class DecoderAttention(nn.Module):
         cu_k = cu
         if cache is not None:
             k, v, cu_k = cache.update(self.layer_idx, k, v, cu)
-        att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=True)
+        # decode step (one query per sequence): every cached key is visible, and the non-causal form may split the key range over workgroups
+        att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
         return self.o_proj(att.view(T, Hq * D), residual=residual)
 
 
@@ -404,12 +405,14 @@ class KVCache:
         self.lens = [0] * batch  # tokens stored per sequence (host)
         self.cap = cap
         self._new = None
+        self._cu = None
 
     def get_seq_length(self):
         return max(self.lens) if self.lens else 0
 
     def begin(self, new_lens):
         self._new = list(new_lens)
+        self._cu = None   # cu_k of this step: the same for every layer, built (one host -> device copy) by the first update()
 
     def update(self, layer, k, v, cu_q):
         """Append this step's packed k/v and return packed (k_all, v_all, cu_k) views for attention."""
@@ -429,7 +432,9 @@ class KVCache:
             kk, vv = ks[0], vs[0]
         else:
             kk, vv = torch.cat(ks), torch.cat(vs)
-        return kk, vv, torch.tensor(cu, dtype=torch.int32, device=k.device)
+        if self._cu is None:
+            self._cu = torch.tensor(cu, dtype=torch.int32, device=k.device)
+        return kk, vv, self._cu
 
     def commit(self):
         self.lens = [a + b for a, b in zip(self.lens, self._new)]

@@ -293,3 +293,30 @@ def test_gemm_tn_weight_gradient_product(dev, K, M, N, f32):
     assert float((got.float() - want).abs().max()) <= (1e-3 if f32 else 2.0 ** -7) * float(want.abs().max()) + 1e-4
     again = ops.gemm_tn(a, b, out_dtype=torch.float32 if f32 else torch.bfloat16)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("act,N,K,bias,res", [("none", 4608, 3584, True, False), ("none", 3584, 3584, False, True), ("swiglu", 37888, 3584, False, False),
+                                              ("none", 3584, 18944, False, True), ("gelu", 1000, 264, True, False), ("relu", 72, 64, True, False),
+                                              ("swiglu", 96, 136, True, False)])
+def test_gemv_decode_rows_match_tiled_gemm(dev, M, act, N, K, bias, res):
+    """The skinny weight-stream kernel (tile 40, picked for M <= 4: the decode step of generate()) against the fp32 oracle and against the tiled
+    kernel on the same rows embedded in a taller matrix: same epilogue semantics, so a decode row rounds like a prefill row (k-order differs)."""
+    from rga3.hip import ops
+
+    a, w = _rand((M, K), dev, seed=21), _rand((N, K), dev, 0.05, seed=22)
+    b = _rand((N,), dev, 0.1, seed=23) if bias else None
+    n_out = N // 2 if act == "swiglu" else N
+    r = _rand((M, n_out), dev, seed=24) if res else None
+    out = ops.gemm(a, w, b, residual=r, act=act)            # M <= 4 -> tile 40
+    tall = torch.cat([a, _rand((128 - M, K), dev, seed=25)])
+    rt = torch.cat([r, _rand((128 - M, n_out), dev, seed=26)]) if res else None
+    ref = ops.gemm(tall, w, b, residual=rt, act=act, tile=12)[:M]
+    assert out.shape == (M, n_out)
+    assert _rel_l2(out, ref.float().cpu()) < 4e-3
+    d = (out.float() - ref.float()).abs()
+    assert float((d > 0).float().mean()) < 0.15 and float(d.max()) <= 2.0 ** -6 * float(ref.float().abs().max()) + 1e-3
+    o32 = ops.gemm(a, w, b, out_dtype=torch.float32) if act == "none" and not res else None
+    if o32 is not None:
+        want = a.float() @ w.float().T + (b.float() if bias else 0)
+        assert float((o32 - want).norm() / want.norm()) < 1e-5
