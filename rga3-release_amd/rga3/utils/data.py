@@ -65,3 +65,32 @@ def make_batch(cfg, device, batch=1, frames_mllm=16, frames_sam=16, side=448, sa
                 video_grid_thw=torch.tensor([[gt, gh, gh]] * batch), second_per_grid_ts=torch.ones(batch), images_sam=to(images_sam),
                 offset=torch.arange(batch + 1), masks_list=[to(m) for m in masks], label_list=[torch.zeros(label_hw) for _ in range(batch)],
                 resize_list=[(sam_side, sam_side)] * batch, inference=False)
+
+
+# ------------------------------------------------------------------------------------------------ frame selection (host side)
+# What the reference's inference scripts do before any preprocessing (evaluation/mevis_val_u/inference_mevis.py:156-160 and the other
+# inference_*.py): choose num_frames_mllm frame indices of the clip for the MLLM, and num_frames_sam of those for SAM2
+# (reference utils/utils.py:201-229).  Pinned by tests/golden/frame_sampling.npz (made by executing the reference's functions).
+def _bin_centres(lo: int, hi: int, n: int):
+    """Centres (floor) of the n integer bins [e_i, e_{i+1} - 1] whose edges are the truncated np.linspace(lo, hi, n + 1)."""
+    edges = np.linspace(start=lo, stop=hi, num=n + 1).astype(int)
+    return ((edges[:-1] + edges[1:] - 1) // 2).tolist()
+
+
+def uniform_sample(total_len: int, sample_num: int):
+    """sample_num frame indices spread evenly over [0, total_len) (utils/utils.py:201-208)."""
+    return _bin_centres(0, total_len, sample_num)
+
+
+def get_sparse_indices(total_frame_num: int, num_frames_mllm: int):
+    """Sorted indices of the frames shown to the MLLM: even sampling of a long clip; a short clip is repeated whole
+    num_frames_mllm // total times plus an even sample of the remainder (utils/utils.py:211-219)."""
+    if total_frame_num > num_frames_mllm:
+        return sorted(uniform_sample(total_frame_num, num_frames_mllm))
+    rep, extra = divmod(num_frames_mllm, total_frame_num)
+    return sorted(list(range(total_frame_num)) * rep + uniform_sample(total_frame_num, extra))
+
+
+def get_dense_indices(num_frames_mllm: int, num_frames_sam: int):
+    """Positions (within the MLLM frame list) of the frames SAM2 segments (utils/utils.py:222-229: bins over [0, num_frames_mllm - 1])."""
+    return _bin_centres(0, num_frames_mllm - 1, num_frames_sam)

@@ -72,3 +72,26 @@ def test_stom_shift_and_mean_flow():
     tracks = np.stack([vip, tgt, vip])[None]
     out = ST.STOM().propagate_in_video(frames, src, 0, tracks=tracks, visibility=np.ones((1, 3, 40), bool))
     assert len(out) == 3 and out[1].shape == (20, 30, 3) and not np.array_equal(out[1], frames[1])
+
+
+def test_frame_sampling_matches_reference_tables():
+    """uniform_sample / get_sparse_indices / get_dense_indices (reference utils/utils.py:201-229) against tables produced by executing the
+    reference's own functions (tests/golden/make_frame_sampling_fixtures.py): integer outputs, bit-exact."""
+    import os
+
+    import numpy as np
+
+    from rga3.utils import data as D
+
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_sampling.npz"))
+    for row in G["uniform"].tolist():
+        total, n = row[:2]
+        assert D.uniform_sample(total, n) == row[2:2 + n], (total, n)
+    for row in G["sparse"].tolist():
+        total, n = row[:2]
+        got = D.get_sparse_indices(total, n)
+        assert got == row[2:2 + n] and got == sorted(got), (total, n)
+    for row in G["dense"].tolist():
+        nm, ns = row[:2]
+        assert D.get_dense_indices(nm, ns) == row[2:2 + ns], (nm, ns)
+    assert len(D.get_sparse_indices(3, 8)) == 8 and set(D.get_sparse_indices(3, 8)) == {0, 1, 2}
