@@ -441,6 +441,37 @@ class KVCache:
         self._new = None
 
 
+class StaticKVCache:
+    """Single-sequence cache view for the captured decode step: the same [1, cap, Hkv, D] buffers as KVCache, but the write position and the
+    visible length live ON THE DEVICE (len_dev / cu_dev), so one captured graph serves every step: the new k / v rows go in by a row scatter at
+    len_dev, attention sees the full-capacity buffer with cu_k = [0, len + 1], and advance() moves both inside the graph."""
+
+    def __init__(self, base: "KVCache", device):
+        assert len(base.lens) == 1
+        self.k, self.v, self.cap = base.k, base.v, base.cap
+        self.len_dev = torch.tensor([base.lens[0]], dtype=torch.int64, device=device)
+        self.cu_dev = torch.tensor([0, base.lens[0] + 1], dtype=torch.int32, device=device)
+
+    def reset(self, n_stored: int):
+        self.len_dev.fill_(n_stored)
+        self.cu_dev[1] = n_stored + 1
+
+    def begin(self, new_lens):
+        pass
+
+    def update(self, layer, k, v, cu_q):
+        ops.scatter_rows_(self.k[layer][0].view(self.cap, -1), self.len_dev, k.reshape(1, -1))
+        ops.scatter_rows_(self.v[layer][0].view(self.cap, -1), self.len_dev, v.reshape(1, -1))
+        return self.k[layer][0], self.v[layer][0], self.cu_dev
+
+    def commit(self):
+        pass
+
+    def advance(self):
+        self.len_dev += 1
+        self.cu_dev[1:] += 1
+
+
 class TextModel(nn.Module):
     def __init__(self, c: Qwen2_5_VLConfig):
         super().__init__()
@@ -639,6 +670,36 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
 
     # -- generation (greedy / sampling) --------------------------------------------------------------------
     @torch.no_grad()
+    def _capture_decode_step(self, cache, tok, pos_host):
+        """First decode step of a single-sequence generate(): run it eagerly on a side stream (tuner picks, workspaces), then capture the same
+        step over static inputs (token id, position, device-side cache length).  Returns the replay state; its "logits" are those of the step
+        just taken.  The eager step and the captured one write the same cache row, so the cache is consistent whichever ran last."""
+        dev = tok.device
+        n_stored = cache.lens[0]
+        st = {"tok": tok.clone(), "pos3": torch.from_numpy(np.broadcast_to(pos_host[None], (3, 1)).copy()).to(dev), "kv": StaticKVCache(cache, dev)}
+        st["cu_q"] = torch.tensor([0, 1], dtype=torch.int32, device=dev)   # every tensor the captured launches read must outlive the graph: keep it in st
+
+        def body():
+            h, _ = self.model(ops.gather_rows(self.model.embed_tokens.weight, st["tok"]), st["pos3"], st["cu_q"], 1, st["kv"])
+            lg = self.lm_head(h)
+            st["pos3"] += 1          # state of the NEXT step, advanced inside the graph
+            st["kv"].advance()
+            return lg
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream().wait_stream(side)
+        st["pos3"] -= 1                # rewind the state the warm-up advanced; the warm-up wrote cache row n_stored, the capture rewrites it
+        st["kv"].reset(n_stored)
+        st["graph"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(st["graph"]):
+            st["logits"] = body()
+        st["graph"].replay()          # capturing executes nothing: the state still says "this step" -- now run it for real
+        cache.lens[0] = n_stored      # the host-side bookkeeping of the eager cache is not used any more during this call
+        return st
+
     def generate(self, input_ids=None, attention_mask=None, max_new_tokens=128, do_sample=False, temperature=1.0, top_p=1.0,
                  eos_token_id=None, pixel_values=None, pixel_values_videos=None, image_grid_thw=None, video_grid_thw=None,
                  second_per_grid_ts=None, **kwargs):
@@ -658,21 +719,53 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         seqs = input_ids
         done = torch.zeros(B, dtype=torch.bool, device=dev)
         pad = c.pad_token_id if c.pad_token_id is not None else next(iter(eos))
-        for _ in range(max_new_tokens):
+        eos_t = torch.tensor(sorted(eos), device=dev)
+        new_cols, all_done = [], []
+        deltas = self.rope_deltas.cpu().numpy().reshape(B) if self.rope_deltas is not None else np.zeros(B, dtype=np.int64)
+        pos_host = am.detach().cpu().numpy().astype(bool).sum(1).astype(np.int64) - 1 + deltas    # mrope position of the last prefill token (modeling_qwen2_5_vl.py:1160-1172)
+        cu_dec = torch.arange(B + 1, dtype=torch.int32, device=dev)
+        graph_ok = (B == 1 and max_new_tokens >= 16 and not torch.is_grad_enabled() and kwargs.get("decode_graph", True)
+                    and all(_is_plain(l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj) for l in self.model.layers))
+        dec = None
+        # The "everyone has emitted EOS" test is a device -> host sync; taken every step it keeps the host from running ahead of the GPU and
+        # exposes every launch.  It is taken every SYNC_EVERY steps instead: a finished batch may run up to SYNC_EVERY - 1 extra steps, whose
+        # columns (all pad by construction) are cut below, so the returned ids are exactly those of the step-by-step loop.
+        SYNC_EVERY = 8
+        for step in range(max_new_tokens):
             if do_sample:
                 pr = torch.softmax(logits.float() / max(temperature, 1e-5), -1)
                 nxt = torch.multinomial(pr, 1)[:, 0]
             else:
                 nxt = logits.float().argmax(-1)
             nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
-            seqs = torch.cat([seqs, nxt[:, None]], dim=1)
+            new_cols.append(nxt[:, None])
             am = torch.cat([am, (~done).to(am.dtype)[:, None]], dim=1)
-            done = done | torch.isin(nxt, torch.tensor(sorted(eos), device=dev))
-            if bool(done.all()):
+            done = done | torch.isin(nxt, eos_t)
+            all_done.append(done.all())
+            if step + 1 == max_new_tokens or ((step + 1) % SYNC_EVERY == 0 and bool(all_done[-1])):
                 break
-            out = self.forward(input_ids=nxt[:, None], attention_mask=am, past_key_values=cache)
-            logits = out.logits[:, -1]
-        return seqs
+            # decode step without any device -> host traffic: the host knows every position (valid prefill tokens + steps + the prefill's
+            # rope delta) and the token ids stay on the device.  Finished sequences keep stepping on pad tokens until the next check (their
+            # outputs are forced to pad above and nothing of theirs is read by the others), which is what keeps the step free of syncs.
+            pos_host += 1
+            if graph_ok:
+                # one sequence: the whole step (embedding row, 28 layers, final norm, LM head: ~400 launches of a few microseconds, bound by
+                # launch latency) is captured once per generate() call after a first eager step and replayed per token
+                if dec is None:
+                    dec = self._capture_decode_step(cache, nxt, pos_host)
+                else:
+                    dec["tok"].copy_(nxt)
+                    dec["graph"].replay()
+                logits = dec["logits"]
+                continue
+            pos3 = torch.from_numpy(np.broadcast_to(pos_host[None], (3, B)).copy()).to(dev)
+            cache.begin([1] * B)
+            h, _ = self.model(ops.gather_rows(self.model.embed_tokens.weight, nxt), pos3, cu_dec, 1, cache)
+            cache.commit()
+            logits = self.lm_head(h)
+        flags = torch.stack(all_done).cpu().numpy() if all_done else np.zeros(0, dtype=bool)
+        keep = int(np.argmax(flags)) + 1 if flags.any() else len(new_cols)   # columns up to and including the step at which the last sequence finished
+        return torch.cat([seqs] + new_cols[:keep], dim=1)
 
 
 def _np(x):
