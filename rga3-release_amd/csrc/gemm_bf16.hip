@@ -1206,7 +1206,7 @@ __device__ __forceinline__ float dot8(const u32x4& a, const u32x4& b, float acc)
     return acc;
 }
 
-template <int MR, int ACT, bool OUT_F32>
+template <int MR, int ACT, bool OUT_F32, bool NT>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
     constexpr int CW = 4;                                   // output columns per wave and pass
     constexpr int RW = (ACT == ACT_SWIGLU) ? 2 * CW : CW;   // weight rows per wave and pass
@@ -1236,7 +1236,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs p) {
     for (int ch = lane; ch < nch; ch += 64) {
         u32x4 w[RW];
 #pragma unroll
-        for (int r = 0; r < RW; ++r) w[r] = *(const u32x4*)(wrow[r] + ch * 8);
+        for (int r = 0; r < RW; ++r) {
+            if constexpr (NT) w[r] = __builtin_nontemporal_load((const u32x4*)(wrow[r] + ch * 8));   // read-once weight stream kept out of L2 / Infinity Cache
+            else w[r] = *(const u32x4*)(wrow[r] + ch * 8);
+        }
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             const u32x4 x = *(const u32x4*)(p.A + (long)min(m, p.M - 1) * p.lda + ch * 8);
@@ -1291,9 +1294,16 @@ static int launch_gemv(const GemmArgs& a, hipStream_t st) {
     g.M = a.M; g.N = a.N; g.K = a.K; g.lda = a.lda; g.ldw = a.ldw; g.ldc = a.ldc; g.ldr = a.ldr;
     const int nout = (ACT == ACT_SWIGLU) ? a.N / 2 : a.N;
     const unsigned grid = (unsigned)cdiv(nout, 16);
-    if (a.M == 1) hipLaunchKernelGGL((gemv_kernel<1, ACT, OUT_F32>), dim3(grid), dim3(256), 0, st, g);
-    else if (a.M == 2) hipLaunchKernelGGL((gemv_kernel<2, ACT, OUT_F32>), dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemv_kernel<4, ACT, OUT_F32>), dim3(grid), dim3(256), 0, st, g);
+    static const bool nt = [] { const char* e = getenv("RGA3_GEMV_NT"); return e ? atoi(e) != 0 : true; }();   // A/B switch (default: nontemporal weight loads)
+    if (nt) {
+        if (a.M == 1) hipLaunchKernelGGL((gemv_kernel<1, ACT, OUT_F32, true>), dim3(grid), dim3(256), 0, st, g);
+        else if (a.M == 2) hipLaunchKernelGGL((gemv_kernel<2, ACT, OUT_F32, true>), dim3(grid), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemv_kernel<4, ACT, OUT_F32, true>), dim3(grid), dim3(256), 0, st, g);
+    } else {
+        if (a.M == 1) hipLaunchKernelGGL((gemv_kernel<1, ACT, OUT_F32, false>), dim3(grid), dim3(256), 0, st, g);
+        else if (a.M == 2) hipLaunchKernelGGL((gemv_kernel<2, ACT, OUT_F32, false>), dim3(grid), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemv_kernel<4, ACT, OUT_F32, false>), dim3(grid), dim3(256), 0, st, g);
+    }
     RGA3_CHECK_LAUNCH("gemv_kernel");
     return 0;
 }
