@@ -429,13 +429,13 @@ def main():
 
     if rank == 0 and args.mode == "lora_fp8":
         n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        fl = accum * (21.6 + 62.6 - 4.6 + 57.9 + 57.9) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + recompute + dX at S = 4160
+        fl = accum * (21.6 + 62.6 - 4.6 + 57.9) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + dX at S = 4160; activations are kept, nothing is recomputed
         line = {"metric": "video-QA samples/sec (fwd+bwd) at 7B/32-frame -- LoRA fine-tune step, grad-accum %d, %s GEMMs for the frozen decoder weights" % (
                     accum, "bf16" if args.no_fp8 else "fp8 e4m3"), "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.no_fp8 else "fp8(e4m3)+bf16", "data": "synthetic",
                 "config": {"workload": "BASELINE.json configs[4] per GPU: Qwen2.5-VL-7B, 32 frames 448x448 (grid [16,32,32], S = 4160), ViT fwd bf16 (frozen), decoder "
-                                       "fwd + per-layer recompute + bwd with the frozen qkv / o / gate-up / down contractions in e4m3 (per-token / per-row scales), "
+                                       "fwd (activations kept in HBM) + bwd with the frozen qkv / o / gate-up / down contractions in e4m3 (per-token / per-row scales), "
                                        "LoRA r128 (dropout 0.05) + lm_head + embed_tokens + norms + attention in bf16, %d micro-steps per optimizer step, "
                                        "one bucketed RCCL all-reduce per optimizer step, AdamW" % accum,
                            "per_gpu_batch": 1, "grad_accum": accum, "seq_len": 4160, "parallelism": f"dp{world}", "trainable_params": n_train,
@@ -447,7 +447,7 @@ def main():
         print(json.dumps(line), flush=True)
     elif rank == 0 and args.mode in ("train", "train_full"):
         n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        fl = (10.8 + 30.8 - 2.3 + 28.5 + 28.5) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + recompute + dX
+        fl = (10.8 + 30.8 - 2.3 + 28.5) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + dX; activations are kept, nothing is recomputed
         if args.mode == "train_full":
             fl += (1.82 * args.sam_frames + 3 * 0.0036 * args.sam_frames) * 1e12   # frozen Hiera-L fwd + mask decoder fwd+bwd
         line = {"metric": ("video-QA samples/sec (fwd+bwd) at 7B/16-frame — full RGA3 step (Qwen2.5-VL-7B + SAM2-L + mask losses)" if args.mode == "train_full"
@@ -455,7 +455,7 @@ def main():
                 "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": ("BASELINE.json configs[2] per GPU: " if args.mode == "train_full" else "") +
-                                       "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd with per-layer recompute, LoRA r128 (alpha 256, dropout 0.05) q/v + lm_head + embed_tokens "
+                                       "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd (layer activations kept in HBM, no recompute), LoRA r128 (alpha 256, dropout 0.05) q/v + lm_head + embed_tokens "
                                        "trainable, AdamW step, bucketed RCCL all-reduce; 16 frames 448x448, S=2112, 1 sample/GPU" +
                                        (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)"
                                         if args.mode == "train_full" else ""), "per_gpu_batch": 1,

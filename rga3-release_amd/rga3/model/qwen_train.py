@@ -203,12 +203,52 @@ def _layer_forward_fp8(layer, x, cos, sin, cu, max_len, seeds):
     return _fgemm(a, mlp, "wd", (mlp.down_proj.weight,), lambda: wd, bias=mlp.down_proj.bias, residual=x1)
 
 
+_acts = {"store": True}
+
+
+def set_activation_recompute(on: bool):
+    """True: a decoder layer saves only its input and recomputes the rest in backward (what the reference's gradient checkpointing does,
+    train_joint.py gradient_checkpointing_enable).  False (default here): the layer keeps what its backward reads -- normed inputs, roped
+    q/k/v, attention output + LSE, the MLP pre-activations: ~290 MB per layer at S = 2112, 8 GB for 28 layers of the 288 GB -- and
+    backward skips the recompute (a qkv, an o-proj and a gate-up GEMM plus an attention forward per layer).  Same arithmetic either way."""
+    _acts["store"] = not on
+
+
+def _layer_forward_store(layer, x, cos, sin, cu, max_len, seeds):
+    """Decoder layer forward for training that returns (y, saved): saved = exactly the tensors DecoderLayerFn.backward otherwise recomputes
+    (same calls in the same order, frozen contractions through _fgemm so the fp8 switch applies)."""
+    at, mlp = layer.self_attn, layer.mlp
+    Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
+    T = x.shape[0]
+    w1, w2 = layer.input_layernorm, layer.post_attention_layernorm
+    h1 = ops.rmsnorm(x, w1.weight, w1.variance_epsilon)
+    qkv2, tq, tv, hq_in, hv_in = qkv_with_lora(at, h1, seeds=seeds, want_inputs=True)
+    qkv = qkv2.view(T, Hq + 2 * Hk, D)
+    ops.rope_(qkv, cos, sin, 0, Hq + Hk)
+    att, lse = ops.attn_varlen(qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:], cu, cu, max_len, D ** -0.5, causal=True, return_lse=True)
+    x1 = _fgemm(att.view(T, Hq * D), at, "wo", (at.o_proj.weight,), lambda: at.o_proj.weight.detach(), residual=x)
+    h2 = ops.rmsnorm(x1, w2.weight, w2.variance_epsilon)
+    wgu, bgu, wd = mlp._packed()
+    gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)
+    y = _fgemm(ops.swiglu_fwd(gu), mlp, "wd", (mlp.down_proj.weight,), lambda: wd, bias=mlp.down_proj.bias, residual=x1)
+    return y, (h1, qkv, att, lse, x1, h2, gu, tq, tv, hq_in, hv_in)
+
+
 class DecoderLayerFn(torch.autograd.Function):
-    """y = DecoderLayer(x); saves x only, recomputes in backward."""
+    """y = DecoderLayer(x).  Keeps the layer's intermediates for backward (default) or only x and recomputes (set_activation_recompute)."""
 
     @staticmethod
     def forward(ctx, x, aq, bq, av, bv, layer, cos, sin, cu, max_len, seeds):
         at0 = layer.self_attn
+        ctx.stored = False
+        if _acts["store"]:
+            with torch.no_grad():
+                y, saved = _layer_forward_store(layer, x, cos, sin, cu, max_len, seeds)
+            ctx.stored = True
+            ctx.seeds = seeds
+            ctx.layer, ctx.cos, ctx.sin, ctx.cu, ctx.max_len = layer, cos, sin, cu, max_len
+            ctx.save_for_backward(x, *saved)
+            return y
         if _fp8["on"]:
             with torch.no_grad():
                 y = _layer_forward_fp8(layer, x, cos, sin, cu, max_len, seeds)
@@ -226,28 +266,31 @@ class DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         layer, cos, sin, cu, max_len = ctx.layer, ctx.cos, ctx.sin, ctx.cu, ctx.max_len
         at, mlp = layer.self_attn, layer.mlp
         Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
         T = x.shape[0]
         dy = dy.contiguous()
         with torch.no_grad():
-            # ---- recompute forward pieces the backward needs
             w1, w2 = layer.input_layernorm, layer.post_attention_layernorm
-            h1 = ops.rmsnorm(x, w1.weight, w1.variance_epsilon)
             wqkv, bqkv = at._packed()
             lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
-            qkv2, tq, tv, hq_in, hv_in = qkv_with_lora(at, h1, seeds=ctx.seeds, want_inputs=True)
             pq, pv = _lora_dropout(at)
-            qkv = qkv2.view(T, Hq + 2 * Hk, D)
-            ops.rope_(qkv, cos, sin, 0, Hq + Hk)
-            q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
-            att, lse = ops.attn_varlen(q, k, v, cu, cu, max_len, D ** -0.5, causal=True, return_lse=True)
-            x1 = _fgemm(att.view(T, Hq * D), at, "wo", (at.o_proj.weight,), lambda: at.o_proj.weight.detach(), residual=x)
-            h2 = ops.rmsnorm(x1, w2.weight, w2.variance_epsilon)
             wgu, bgu, wd = mlp._packed()
-            gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)   # pre-activations, interleaved [T, 2*Ip]
+            if ctx.stored:
+                h1, qkv, att, lse, x1, h2, gu, tq, tv, hq_in, hv_in = ctx.saved_tensors[1:]
+            else:
+                # ---- recompute forward pieces the backward needs
+                h1 = ops.rmsnorm(x, w1.weight, w1.variance_epsilon)
+                qkv2, tq, tv, hq_in, hv_in = qkv_with_lora(at, h1, seeds=ctx.seeds, want_inputs=True)
+                qkv = qkv2.view(T, Hq + 2 * Hk, D)
+                ops.rope_(qkv, cos, sin, 0, Hq + Hk)
+                att, lse = ops.attn_varlen(qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:], cu, cu, max_len, D ** -0.5, causal=True, return_lse=True)
+                x1 = _fgemm(att.view(T, Hq * D), at, "wo", (at.o_proj.weight,), lambda: at.o_proj.weight.detach(), residual=x)
+                h2 = ops.rmsnorm(x1, w2.weight, w2.variance_epsilon)
+                gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)   # pre-activations, interleaved [T, 2*Ip]
+            q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
             # ---- MLP backward
             da = _fgemm(dy, mlp, "wd_t", (mlp.down_proj.weight,), lambda: ops.transpose(wd))                                   # [T, Ip]
             dgu = ops.swiglu_bwd(gu, da)

@@ -298,3 +298,28 @@ def test_fused_adamw_with_bucket_norm_matches_torch(dev):
     torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0).step()
     for a, r in zip(outs[0][0], ref):
         assert torch.allclose(a, r.detach().to(torch.bfloat16).float(), atol=1e-2, rtol=2e-2)
+
+
+def test_stored_activations_equal_recompute(dev):
+    """DecoderLayerFn keeps its intermediates by default (288 GB of HBM) and can recompute them like the reference's gradient checkpointing
+    (set_activation_recompute): same calls either way, so loss and gradients must agree to bf16 rounding of the one op that differs in
+    form (SwiGLU as a kernel vs as the gate-up GEMM's epilogue)."""
+    from rga3.model import qwen_train as QT
+
+    G = gold()
+    px = torch.cat([det_tensor("pixel_values_full0", (192, 1176), 1.0, seed=5), det_tensor("pixel_values_full1", (192, 1176), 1.0, seed=6)], 0).to(torch.bfloat16)
+    ids, am, labels = (torch.from_numpy(G[k]) for k in ("full_input_ids", "full_attention_mask", "full_labels"))
+    res = {}
+    try:
+        for mode in (False, True):
+            QT.set_activation_recompute(mode)
+            model, _ = _build_lora_model(dev, G)
+            out = model(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev), pixel_values_videos=px.to(dev),
+                        video_grid_thw=torch.from_numpy(G["full_grid"]), second_per_grid_ts=torch.tensor([1.0, 1.0]))
+            out.loss.backward()
+            res[mode] = (out.loss.item(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.requires_grad})
+    finally:
+        QT.set_activation_recompute(False)
+    assert abs(res[False][0] - res[True][0]) <= 2e-3 * abs(res[True][0])
+    for n in res[True][1]:
+        assert rel_l2(res[False][1][n], res[True][1][n]) < 2e-2, n
