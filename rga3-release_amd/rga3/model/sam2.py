@@ -766,7 +766,7 @@ class SAM2(nn.Module):
         for o in range(n_obj):
             sess = session if o == 0 else VideoSession(self.sam2_model, session.images, feats=session.feats)
             for t in range(T):
-                sess.add_language_embd(t, language_embd[t][o].reshape(1, 1, -1))
+                sess.add_language_embd(t, language_embd[t][o].reshape(1, 1, -1), use_graph=True)
             outs.append(torch.cat([mk for _, mk in sess.propagate()], dim=0))
         return torch.cat(outs, dim=1)
 
@@ -809,13 +809,57 @@ class VideoSession:
         h, w = f["hw"]
         return f["feat"][t * h * w:(t + 1) * h * w]
 
-    def add_language_embd(self, frame_idx, language_embd):
+    def add_language_embd(self, frame_idx, language_embd, use_graph: bool = False):
+        """Language prompt on one frame (reference add_language_embd, sam2.py:3824-3975): mask decoder on the frame's features without memory.
+        use_graph: the step (≈100 short launches, the same shapes for every frame) is captured once per model and replayed."""
         f = self._ensure_feats()
-        pix = ops.add_bcast(self._frame_tokens(frame_idx), self.m.no_mem_embed.view(1, -1))
-        o = self.m.forward_sam_heads(pix, f, language_embd, frame_slice=(frame_idx, frame_idx + 1))
+        if use_graph and not _ag():
+            o = self._graph_prompt(frame_idx, language_embd)
+        else:
+            pix = ops.add_bcast(self._frame_tokens(frame_idx), self.m.no_mem_embed.view(1, -1))
+            o = self.m.forward_sam_heads(pix, f, language_embd, frame_slice=(frame_idx, frame_idx + 1))
         self.counts["dec"] += 1
         self.temp_cond[frame_idx] = {"pred_masks": o["low_res_masks"], "obj_ptr": o["obj_ptr"], "best_iou_inds": o["best_iou_inds"]}
         return o["low_res_masks"]
+
+    def _graph_prompt(self, t, language_embd):
+        m, f = self.m, self._ensure_feats()
+        h, w = f["hw"]
+        hw, dev = h * w, f["feat"].device
+        cache = m.__dict__.setdefault("_frame_graphs", {})
+        if "pool" not in cache:
+            cache["pool"] = torch.cuda.graph_pool_handle()
+        key = ("prompt", hw, tuple(language_embd.shape), str(dev), f["feat"].dtype)
+        ent = cache.get(key)
+        fresh = ent is None
+        if fresh:
+            ent = cache[key] = {"G": {"tok": torch.empty_like(f["feat"][:hw]), "s0": torch.empty_like(f["feat_s0"][:16 * hw]),
+                                      "s1": torch.empty_like(f["feat_s1"][:4 * hw]), "emb": torch.empty_like(language_embd), "pos": torch.empty_like(f["pos"])}}
+        G = ent["G"]
+        G["tok"].copy_(f["feat"][t * hw:(t + 1) * hw])
+        G["s0"].copy_(f["feat_s0"][t * 16 * hw:(t + 1) * 16 * hw])
+        G["s1"].copy_(f["feat_s1"][t * 4 * hw:(t + 1) * 4 * hw])
+        G["emb"].copy_(language_embd)
+        G["pos"].copy_(f["pos"])     # everything the captured launches read lives in G (the graph outlives this session)
+        feats1 = {"feat_s0": G["s0"], "feat_s1": G["s1"], "feat": G["tok"], "hw": (h, w), "n": 1, "pos": G["pos"]}
+
+        def body():
+            pix = ops.add_bcast(G["tok"], m.no_mem_embed.view(1, -1))
+            o = m.forward_sam_heads(pix, feats1, G["emb"], frame_slice=(0, 1))
+            return o["low_res_masks"], o["obj_ptr"], o["best_iou_inds"]
+
+        if fresh:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream().wait_stream(side)
+            ent["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent["graph"], pool=cache["pool"]):
+                ent["outs"] = body()
+        ent["graph"].replay()
+        low, ptr, best = ent["outs"]
+        return {"low_res_masks": low.clone(), "obj_ptr": ptr.clone(), "best_iou_inds": best.clone()}
 
     def _memory_for(self, t, low_res_masks):
         S = self.m.image_size

@@ -145,4 +145,23 @@ def test_graph_replay_equals_eager_stream(model, dev):
     for t in range(1, T - 1):
         assert torch.equal(a.non_cond[t]["obj_ptr"], b.non_cond[t]["obj_ptr"]) and torch.equal(a.non_cond[t]["obj_ptr"], c.non_cond[t]["obj_ptr"])
         assert torch.equal(a.non_cond[t]["maskmem_features"], b.non_cond[t]["maskmem_features"])
-    assert len(model.sam2_model._frame_graphs) == 16 + 1   # 16 bank states + the shared pool handle
+    assert sum(1 for k in model.sam2_model._frame_graphs if isinstance(k, tuple) and isinstance(k[0], int)) == 16   # one graph per bank state
+
+
+def test_prompt_every_frame_graph_equals_eager(model, dev):
+    """language_embd_inference (the evaluate() path: language prompt on every frame) replays one captured hipGraph per frame; masks must equal
+    the eager per-frame path bit for bit, for a second clip as well (the graph is kept on the model)."""
+    from rga3.model.sam2 import VideoSession
+
+    torch.manual_seed(9)
+    for rep in range(2):
+        T = 6
+        vid = (torch.randn(T, 3, 128, 128) * 0.5).to(torch.bfloat16).to(dev)
+        embs = [[torch.randn(1, 256).to(torch.bfloat16).to(dev)] for _ in range(T)]
+        with torch.no_grad():
+            a = VideoSession(model.sam2_model, vid)
+            for t in range(T):
+                a.add_language_embd(t, embs[t][0].reshape(1, 1, -1))
+            ra = torch.cat([mk for _, mk in a.propagate()], dim=0)
+            rb = model.language_embd_inference(VideoSession(model.sam2_model, vid, feats=a.feats), embs)
+        assert rb.shape[0] == T and torch.equal(ra, rb.reshape(ra.shape))
