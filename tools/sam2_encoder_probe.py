@@ -1,0 +1,17 @@
+"""SAM2-L image encoder (Hiera-L + FPN) alone: ms per 8-frame chunk.  python tools/sam2_encoder_probe.py [iters]"""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
+from rga3.model.sam2 import SAM2
+it = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+torch.manual_seed(1)
+m = SAM2().to(torch.bfloat16).cuda().eval()
+with torch.no_grad():
+    for n, p_ in m.named_parameters():
+        if p_.dim() >= 2: p_.normal_(0, 0.02)
+    x = torch.randn(8, 3, 1024, 1024, device="cuda").to(torch.bfloat16)
+    for _ in range(2): m.sam2_model.forward_image(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(it): m.sam2_model.forward_image(x)
+    torch.cuda.synchronize()
+    print(f"{(time.perf_counter()-t0)/it*1e3:.1f} ms per 8 frames")
