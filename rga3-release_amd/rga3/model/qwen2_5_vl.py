@@ -709,7 +709,20 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         dev = self.device
         eos = eos_token_id if eos_token_id is not None else c.eos_token_id
         eos = set(eos if isinstance(eos, (list, tuple)) else [eos])
-        cache = KVCache(c.num_hidden_layers, B, S + max_new_tokens, c.num_key_value_heads, c.head_dim, dev, self.dtype)
+        # single sequences decode by replaying a captured step: its KV buffers and graph are kept on the model per capacity bucket, so only the
+        # first generate() of a given length class pays for the capture
+        graph_ok = (B == 1 and max_new_tokens >= 16 and not torch.is_grad_enabled() and kwargs.get("decode_graph", True)
+                    and all(_is_plain(l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj) for l in self.model.layers))
+        dstate = None
+        if graph_ok:
+            cap = (S + max_new_tokens + 1023) // 1024 * 1024
+            dstate = self.__dict__.setdefault("_decode_states", {}).setdefault((cap, str(dev), self.dtype), {})
+            if "cache" not in dstate:
+                dstate["cache"] = KVCache(c.num_hidden_layers, 1, cap, c.num_key_value_heads, c.head_dim, dev, self.dtype)
+            cache = dstate["cache"]
+            cache.lens = [0]
+        else:
+            cache = KVCache(c.num_hidden_layers, B, S + max_new_tokens, c.num_key_value_heads, c.head_dim, dev, self.dtype)
         am = attention_mask if attention_mask is not None else torch.ones_like(input_ids)
         out = self.forward(input_ids=input_ids, attention_mask=am, past_key_values=cache, pixel_values=pixel_values,
                            pixel_values_videos=pixel_values_videos, image_grid_thw=image_grid_thw, video_grid_thw=video_grid_thw,
@@ -724,8 +737,6 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         deltas = self.rope_deltas.cpu().numpy().reshape(B) if self.rope_deltas is not None else np.zeros(B, dtype=np.int64)
         pos_host = am.detach().cpu().numpy().astype(bool).sum(1).astype(np.int64) - 1 + deltas    # mrope position of the last prefill token (modeling_qwen2_5_vl.py:1160-1172)
         cu_dec = torch.arange(B + 1, dtype=torch.int32, device=dev)
-        graph_ok = (B == 1 and max_new_tokens >= 16 and not torch.is_grad_enabled() and kwargs.get("decode_graph", True)
-                    and all(_is_plain(l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj) for l in self.model.layers))
         dec = None
         # The "everyone has emitted EOS" test is a device -> host sync; taken every step it keeps the host from running ahead of the GPU and
         # exposes every launch.  It is taken every SYNC_EVERY steps instead: a finished batch may run up to SYNC_EVERY - 1 extra steps, whose
@@ -750,9 +761,17 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
             pos_host += 1
             if graph_ok:
                 # one sequence: the whole step (embedding row, 28 layers, final norm, LM head: ~400 launches of a few microseconds, bound by
-                # launch latency) is captured once per generate() call after a first eager step and replayed per token
-                if dec is None:
+                # launch latency) is captured once (kept on the model per capacity bucket) after a first eager step and replayed per token
+                if dec is None and "graph" in dstate:          # captured by an earlier call: point the static state at this sequence
+                    dec = dstate
+                    dec["pos3"].copy_(torch.from_numpy(np.broadcast_to(pos_host[None], (3, 1)).copy()).to(dev))
+                    dec["kv"].reset(cache.lens[0])
+                    dec["tok"].copy_(nxt)
+                    dec["graph"].replay()
+                elif dec is None:
                     dec = self._capture_decode_step(cache, nxt, pos_host)
+                    dstate.update(dec)
+                    dec = dstate
                 else:
                     dec["tok"].copy_(nxt)
                     dec["graph"].replay()

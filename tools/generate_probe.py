@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 model, cfg = bench.build_model(dev)
 inputs = bench.make_inputs(cfg, dev)
 with torch.no_grad():
-    for n in (8, N):
+    for n in (8, N, N):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = model.generate(**inputs, max_new_tokens=1, do_sample=False)
         torch.cuda.synchronize(); t1 = time.perf_counter()
