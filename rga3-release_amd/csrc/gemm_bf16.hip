@@ -1338,6 +1338,9 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 4:  // 128x320: N = 1280 (ViT proj / fc2) at M = 8192 is exactly 256 tiles; 5 n-tiles per wave, so no SwiGLU pairs
             if constexpr (ACT != ACT_SWIGLU) return launch_cfg<128, 320, 2, 4, ACT, OUT_F32, 0>(a, st);
             else return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
+        case 5:   // 128x192: N = 576 = 3 x 192 (Hiera stage-3 proj / fc2 outputs: 2.25 tiles of 256 otherwise); 3 n-tiles per wave, so no SwiGLU pairs
+            if constexpr (ACT != ACT_SWIGLU) return launch_cfg<128, 192, 2, 4, ACT, OUT_F32, 0>(a, st);
+            else return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 10: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 13: return launch_cfg<64, 64, 2, 2, ACT, OUT_F32, 0>(a, st);   // small products (SAM2 per-frame 4096 x 256 x 256: 256 tiles instead of 64)
         case 20: return launch_pp<ACT, OUT_F32>(a, st);
@@ -1382,7 +1385,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || (tile >= 10 && tile <= 13) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || tile == 5 || (tile >= 10 && tile <= 13) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;

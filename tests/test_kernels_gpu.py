@@ -25,7 +25,7 @@ def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed / mis-mapped C fragment layout."""
     from rga3.hip import ops
 
-    for tile in (3, 4, 10, 11, 12, 13, 20, 21, 22, 31, 32):
+    for tile in (3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 31, 32):
         n, k = 256, 256
         a = torch.eye(k, dtype=torch.bfloat16, device=dev)
         w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(torch.bfloat16).to(dev)
@@ -35,7 +35,7 @@ def test_gemm_identity_asymmetric(dev):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (2112, 512, 3584), (8192, 1280, 1280), (64, 3456, 1280),
                                    (17, 24, 64), (1000, 152064 // 16, 192)])
-@pytest.mark.parametrize("tile", [-1, 3, 4, 10, 11, 12, 13, 20, 21, 22, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 31, 32])
 def test_gemm_plain(dev, M, N, K, tile):
     from rga3.hip import ops
 
@@ -62,7 +62,7 @@ def test_gemm_stream_k_split_shapes(dev):
 
 
 @pytest.mark.parametrize("act", ["none", "gelu", "relu", "swiglu"])
-@pytest.mark.parametrize("tile", [3, 4, 10, 11, 12, 13, 20, 21, 22, 31, 32])
+@pytest.mark.parametrize("tile", [3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 31, 32])
 def test_gemm_epilogues(dev, act, tile):
     from rga3.hip import ops
 

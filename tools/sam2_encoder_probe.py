@@ -15,3 +15,8 @@ with torch.no_grad():
     for _ in range(it): m.sam2_model.forward_image(x)
     torch.cuda.synchronize()
     print(f"{(time.perf_counter()-t0)/it*1e3:.1f} ms per 8 frames")
+from rga3.hip import tuner
+for k, v in tuner.timings().items():
+    Mb, N, K = k[0], k[1], k[2]
+    best = tuner.table().get(k)
+    print(k[:4], "best", best, {t: round(2.0 * Mb * 256 * N * K / ms / 1e9) for t, ms in v.items()})
