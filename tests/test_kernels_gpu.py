@@ -320,3 +320,30 @@ def test_gemv_decode_rows_match_tiled_gemm(dev, M, act, N, K, bias, res):
     if o32 is not None:
         want = a.float() @ w.float().T + (b.float() if bias else 0)
         assert float((o32 - want).norm() / want.norm()) < 1e-5
+
+
+def test_raw_ctypes_binding_as_in_integration_md(dev):
+    """The binding a reference maintainer would write, with no help from rga3's own Python: plain ctypes on the C ABI."""
+    import ctypes as C
+
+    from rga3.hip import lib as L
+
+    L.load()   # torch's HIP runtime first, as the document says
+    so = C.CDLL(L.LIB_PATH)
+    so.rga3_gemm_bf16.restype = C.c_int
+    so.rga3_gemm_bf16.argtypes = [C.c_void_p] * 6 + [C.c_int64] * 7 + [C.c_int] * 3 + [C.c_void_p, C.c_int64, C.c_void_p]
+    so.rga3_gemm_workspace_bytes.restype = C.c_int64
+    ws = torch.zeros(so.rga3_gemm_workspace_bytes(), dtype=torch.uint8, device=dev)
+    x, w, b = _rand((300, 264), dev, seed=31), _rand((520, 264), dev, 0.05, seed=32), _rand((520,), dev, 0.1, seed=33)
+    out = torch.empty(300, 520, dtype=torch.bfloat16, device=dev)
+    rc = so.rga3_gemm_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, out.data_ptr(), 300, 520, 264, x.stride(0), w.stride(0), out.stride(0), 0,
+                           0, 0, -1, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert _rel_l2(out, R.linear_ref(x.cpu(), w.cpu(), b.cpu())) < 6e-3
+    # errors come back as codes + a message, never as exceptions or aborts
+    so.rga3_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    rc = so.rga3_gemm_bf16(x.data_ptr(), w.data_ptr(), None, None, None, out.data_ptr(), 300, 520, 263, x.stride(0), w.stride(0), out.stride(0), 0,
+                           0, 0, -1, None, 0, torch.cuda.current_stream().cuda_stream)
+    buf = C.create_string_buffer(256)
+    so.rga3_last_error(buf, 256)
+    assert rc != 0 and b"multiple of 8" in buf.value
