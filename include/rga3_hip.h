@@ -77,11 +77,14 @@ int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, i
  * variant (debug cross-check). 
  * split_ws (optional, f32, split_ws_elems floats): non-causal calls whose grid would leave most CUs idle (query blocks x heads x
  * segments < 128) over a long key range (max_k >= 1024; max_k is only read for this decision) cut the keys into <= 8 slices, one
- * workgroup each, and merge them by their log-sum-exp in a second pass; needs nsplit * total_q * Hq * (D + 1) floats. */
+ * workgroup each, and merge them by their log-sum-exp in a second pass; needs nsplit * total_q * Hq * (D + 1) floats.
+ * block_q / block_k (0 = off, else powers of two, non-causal): block-diagonal visibility inside a segment -- query i sees key j iff
+ * i / block_q == j / block_k -- so that several tiny windows (Hiera's 4- and 16-token windows, model/sam2.py:986-1033) are packed into one
+ * 64-row segment instead of one workgroup per window. */
 int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q,
                          const int32_t* cu_k, int nseg, int max_q, int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh,
                          int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
-                         float scale, int causal, int impl, float* split_ws, int64_t split_ws_elems, int max_k, void* stream);
+                         float scale, int causal, int impl, float* split_ws, int64_t split_ws_elems, int max_k, int block_q, int block_k, void* stream);
 
 /* y = weight * (x * rsqrt(mean(x^2) + eps)) rounded to bf16 before the weight multiply, exactly as
  * HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:65-79).  x,y: [rows, dim] bf16; optional fused residual:

@@ -37,6 +37,9 @@ struct AttnArgs {
     float* split_o;    // f32 [nsplit][total_q][Hq][D] normalised partial outputs
     float* split_lse;  // f32 [nsplit][Hq][total_q] partial log2-sum-exp (of the scaled scores)
     int nsplit;
+    // block-diagonal visibility inside a segment (several tiny windows packed into one segment: Hiera's 4- and 16-token windows would
+    // otherwise be one workgroup each): query i sees key j iff (i >> bq_shift) == (j >> bk_shift); -1 = off
+    int bq_shift, bk_shift;
 };
 
 constexpr int KV_TILE = 64;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
 
         // ---- scale, mask, online softmax (per lane: one query per q-tile).  Interior tiles take the mask-free body.
         const int k0 = kt * KV_TILE;
-        const bool need_mask = (k0 + KV_TILE > Lk) || (p.causal && (k0 + KV_TILE - 1 > qb0 + shift));
+        const bool need_mask = (k0 + KV_TILE > Lk) || (p.causal && (k0 + KV_TILE - 1 > qb0 + shift)) || (p.bq_shift >= 0);
         bf16x8 pf[QT][2];
         auto softmax_tile = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
                                                                 // 16 multiplies per tile and measurably perturbs bf16 gradient parity)
                         if constexpr (MASKED) {
                             const int key = k0 + j * 16 + 4 * g + r;
-                            const bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
+                            bool ok = (key < Lk) && (!p.causal || key <= qi + shift);
+                            if (p.bq_shift >= 0) ok = ok && ((qi >> p.bq_shift) == (key >> p.bk_shift));
                             x = ok ? x : -INFINITY;
                         }
                         s[t][j][r] = x;
@@ -432,7 +436,7 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                                     const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q, int64_t total_q,
                                     int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh,
                                     int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal,
-                                    int impl, float* split_ws, int64_t split_ws_elems, int max_k, void* stream) {
+                                    int impl, float* split_ws, int64_t split_ws_elems, int max_k, int block_q, int block_k, void* stream) {
     RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k, "attn: null pointer");
     RGA3_CHECK_ARG(nseg > 0 && max_q > 0 && total_q > 0, "attn: nseg=%d max_q=%d total_q=%ld", nseg, max_q, (long)total_q);
     RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attn: Hq=%d Hkv=%d", Hq, Hkv);
@@ -456,8 +460,13 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     a.scale_log2 = scale * 1.4426950408889634f;
     a.causal = causal;
     // split the key range when the grid would leave most CUs idle: <= 8 slices, >= 8 key tiles each, workspace permitting
+    RGA3_CHECK_ARG((block_q == 0) == (block_k == 0) && block_q >= 0 && (block_q & (block_q - 1)) == 0 && (block_k & (block_k - 1)) == 0,
+                   "attn: block_q / block_k must both be 0 or powers of two (got %d, %d)", block_q, block_k);
+    RGA3_CHECK_ARG(block_q == 0 || !causal, "attn: block-diagonal packing is for non-causal windows");
+    a.bq_shift = a.bk_shift = -1;
+    if (block_q > 0) { a.bq_shift = __builtin_ctz((unsigned)block_q); a.bk_shift = __builtin_ctz((unsigned)block_k); }
     a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1;
-    if (split_ws && !causal && D % 4 == 0 && max_k >= 1024) {
+    if (split_ws && !causal && block_q == 0 && D % 4 == 0 && max_k >= 1024) {
         const long wgs = (long)cdiv(max_q, 64) * Hq * nseg;
         int ns = (int)(256 / (wgs > 0 ? wgs : 1));
         if (ns > 8) ns = 8;

@@ -129,7 +129,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
 
 
 def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = False, out=None, return_lse=False,
-                impl: int = 0):
+                impl: int = 0, block=None):
     """softmax(q k^T * scale) v over packed variable-length segments.
 
     q [Tq, Hq, D], k/v [Tk, Hkv, D] (arbitrary token/head strides, unit stride on D); cu_* int32 [nseg+1].
@@ -146,6 +146,7 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
     lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device) if return_lse else None
     # few query blocks x heads over a long key range (SAM2 memory attention: one head, 4096 queries, <= 28 736 keys): hand the kernel a
     # workspace so it can split the keys over up to 8 workgroups per query block
+    bq, bk = (int(block[0]), int(block[1])) if block else (0, 0)   # block-diagonal visibility inside a segment: (query block, key block), powers of two
     split_ws, max_k = None, 0
     if not causal and ((int(max_q) + 63) // 64) * Hq * nseg < 128 and k.shape[0] >= 1024 and D % 4 == 0:
         max_k = k.shape[0] if nseg == 1 else int((cu_k[1:] - cu_k[:-1]).max())
@@ -155,7 +156,7 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
                                           cu_q.data_ptr(), cu_k.data_ptr(), nseg, int(max_q), Tq, Hq, Hkv, D,
                                           q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                           out.stride(0), out.stride(1), float(scale), int(bool(causal)), impl, _ptr(split_ws),
-                                          split_ws.numel() if split_ws is not None else 0, int(max_k), _stream())
+                                          split_ws.numel() if split_ws is not None else 0, int(max_k), bq, bk, _stream())
     _lib.check(rc, "attn_varlen_fwd")
     return (out, lse) if return_lse else out
 

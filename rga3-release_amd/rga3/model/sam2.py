@@ -183,8 +183,18 @@ class MultiScaleBlock(nn.Module):
         hd = do // heads
         qv = q.view(q.shape[0], heads, hd) if q.is_contiguous() else q.unflatten(1, (heads, hd))
         kv = qkv.view(qkv.shape[0], 3 * heads, hd)
-        att = ops.attn_varlen(qv, kv[:, heads:2 * heads], kv[:, 2 * heads:], _cu(nwin, seg_q, x.device), _cu(nwin, seg, x.device), seg_q,
-                              hd ** -0.5, causal=False)
+        # tiny windows (16 tokens in stage 2, 4 pooled queries x 16 keys at the stage change): g windows are packed into one segment of up to
+        # 64 query rows with block-diagonal visibility -- one workgroup per 64 rows instead of one per window
+        g = 1
+        if ws > 0 and seg_q < 64 and (seg_q & (seg_q - 1)) == 0 and (seg & (seg - 1)) == 0:
+            while seg_q * g * 2 <= 64 and nwin % (g * 2) == 0:
+                g *= 2
+        if g > 1:
+            att = ops.attn_varlen(qv, kv[:, heads:2 * heads], kv[:, 2 * heads:], _cu(nwin // g, seg_q * g, x.device), _cu(nwin // g, seg * g, x.device),
+                                  seg_q * g, hd ** -0.5, causal=False, block=(seg_q, seg))
+        else:
+            att = ops.attn_varlen(qv, kv[:, heads:2 * heads], kv[:, 2 * heads:], _cu(nwin, seg_q, x.device), _cu(nwin, seg, x.device), seg_q,
+                                  hd ** -0.5, causal=False)
         x = self.attn.proj(att.view(att.shape[0], do), residual=shortcut)
         if self.pool_q:
             H, W, layout_w = H // 2, W // 2, ws // 2

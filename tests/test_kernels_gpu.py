@@ -347,3 +347,25 @@ def test_raw_ctypes_binding_as_in_integration_md(dev):
     buf = C.create_string_buffer(256)
     so.rga3_last_error(buf, 256)
     assert rc != 0 and b"multiple of 8" in buf.value
+
+
+@pytest.mark.parametrize("seg_q,seg_k,nwin,H,D", [(16, 16, 64, 4, 72), (4, 16, 128, 8, 72), (8, 8, 32, 2, 64), (32, 32, 6, 3, 128), (2, 64, 64, 1, 32)])
+def test_attention_block_diagonal_packing(dev, seg_q, seg_k, nwin, H, D):
+    """Several tiny windows packed into one segment with block-diagonal visibility (block_q, block_k) == one segment per window, bit for bit
+    (the same keys enter every row's softmax in the same order; masked scores contribute exact zeros)."""
+    from rga3.hip import ops
+
+    q = _rand((nwin * seg_q, H, D), dev, seed=41)
+    k = _rand((nwin * seg_k, H, D), dev, seed=42)
+    v = _rand((nwin * seg_k, H, D), dev, seed=43)
+    cq = (torch.arange(nwin + 1, dtype=torch.int32) * seg_q).to(dev)
+    ck = (torch.arange(nwin + 1, dtype=torch.int32) * seg_k).to(dev)
+    ref = ops.attn_varlen(q, k, v, cq, ck, seg_q, D ** -0.5)
+    g = 1
+    while seg_q * g * 2 <= 64 and nwin % (g * 2) == 0:
+        g *= 2
+    assert g > 1
+    cq2 = (torch.arange(nwin // g + 1, dtype=torch.int32) * seg_q * g).to(dev)
+    ck2 = (torch.arange(nwin // g + 1, dtype=torch.int32) * seg_k * g).to(dev)
+    got = ops.attn_varlen(q, k, v, cq2, ck2, seg_q * g, D ** -0.5, block=(seg_q, seg_k))
+    assert torch.equal(got, ref)
