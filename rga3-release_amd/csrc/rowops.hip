@@ -188,6 +188,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
     }
 }
 
+// Narrow rows (dim <= 512): LPR lanes per row, 64 / LPR rows per wave, at most two 16-byte chunks per lane -- Hiera-L's stage-1 / stage-2
+// rows (144 / 288 channels: 18 / 36 chunks) keep 28 % / 56 % of a wave busy in the one-row-per-wave kernel above.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                             const unsigned short* __restrict__ b, unsigned short* __restrict__ y,
+                                                             long rows, int dim, long ldx, long ldy, float eps, int act) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
+    const int nch = dim / 8;
+    u32x4 buf[2];
+    float f[2][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = sub + i * LPR;
+        buf[i] = u32x4{0u, 0u, 0u, 0u};
+        if (live && ch < nch) buf[i] = *(const u32x4*)(x + row * ldx + ch * 8);
+        unpack8(buf[i], f[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += f[i][e];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    const float mean = s1 / (float)dim;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = sub + i * LPR;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; s2 += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rinv = rsqrtf(s2 / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = sub + i * LPR;
+        if (live && ch < nch) {
+            float fw[8], fb[8], o8[8];
+            unpack8(*(const u32x4*)(w + ch * 8), fw);
+            if (b) unpack8(*(const u32x4*)(b + ch * 8), fb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (f[i][e] - mean) * rinv * fw[e] + (b ? fb[e] : 0.f);
+                if (act == 1) { float t = bf2f(f2bf(v)); v = 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); }
+                o8[e] = v;
+            }
+            *(u32x4*)(y + row * ldy + ch * 8) = pack8(o8);
+        }
+    }
+}
+
 // Narrow rows (dim < 8 or not a multiple of 8, <= 16): one thread per row, scalar bf16 loads.  The 4-channel LayerNorm2d + GELU of the
 // memory encoder's first mask-downsampler stage (reference model/sam2.py:611-643) runs 4 x 512 x 512 rows per frame through this.
 __global__ __launch_bounds__(256) void layernorm_tiny_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
@@ -426,7 +483,11 @@ extern "C" int rga3_layernorm_fwd(const void* x, const void* weight, const void*
     dim3 grid((unsigned)cdiv(rows, 4));
     const unsigned short *xp = (const unsigned short*)x, *wp = (const unsigned short*)weight, *bp = (const unsigned short*)bias;
     unsigned short* yp = (unsigned short*)y;
-    if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+    if (dim <= 16 * 8 * 2) {          // <= 32 chunks: 16 lanes per row, 4 rows per wave
+        hipLaunchKernelGGL(layernorm_rows_kernel<16>, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+    } else if (dim <= 32 * 8 * 2) {   // <= 64 chunks: 32 lanes per row, 2 rows per wave
+        hipLaunchKernelGGL(layernorm_rows_kernel<32>, dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+    } else if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
     else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
     else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
     RGA3_CHECK_LAUNCH("layernorm_kernel");

@@ -164,7 +164,7 @@ def test_rmsnorm(dev, rows, dim):
     assert _rel_l2(y2, R.rmsnorm_ref(s.cpu(), w.cpu(), 1e-6)) < 6e-3
 
 
-@pytest.mark.parametrize("rows,dim", [(65, 144), (10, 1152), (3, 256)])
+@pytest.mark.parametrize("rows,dim", [(65, 144), (10, 1152), (3, 256), (1001, 288), (77, 512), (5, 16), (130, 264), (33, 576), (9, 2304)])
 def test_layernorm(dev, rows, dim):
     from rga3.hip import ops
 
@@ -172,6 +172,10 @@ def test_layernorm(dev, rows, dim):
     w, b = _rand((dim,), dev, seed=34), _rand((dim,), dev, seed=35)
     y = ops.layernorm(x, w, b, 1e-6)
     assert _rel_l2(y, R.layernorm_ref(x.cpu(), w.cpu(), b.cpu(), 1e-6)) < 6e-3
+    wide = torch.zeros((rows, dim + 16), dtype=torch.bfloat16, device=dev)      # strided rows, no bias: every row path of the launcher
+    wide[:, 8:8 + dim] = x
+    y2 = ops.layernorm(wide[:, 8:8 + dim], w, None, 1e-6)
+    assert _rel_l2(y2, R.layernorm_ref(x.cpu(), w.cpu(), None, 1e-6)) < 6e-3
 
 
 @pytest.mark.parametrize("D,H", [(80, 16), (128, 32)])
