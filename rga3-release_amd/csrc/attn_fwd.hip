@@ -53,8 +53,8 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     constexpr int STRIDE = DP * 2 + 32;   // LDS row stride in bytes (see header comment)
     constexpr int DS = DP / 32;           // 32-wide d steps of the QK^T contraction
     constexpr int DT = DP / 16;           // 16-wide d tiles of the output
-    constexpr int LOADS = (KV_TILE * CH) / NT;
-    static_assert((KV_TILE * CH) % NT == 0, "tile chunks must divide evenly over threads");
+    constexpr int LOADS = (KV_TILE * CH + NT - 1) / NT;   // the last pass may cover only part of the threads (D = 96 with 8 waves: 768 chunks over 512 threads)
+    constexpr bool EVEN = (KV_TILE * CH) % NT == 0;
     constexpr int RING = (LOADS <= 2) ? 3 : (LOADS <= 3) ? 2 : 1;  // K/V register slots in flight (8 * LOADS registers each)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
             const int r = idx / CH, ch = idx % CH;
             const int key = kt * KV_TILE + r;
             u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
-            if (key < Lk && ch * 8 < p.D) {
+            if ((EVEN || idx < KV_TILE * CH) && key < Lk && ch * 8 < p.D) {
                 zk = *(const u32x4*)(kt_k + koff0[i]);
                 zv = *(const u32x4*)(kt_v + voff0[i]);
             }
@@ -163,8 +163,10 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
         for (int i = 0; i < LOADS; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / CH, ch = idx % CH;
-            *(u32x4*)(Ks + r * STRIDE + ch * 16) = kreg[slot][i];
-            *(u32x4*)(Vs + r * STRIDE + ch * 16) = vreg[slot][i];
+            if (EVEN || idx < KV_TILE * CH) {
+                *(u32x4*)(Ks + r * STRIDE + ch * 16) = kreg[slot][i];
+                *(u32x4*)(Vs + r * STRIDE + ch * 16) = vreg[slot][i];
+            }
         }
     };
 
@@ -409,6 +411,10 @@ static int launch_dp(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
         // long sequences: 8 waves x 16 query rows keeps the register footprint near 110 VGPRs (4 waves/SIMD) instead of
         // one 300-register wave per SIMD
         if (max_q > 64 && g_attn_variant != 1) return launch_attn<DP, 1, 8, USE_TR>(a, nseg, max_q, st);
+    }
+    if constexpr (DP == 96) {
+        // a whole 256-token window (Hiera stage 3) per workgroup: K / V staged once instead of once per 128-row half
+        if (!a.causal && max_q >= 256 && max_q % 256 == 0 && g_attn_variant != 1) return launch_attn<DP, 2, 8, USE_TR>(a, nseg, max_q, st);
     }
     if constexpr (DP >= 256) {
         return launch_attn<DP, 1, 4, USE_TR>(a, nseg, max_q, st);
