@@ -23,3 +23,6 @@ python3 $R/bench.py --mode lora_fp8 --steps 3 --warmup 1 > $O/bench_lora_fp8.jso
 python3 $R/bench.py --mode sam2_stream --steps 3 --warmup 1 > $O/bench_sam2_stream.json 2> $O/bench_sam2_stream.err; tail -c 300 $O/bench_sam2_stream.json
 python3 $R/tools/bench_preproc.py > $O/bench_preproc.log 2>&1; tail -3 $O/bench_preproc.log
 python3 $R/tools/blas_reference_point.py > $O/blas_reference_point.log 2>&1; tail -3 $O/blas_reference_point.log
+python3 $R/tools/evaluate_probe.py > $O/evaluate_probe.log 2>&1; tail -1 $O/evaluate_probe.log
+python3 $R/tools/generate_probe.py 64 > $O/generate_probe.log 2>&1; tail -1 $O/generate_probe.log
+python3 $R/tools/sam2_encoder_probe.py 5 2>&1 | grep "ms per" > $O/sam2_encoder_probe.log; cat $O/sam2_encoder_probe.log
