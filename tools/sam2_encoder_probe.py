@@ -9,12 +9,13 @@ m = SAM2().to(torch.bfloat16).cuda().eval()
 with torch.no_grad():
     for n, p_ in m.named_parameters():
         if p_.dim() >= 2: p_.normal_(0, 0.02)
-    x = torch.randn(8, 3, 1024, 1024, device="cuda").to(torch.bfloat16)
+    NF = int(os.environ.get("NF", "8"))
+    x = torch.randn(NF, 3, 1024, 1024, device="cuda").to(torch.bfloat16)
     for _ in range(2): m.sam2_model.forward_image(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(it): m.sam2_model.forward_image(x)
     torch.cuda.synchronize()
-    print(f"{(time.perf_counter()-t0)/it*1e3:.1f} ms per 8 frames")
+    print(f"{(time.perf_counter()-t0)/it*1e3:.1f} ms per {NF} frames")
 from rga3.hip import tuner
 for k, v in tuner.timings().items():
     Mb, N, K = k[0], k[1], k[2]
