@@ -717,6 +717,12 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         if graph_ok:
             cap = (S + max_new_tokens + 1023) // 1024 * 1024
             dstate = self.__dict__.setdefault("_decode_states", {}).setdefault((cap, str(dev), self.dtype), {})
+            # the captured launches read the weights (and the packs built from them) through their pointers: any in-place update since the
+            # capture bumps a parameter version and the graph is dropped (re-captured on this call)
+            sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            if dstate.get("sig") != sig:
+                dstate.clear()
+                dstate["sig"] = sig
             if "cache" not in dstate:
                 dstate["cache"] = KVCache(c.num_hidden_layers, 1, cap, c.num_key_value_heads, c.head_dim, dev, self.dtype)
             cache = dstate["cache"]

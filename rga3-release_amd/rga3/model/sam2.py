@@ -784,6 +784,23 @@ class SAM2(nn.Module):
         raise NotImplementedError
 
 
+def _graph_cache(m, session=None):
+    """The captured frame graphs of model m.  They read the weights (and the packs built from them) through their pointers, so any
+    in-place parameter update since the capture -- seen as a bumped tensor version -- drops them all; the next frame re-captures.
+    The check walks ~900 parameters, so a session does it once (weights do not change inside a session)."""
+    cache = m.__dict__.setdefault("_frame_graphs", {})
+    if session is None or not getattr(session, "_graphs_checked", False):
+        sig = tuple((p.data_ptr(), p._version) for p in m.parameters())
+        if cache.get("sig") != sig:
+            cache.clear()
+            cache["sig"] = sig
+        if session is not None:
+            session._graphs_checked = True
+    if "pool" not in cache:
+        cache["pool"] = torch.cuda.graph_pool_handle()               # the graphs never run concurrently: one private pool for all
+    return cache
+
+
 class VideoSession:
     """Single-object video state (reference SAM2VideoPredictor.init_state / add_language_embd / propagate_in_video,
     sam2.py:3771-4132).  Image features are computed once per frame and kept; the memory encoder runs only for frames
@@ -836,9 +853,7 @@ class VideoSession:
         m, f = self.m, self._ensure_feats()
         h, w = f["hw"]
         hw, dev = h * w, f["feat"].device
-        cache = m.__dict__.setdefault("_frame_graphs", {})
-        if "pool" not in cache:
-            cache["pool"] = torch.cuda.graph_pool_handle()
+        cache = _graph_cache(m, self)
         key = ("prompt", hw, tuple(language_embd.shape), str(dev), f["feat"].dtype)
         ent = cache.get(key)
         fresh = ent is None
@@ -934,9 +949,7 @@ class VideoSession:
         d = t - start
         n_nc, n_pp = min(d - 1, n_mem - 1), min(d - 1, max_pp)        # earlier non-conditioning memories / pointers in the bank
         cond = self.cond[start]
-        cache = m.__dict__.setdefault("_frame_graphs", {})
-        if "pool" not in cache:
-            cache["pool"] = torch.cuda.graph_pool_handle()           # the graphs never run concurrently: one private pool for all
+        cache = _graph_cache(m, self)
         key = (hw, n_nc, n_pp, str(dev), f["feat"].dtype)
         ent = cache.get(key)
         fresh = ent is None

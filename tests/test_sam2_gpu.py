@@ -165,3 +165,32 @@ def test_prompt_every_frame_graph_equals_eager(model, dev):
             ra = torch.cat([mk for _, mk in a.propagate()], dim=0)
             rb = model.language_embd_inference(VideoSession(model.sam2_model, vid, feats=a.feats), embs)
         assert rb.shape[0] == T and torch.equal(ra, rb.reshape(ra.shape))
+
+
+def test_frame_graphs_dropped_when_weights_change(model, dev):
+    """The captured prompt step reads weights through pointers: after an in-place weight update the graphs must be re-captured, and the result
+    must equal the eager path on the NEW weights."""
+    from rga3.model.sam2 import VideoSession
+
+    torch.manual_seed(13)
+    vid = (torch.randn(3, 3, 128, 128) * 0.5).to(torch.bfloat16).to(dev)
+    embs = [[torch.randn(1, 256).to(torch.bfloat16).to(dev)] for _ in range(3)]
+    w = model.sam2_model.sam_mask_decoder.iou_prediction_head.layers[0].weight
+    with torch.no_grad():
+        s0 = VideoSession(model.sam2_model, vid)
+        r0 = model.language_embd_inference(s0, embs)
+        keep = w.clone()
+        try:
+            w.mul_(1.5)
+            for p in model.sam2_model.sam_mask_decoder.output_hypernetworks_mlps.parameters():
+                p.mul_(0.5)
+            a = VideoSession(model.sam2_model, vid, feats=s0.feats)
+            for t in range(3):
+                a.add_language_embd(t, embs[t][0].reshape(1, 1, -1))
+            ra = torch.cat([mk for _, mk in a.propagate()], dim=0)
+            rb = model.language_embd_inference(VideoSession(model.sam2_model, vid, feats=s0.feats), embs)
+            assert torch.equal(ra, rb.reshape(ra.shape)) and not torch.equal(rb, r0)
+        finally:
+            w.copy_(keep)
+            for p in model.sam2_model.sam_mask_decoder.output_hypernetworks_mlps.parameters():
+                p.mul_(2.0)
