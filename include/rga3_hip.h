@@ -61,9 +61,11 @@ int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* r
  * small) those tilings run as 21 / 20. */
 int64_t rga3_gemm_workspace_bytes(void);
 /* C[M,N] (bf16 / f32) = A^T . B (+ bias[n]); A [K,M], B [K,N] bf16 row-major (K = tokens): the weight-gradient product dW = dY^T X of
- * nn.Linear / LoRA (autograd under reference train_joint.py:534) without transposing the activations first.  M, N multiples of 8. */
+ * nn.Linear / LoRA (autograd under reference train_joint.py:534) without transposing the activations first.  M, N multiples of 8.
+ * workspace (optional, caller-owned, 16-byte aligned): with few output tiles over many tokens (LoRA dW: 128 x 3584 over 2112-4160 tokens) K is
+ * cut into <= 16 slices whose f32 partial sums (Z * M * N * 4 bytes) are added in fixed order by a second launch. */
 int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                      int64_t ldc, int out_dtype, void* stream);
+                      int64_t ldc, int out_dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
 
 /* Variable-length fused attention forward (online softmax, fp32 statistics), bf16 in/out.

@@ -1097,6 +1097,8 @@ struct TnArgs {
     const unsigned short* B;  // [K, N]
     long lda, ldb;
     int K;
+    int kt_per_z;   // K-tiles (of 32) per grid.z slice; slices > 0 write f32 partial sums to slab z of p.C (see rga3_gemm_tn_bf16)
+    long slab;      // elements per slab (0: no K split)
 };
 
 template <bool OUT_F32>
@@ -1158,9 +1160,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (t.K + BK - 1) / BK;
-    load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_all = (t.K + BK - 1) / BK;
+    const int kt0 = (int)blockIdx.z * t.kt_per_z;            // this workgroup's K range (the whole of K without a split)
+    const int nk = min(nk_all, kt0 + t.kt_per_z);
+    if (t.slab) p.C = (void*)((float*)p.C + (long)blockIdx.z * t.slab);
+    load_tile(kt0);
+    for (int kt = kt0; kt < nk; ++kt) {
         store_tile(kt & 1);
         __syncthreads();   // tile kt visible; everyone is past the reads of tile kt-1 (the other buffer is free for kt+1)
         if (kt + 1 < nk) load_tile(kt + 1);
@@ -1178,6 +1183,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
     }
     __syncthreads();
     gemm_epilogue<4, 4, 64, 64, ACT_NONE, OUT_F32>(acc, p, smem, lane, m0, n0, wm, wn);
+}
+
+// out[i] = sum_z slabs[z][i] in fixed order (deterministic), to bf16 or f32; 4 elements per thread
+__global__ __launch_bounds__(256) void tn_slab_sum_kernel(const float* __restrict__ slabs, void* __restrict__ out, long n, long ldc, int ncols, int Z, int out_f32) {
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    f32x4 acc = *(const f32x4*)(slabs + i4);
+    for (int z = 1; z < Z; ++z) acc += *(const f32x4*)(slabs + (long)z * n + i4);
+    const long r = i4 / ncols, c = i4 % ncols;     // ncols % 8 == 0: a quad never crosses a row
+    if (out_f32) {
+        *(f32x4*)((float*)out + r * ldc + c) = acc;
+    } else {
+        u32x2 pk;
+        pk[0] = pack_bf2(acc[0], acc[1]);
+        pk[1] = pack_bf2(acc[2], acc[3]);
+        *(u32x2*)((unsigned short*)out + r * ldc + c) = pk;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1414,11 +1436,11 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
 // C[M, N] (bf16 or f32) = A^T . B (+ bias[n]) with A [K, M], B [K, N] bf16 row-major: the weight-gradient product dW = dY^T X without
 // transposing either operand first.  M, N multiples of 8; lda / ldb / ldc in elements.
 extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                                 int64_t ldb, int64_t ldc, int out_dtype, void* stream) {
+                                 int64_t ldb, int64_t ldc, int out_dtype, void* workspace, int64_t workspace_bytes, void* stream) {
     RGA3_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
     RGA3_CHECK_ARG(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0, "gemm_tn: bad shape M=%ld N=%ld K=%ld (M, N multiples of 8)", (long)M, (long)N, (long)K);
-    RGA3_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "gemm_tn: lda/ldb must be multiples of 8 elements");
-    RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "gemm_tn: pointers must be 16-byte aligned");
+    RGA3_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_tn: lda/ldb must be multiples of 8 elements, ldc of 4");
+    RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) == 0, "gemm_tn: pointers must be 16-byte aligned");
     RGA3_CHECK_ARG(out_dtype == RGA3_BF16 || out_dtype == RGA3_F32, "gemm_tn: out_dtype %d", out_dtype);
     RGA3_CHECK_ARG(cdiv(M, 128) <= 65535, "gemm_tn: M too large");
     GemmArgs a;
@@ -1430,9 +1452,37 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     a.ws = nullptr; a.ws_bytes = 0; a.dbg = 0;
     TnArgs t;
     t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
-    dim3 grid((unsigned)a.ntn, (unsigned)a.ntm);
-    if (out_dtype == RGA3_F32) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, t);
-    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, t);
+    const int nk = (int)cdiv(K, 32);
+    // few output tiles over many tokens (LoRA dW: 1 x 28 tiles, K = 2112 / 4160): cut K into Z slices, one workgroup each, f32 partial slabs in
+    // the caller's workspace, summed in fixed order by a second launch (deterministic; no atomics)
+    int Z = 1;
+    const long tiles = (long)a.ntm * a.ntn;
+    if (workspace && !bias && tiles < 128 && nk >= 32) {
+        Z = (int)(256 / tiles);
+        if (Z > 16) Z = 16;
+        if (Z > nk / 8) Z = nk / 8;
+        const long fit = workspace_bytes / (M * N * 4);
+        if (Z > fit) Z = (int)fit;
+        if (Z < 2) Z = 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (Z == 1) {
+        t.kt_per_z = nk; t.slab = 0;
+        dim3 grid((unsigned)a.ntn, (unsigned)a.ntm);
+        if (out_dtype == RGA3_F32) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a, t);
+        else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a, t);
+        RGA3_CHECK_LAUNCH("gemm_tn_kernel");
+        return 0;
+    }
+    t.kt_per_z = (int)cdiv(nk, Z);
+    Z = (int)cdiv(nk, t.kt_per_z);
+    t.slab = M * N;
+    a.C = workspace; a.ldc = N;
+    dim3 grid((unsigned)a.ntn, (unsigned)a.ntm, (unsigned)Z);
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a, t);
     RGA3_CHECK_LAUNCH("gemm_tn_kernel");
+    hipLaunchKernelGGL(tn_slab_sum_kernel, dim3((unsigned)cdiv(M * N / 4, 256)), dim3(256), 0, st, (const float*)workspace, C, (long)(M * N), (long)ldc, (int)N, Z,
+                       out_dtype == RGA3_F32 ? 1 : 0);
+    RGA3_CHECK_LAUNCH("tn_slab_sum_kernel");
     return 0;
 }

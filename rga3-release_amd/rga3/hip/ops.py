@@ -123,8 +123,13 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == out_dtype
+    ws = None
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles < 128 and K >= 1024:      # few output tiles over many tokens: give the kernel room to split K (<= 16 f32 slabs)
+        ws = torch.empty((min(16, 256 // tiles) * M * N,), dtype=torch.float32, device=a.device)
     _lib.check(_lib.load().rga3_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-                                             BF16 if out_dtype == torch.bfloat16 else F32, _stream()), "gemm_tn_bf16")
+                                             BF16 if out_dtype == torch.bfloat16 else F32, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
+               "gemm_tn_bf16")
     return out
 
 
