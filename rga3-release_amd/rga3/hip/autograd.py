@@ -75,7 +75,7 @@ class GeluFn(torch.autograd.Function):
 class AttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, cu_q, cu_k, max_q, max_k, scale):
-        o, lse = ops.attn_varlen(q, k, v, cu_q, cu_k, max_q, scale, False, return_lse=True)
+        o, lse = ops.attn_varlen(q, k, v, cu_q, cu_k, max_q, scale, False, return_lse=True, max_k=max_k)
         ctx.save_for_backward(q, k, v, o, lse, cu_q, cu_k)
         ctx.args = (max_q, max_k, scale)
         return o

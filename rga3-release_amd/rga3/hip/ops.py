@@ -134,7 +134,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
 
 
 def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = False, out=None, return_lse=False,
-                impl: int = 0, block=None):
+                impl: int = 0, block=None, max_k: int = 0):
     """softmax(q k^T * scale) v over packed variable-length segments.
 
     q [Tq, Hq, D], k/v [Tk, Hkv, D] (arbitrary token/head strides, unit stride on D); cu_* int32 [nseg+1].
@@ -152,9 +152,10 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
     # few query blocks x heads over a long key range (SAM2 memory attention: one head, 4096 queries, <= 28 736 keys): hand the kernel a
     # workspace so it can split the keys over up to 8 workgroups per query block
     bq, bk = (int(block[0]), int(block[1])) if block else (0, 0)   # block-diagonal visibility inside a segment: (query block, key block), powers of two
-    split_ws, max_k = None, 0
+    split_ws = None
     if not causal and ((int(max_q) + 63) // 64) * Hq * nseg < 128 and k.shape[0] >= 1024 and D % 4 == 0:
-        max_k = k.shape[0] if nseg == 1 else int((cu_k[1:] - cu_k[:-1]).max())
+        if not max_k:    # longest key segment: known to most callers (max_k); reading it back from cu_k is a device -> host sync
+            max_k = k.shape[0] if nseg == 1 else int((cu_k[1:] - cu_k[:-1]).max())
         if max_k >= 1024:
             split_ws = torch.empty((8 * Tq * Hq * (D + 1),), dtype=torch.float32, device=q.device)
     rc = _lib.load().rga3_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(lse),

@@ -335,7 +335,7 @@ class Attention(nn.Module):
         if _ag():
             o = AG.AttnFn.apply(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, nk, hd ** -0.5)
         else:
-            o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5)
+            o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5, max_k=nk)
         return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
 
 

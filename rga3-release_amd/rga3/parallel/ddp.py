@@ -60,23 +60,35 @@ class GradBucketReducer:
 
     def _on_grad(self, p):
         bi, off, n = self.slices[p]
-        self.flat[bi][off:off + n].add_(p.grad.reshape(-1)) if self._accum_started[bi] else self.flat[bi][off:off + n].copy_(p.grad.reshape(-1))
-        p.grad = None  # the bucket slice is the gradient from here on (no second copy kept)
+        if p.grad is not None:   # (a graphed backward hands an undefined gradient to parameters its forward never used: nothing to add)
+            if p in self._written:   # a later micro-step of the same optimizer step accumulates
+                self.flat[bi][off:off + n].add_(p.grad.reshape(-1))
+            else:
+                self.flat[bi][off:off + n].copy_(p.grad.reshape(-1))
+                self._written.add(p)
+            p.grad = None  # the bucket slice is the gradient from here on (no second copy kept)
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
-            self._accum_started[bi] = True
-            if self.sync and self.world > 1:
-                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-                self.handles.append((bi, dist.all_reduce(self.flat[bi], op=op, group=self.pg, async_op=True)))
+            self._launch(bi)
+
+    def _launch(self, bi):
+        self._accum_started[bi] = True
+        if self.sync and self.world > 1 and not self._launched[bi]:
+            self._launched[bi] = True
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self.handles.append((bi, dist.all_reduce(self.flat[bi], op=op, group=self.pg, async_op=True)))
 
     def begin_step(self):
         """Call before the first micro-step of an optimizer step."""
         self._accum_started = [False] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._written = set()
         self.handles = []
         self.pending = [len(b) for b in self.buckets]
 
     def begin_micro_step(self):
         self.pending = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -88,7 +100,17 @@ class GradBucketReducer:
             self.sync = old
 
     def finish(self):
-        """Wait for the outstanding collectives; afterwards grad_view(p) holds the averaged gradient."""
+        """Wait for the outstanding collectives; afterwards grad_view(p) holds the averaged gradient.  Buckets some of whose parameters got
+        no gradient in this step (parameters the loss does not reach: e.g. the IoU / object-score heads of the mask decoder, which only feed an
+        argmax) never count down to zero during backward: they are exchanged here (their untouched slices hold zeros)."""
+        for p in self.params:    # a parameter without a gradient in this step must not hand last step's slice to the optimizer
+            if p not in self._written:
+                bi, off, n = self.slices[p]
+                self.flat[bi][off:off + n].zero_()
+        if self.sync and self.world > 1:
+            for bi in range(len(self.buckets)):
+                if not self._launched[bi]:
+                    self._launch(bi)
         for bi, h in self.handles:
             h.wait()
             if not self._avg and self.world > 1:

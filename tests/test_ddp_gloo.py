@@ -40,6 +40,30 @@ def _worker(rank, world, port, q):
         for a, p in zip(ref, net.parameters()):
             a += p.grad / world
     ok = all(torch.allclose(a, b, atol=1e-5) for a, b in zip(got, ref))
+    # a parameter the loss never reaches (its bucket never counts down during backward) + accumulation: the bucket is still exchanged in
+    # finish(), the used parameters accumulate over both micro-steps, the unused one reads as zeros -- also on a second optimizer step
+    torch.manual_seed(1)
+    used, unused = torch.nn.Linear(8, 4), torch.nn.Linear(8, 4)
+    ref2 = [torch.zeros_like(p) for p in used.parameters()]          # reference first: no reducer hooks attached yet
+    for r in range(world):
+        used.zero_grad()
+        for m in range(2):
+            used(xs[2 * r + m]).pow(2).sum().backward()
+        for a, p in zip(ref2, used.parameters()):
+            a += p.grad / world
+    used.zero_grad()
+    red2 = GradBucketReducer(list(used.parameters()) + list(unused.parameters()), bucket_mb=1.0)   # ONE bucket holding all four tensors
+    for step in range(2):
+        red2.begin_step()
+        with red2.no_sync():
+            red2.begin_micro_step()
+            used(my[0]).pow(2).sum().backward()
+        red2.begin_micro_step()
+        used(my[1]).pow(2).sum().backward()
+        red2.finish()
+        ok = ok and all(torch.allclose(red2.grad_view(p), a, atol=1e-5) for p, a in zip(used.parameters(), ref2))
+        ok = ok and all(float(red2.grad_view(p).abs().max()) == 0.0 for p in unused.parameters())
+    red2.remove()
     q.put((rank, ok, [g.sum().item() for g in got]))
     dist.destroy_process_group()
 
