@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — RGA3 hot path on MI355X.
 
-Workload (config.workload): BASELINE.json configs[1] — Qwen2.5-VL-7B visual-encoder + LLM forward on one
-16-frame 448x448 clip (video_grid_thw [[8,32,32]], 8192 patches -> 2048 video tokens) + 64 text tokens
-(S = 2112), bf16, random-init weights of the public 7B architecture, synthetic inputs resident in HBM.
-A "step" is one such forward (one sample per GPU).  N > 1: one process per GPU, independent replicas
-(the forward path has no exchange step) — weak scaling, value = N samples / max-rank step time.
+Default workload (`--mode headline`, the BASELINE.json metric "video-QA samples/sec (fwd+bwd) at 7B/16-frame"):
+BASELINE.json configs[2] per GPU — the complete RGA3 training micro-step of reference train_joint.py:521-535 on one
+synthetic sample per GPU: Qwen2.5-VL-7B ViT (frozen) + decoder forward/backward with LoRA r128 on q/v, lm_head and
+embed_tokens trainable, SAM2-L on 16 frames 1024x1024 (frozen Hiera-L + FPN, trainable mask decoder + text_hidden_fcs,
+BCE + dice), bucketed gradient exchange, AdamW.  A "step" is one such micro-step + optimizer step; `value` = samples/s
+over all ranks.  The same process also measures BASELINE.json configs[1] (ViT + LLM forward, S = 2112) on the same
+weights: that is the `roofline` object (dominant kernel family = the bf16 MFMA GEMM, HIP events on the launch stream
+around every GEMM launch; `whole_forward_frac` is the >= 40 % target of the north star); `roofline_fwd_bwd` is the
+same measurement for the timed training step.  `cpu_baseline` times the fp32 oracle restatement (a "port": the
+reference is Python and cannot travel) on the host cores on a bounded sample of the same fwd+bwd workload.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel = the bf16 MFMA
-GEMM; achieved = algorithmic GEMM FLOPs per step / summed GEMM launch durations measured with HIP events on
-the launch stream in a separate instrumented pass of the same K steps) and `cpu_baseline` (the fp32 oracle
-restatement timed on this box's host cores on a bounded sample of the same workload).
+`--gpus N` with N > 1 and no torchrun environment: this process launches N ranks of itself (one per GPU, RCCL) BEFORE
+touching the GPU and exits with their code; with fewer than N visible GPUs it exits non-zero.  Under the driver's
+`python -m torch.distributed.run ... bench.py --gpus N` the ranks read RANK / LOCAL_RANK / WORLD_SIZE as usual.
+Only `tests/`, `smoke()` and this file's cpu_baseline leg import `oracle/`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +35,27 @@ import torch  # noqa: E402
 # algorithmic FLOPs per sample, SURVEY.md 8(d) / BASELINE.md 3
 GEMM_FLOPS = (10.33 + 0.0247 + 0.182 + 27.6 + 2.30) * 1e12   # ViT linear + patch + merger + LLM linear + lm_head
 ATTN_FLOPS = (0.247 + 0.90) * 1e12
-TOTAL_FLOPS = GEMM_FLOPS + ATTN_FLOPS                          # 41.6 T
+TOTAL_FLOPS = GEMM_FLOPS + ATTN_FLOPS                          # 41.6 T: configs[1] forward
 PEAK_BF16 = 2.5e15                                             # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def train_flops(sam_frames):
+    """Algorithmic FLOPs of one full RGA3 training sample as THIS build runs it: ViT fwd (frozen) + LLM fwd with the LM head on
+    labelled rows only + LLM dX (activations are kept: nothing is recomputed) + frozen Hiera-L fwd + mask decoder fwd+bwd."""
+    return (10.8 + 30.8 - 2.3 + 28.5 + 1.82 * sam_frames + 3 * 0.0036 * sam_frames) * 1e12
+
+
+# ------------------------------------------------------------------------------------------------ models / inputs
+def _init_params(model):
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+            elif "norm" in n or "ln_q" in n:
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.02)
 
 
 def build_model(dev):
@@ -44,38 +70,20 @@ def build_model(dev):
             model = Qwen2_5_VLForConditionalGeneration(cfg)
     finally:
         torch.set_default_dtype(old)
-    with torch.no_grad():
-        for n, p in model.named_parameters():
-            if p.dim() >= 2:
-                p.normal_(0.0, 0.02)
-            elif "norm" in n or "ln_q" in n:
-                p.fill_(1.0)
-            else:
-                p.normal_(0.0, 0.02)
+    _init_params(model)
     return model.eval(), cfg
 
 
-def make_inputs(cfg, dev, seed=0):
+def make_inputs(cfg, dev, seed=0, n_video=2048, grid=(8, 32, 32)):
+    """template + n_video x video_token_id + 64 others (S = 2112); config 5: n_video 4096, grid [16,32,32] (S = 4160)."""
     g = torch.Generator().manual_seed(seed)
-    px = torch.randn(8192, 1176, generator=g).clamp_(-1.8, 2.2).to(torch.bfloat16).to(dev)
+    px = torch.randn(grid[0] * grid[1] * grid[2], 1176, generator=g).clamp_(-1.8, 2.2).to(torch.bfloat16).to(dev)
     text = torch.randint(0, 151643, (64,), generator=g)
-    ids = torch.cat([text[:14], torch.tensor([cfg.vision_start_token_id]), torch.full((2048,), cfg.video_token_id),
+    ids = torch.cat([text[:14], torch.tensor([cfg.vision_start_token_id]), torch.full((n_video,), cfg.video_token_id),
                      torch.tensor([cfg.vision_end_token_id]), text[16:]])[None]
-    assert ids.shape[1] == 2112
+    assert ids.shape[1] == n_video + 64
     return dict(input_ids=ids.to(dev), attention_mask=torch.ones_like(ids).to(dev), pixel_values_videos=px,
-                video_grid_thw=torch.tensor([[8, 32, 32]]), second_per_grid_ts=torch.tensor([1.0]))
-
-
-def make_inputs_32f(cfg, dev, seed=0):
-    """32 frames 448x448 -> grid [[16,32,32]], 16 384 patches, 4096 video tokens + 64 others = S 4160."""
-    g = torch.Generator().manual_seed(seed)
-    px = torch.randn(16384, 1176, generator=g).clamp_(-1.8, 2.2).to(torch.bfloat16).to(dev)
-    text = torch.randint(0, 151643, (64,), generator=g)
-    ids = torch.cat([text[:14], torch.tensor([cfg.vision_start_token_id]), torch.full((4096,), cfg.video_token_id),
-                     torch.tensor([cfg.vision_end_token_id]), text[16:]])[None]
-    assert ids.shape[1] == 4160
-    return dict(input_ids=ids.to(dev), attention_mask=torch.ones_like(ids).to(dev), pixel_values_videos=px,
-                video_grid_thw=torch.tensor([[16, 32, 32]]), second_per_grid_ts=torch.tensor([1.0]))
+                video_grid_thw=torch.tensor([list(grid)]), second_per_grid_ts=torch.tensor([1.0]))
 
 
 def build_full(dev, rank, sam_frames):
@@ -93,18 +101,282 @@ def build_full(dev, rank, sam_frames):
             model.initialize_sam_modules(cfg)
     finally:
         torch.set_default_dtype(old)
+    _init_params(model)
+    batch = make_batch(cfg, dev, batch=1, frames_mllm=16, frames_sam=sam_frames, seed=rank)
+    return model, cfg, batch
+
+
+def make_trainable(model, full, reducer_kw=None):
+    """LoRA + trainable set of reference train_joint.py:193-251 (r128 / alpha 256 / dropout 0.05 on q_proj, v_proj of the decoder; lm_head, embed_tokens,
+    and on the full model the SAM2 mask decoder + text_hidden_fcs), the bucketed gradient exchange and the fused AdamW of :300-324."""
+    from rga3.model.qwen_train import add_lora
+    from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
+
+    add_lora(model, r=128, alpha=256, dropout=0.05, exclude=("sam_model", "grounding_encoder", "visual", "text_hidden_fcs"))
+    model.train()
+    for n, p in model.named_parameters():
+        p.requires_grad_(("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight") or (full and ("sam_mask_decoder" in n or "text_hidden_fcs" in n)))
     with torch.no_grad():
         for n, p in model.named_parameters():
-            if p.dim() >= 2:
-                p.normal_(0.0, 0.02)
-            elif "norm" in n or "ln_q" in n:
-                p.fill_(1.0)
-            else:
-                p.normal_(0.0, 0.02)
-    batch = make_batch(cfg, dev, batch=1, frames_mllm=16, frames_sam=sam_frames, seed=rank)
-    return model.train(), cfg, batch
+            if "lora_B" in n:
+                p.normal_(0.0, 0.01)
+    trainables = [p for p in model.parameters() if p.requires_grad]
+    sparse = [model.model.embed_tokens.weight] if model.model.embed_tokens.weight.requires_grad else []
+    reducer = GradBucketReducer(trainables, bucket_mb=256.0, sparse_params=sparse, **(reducer_kw or {}))
+    opt = FusedAdamW(trainables, lr=4e-5, betas=(0.9, 0.95), weight_decay=0.0, max_grad_norm=1.0)
+    return trainables, reducer, opt
 
 
+class GemmTimer:
+    """HIP events (torch.cuda.Event on the stream the kernels are launched on) around every GEMM-family launch of rga3.hip.ops."""
+
+    def __init__(self, ops):
+        self.ops, self.ev, self.flops, self.bytes = ops, [], 0.0, 0.0
+        self._real = {}
+
+    def _wrap(self, name, shape_of):
+        real = getattr(self.ops, name)
+        self._real[name] = real
+
+        def timed(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = real(*a, **k)
+            e.record()
+            self.ev.append((s, e))
+            M, N, K = shape_of(a)
+            self.flops += 2.0 * M * N * K
+            self.bytes += a[0].numel() * a[0].element_size() + a[1].numel() * a[1].element_size() + r.numel() * r.element_size()
+            return r
+        setattr(self.ops, name, timed)
+
+    def __enter__(self):
+        self._wrap("gemm", lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]))
+        self._wrap("gemm_tn", lambda a: (a[0].shape[1], a[1].shape[1], a[0].shape[0]))
+        self._wrap("gemm_fp8", lambda a: (a[0].shape[0], a[2].shape[0], a[0].shape[1]))
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._real.items():
+            setattr(self.ops, n, f)
+
+    def total_ms(self):
+        torch.cuda.synchronize()
+        return sum(s.elapsed_time(e) for s, e in self.ev)
+
+
+def _traffic(tag):
+    """HBM-side traffic per GEMM launch cannot be sampled inside the timed run (PMC needs rocprofv3): it comes from the committed two-pass
+    FETCH_SIZE / WRITE_SIZE collection of this same command, summarised by tools/pmc_traffic.py."""
+    for r in ("r02",):
+        path = os.path.join(ROOT, "profiles", f"{r}_bench_{tag}_gemm_traffic.json")
+        if os.path.exists(path):
+            tj = json.load(open(path))
+            return round(tj["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)"
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------ cpu baseline (oracle "port")
+def _host_threads():
+    """Threads for the CPU leg: all hardware threads oversubscribe the fp32 GEMMs on SMT hosts (round 1: 256 threads ran 2.6x slower than the
+    reference stack on 8 cores) -- a 2048^3 product is timed at a few thread counts and the fastest is used."""
+    n = os.cpu_count() or 1
+    cands = sorted({c for c in (n, n // 2, 64, 32, 16, 8) if 1 <= c <= n}, reverse=True)
+    a, b = torch.randn(2048, 2048), torch.randn(2048, 2048)
+    best, best_t = cands[-1], float("inf")
+    for c in cands:
+        torch.set_num_threads(c)
+        (a @ b)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            (a @ b)
+        t = time.perf_counter() - t0
+        if t < best_t:
+            best, best_t = c, t
+    torch.set_num_threads(best)
+    return best
+
+
+def _oracle_vit_params(R):
+    P = {"visual.patch_embed.proj.weight": R(1280, 1176), "visual.merger.ln_q.weight": torch.ones(1280),
+         "visual.merger.mlp.0.weight": R(5120, 5120), "visual.merger.mlp.0.bias": R(5120), "visual.merger.mlp.2.weight": R(3584, 5120),
+         "visual.merger.mlp.2.bias": R(3584)}
+    for i in range(2):
+        p = f"visual.blocks.{i}."
+        P.update({p + "norm1.weight": torch.ones(1280), p + "norm2.weight": torch.ones(1280), p + "attn.qkv.weight": R(3840, 1280),
+                  p + "attn.qkv.bias": R(3840), p + "attn.proj.weight": R(1280, 1280), p + "attn.proj.bias": R(1280),
+                  p + "mlp.gate_proj.weight": R(3420, 1280), p + "mlp.gate_proj.bias": R(3420), p + "mlp.up_proj.weight": R(3420, 1280),
+                  p + "mlp.up_proj.bias": R(3420), p + "mlp.down_proj.weight": R(1280, 3420), p + "mlp.down_proj.bias": R(1280)})
+    return P
+
+
+def _oracle_layer_params(R, lora=False):
+    p = "model.layers.0."
+    L = {p + "input_layernorm.weight": torch.ones(3584), p + "post_attention_layernorm.weight": torch.ones(3584),
+         p + "self_attn.q_proj.weight": R(3584, 3584), p + "self_attn.q_proj.bias": R(3584), p + "self_attn.k_proj.weight": R(512, 3584),
+         p + "self_attn.k_proj.bias": R(512), p + "self_attn.v_proj.weight": R(512, 3584), p + "self_attn.v_proj.bias": R(512),
+         p + "self_attn.o_proj.weight": R(3584, 3584), p + "mlp.gate_proj.weight": R(18944, 3584), p + "mlp.up_proj.weight": R(18944, 3584),
+         p + "mlp.down_proj.weight": R(3584, 18944), "model.norm.weight": torch.ones(3584)}
+    if lora:
+        L["lora_scaling"] = 2.0
+        for nm, o in (("q_proj", 3584), ("v_proj", 512)):
+            L[p + f"self_attn.{nm}.lora_A.default.weight"] = R(128, 3584).requires_grad_(True)
+            L[p + f"self_attn.{nm}.lora_B.default.weight"] = R(o, 128).requires_grad_(True)
+    return L
+
+
+def cpu_baseline(train: bool, sam_frames: int = 16):
+    """Oracle (fp32 restatement of the reference's algorithm, 'port') on the host cores, bounded sample: one windowed + one full ViT block, one decoder
+    layer and a 1/16 lm_head slice at 7B dims (train: + their backward as the reference runs it under gradient checkpointing, + one SAM2-L frame
+    through Hiera-L/FPN and the mask decoder fwd+bwd), extrapolated to a whole sample (28 + 4 ViT blocks, 28 layers, lm_head, sam_frames frames)."""
+    from oracle import qwen25vl as Q
+
+    cores = _host_threads()
+    g = torch.Generator().manual_seed(0)
+    R = lambda *s: torch.randn(*s, generator=g) * 0.02
+    tc = Q.TextCfg(num_hidden_layers=1, vocab_size=152064 // 16)
+    P = _oracle_vit_params(R)
+    px = torch.randn(8192, 1176, generator=g)
+    grid = np.array([[8, 32, 32]])
+
+    def vit_time(depth, full):
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            Q.vit_forward(P, px, grid, Q.QwenCfg(vision=Q.VisionCfg(depth=depth, fullatt_block_indexes=full), text=tc))
+            return time.perf_counter() - t0
+
+    t_em = vit_time(0, ())
+    t_win = vit_time(1, ()) - t_em
+    t_full = vit_time(2, (1,)) - t_em - t_win
+    t_vit = t_em + 28 * t_win + 4 * t_full
+    cfg1 = Q.QwenCfg(vision=Q.VisionCfg(depth=0, fullatt_block_indexes=()), text=tc)
+    L = _oracle_layer_params(R, lora=train)
+    x = torch.randn(1, 2112, 3584, generator=g)
+    pos = torch.arange(2112)[None, None].expand(3, 1, -1)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        h = Q.llm_forward(L, x, pos, None, cfg1)
+        t_layer_f = time.perf_counter() - t0
+    wl = R(152064 // 16, 3584)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        (h[0] @ wl.t()).float()
+        t_lm_f = (time.perf_counter() - t0) * 16
+    parts = f"patch-embed+merger {t_em:.2f}s, 1 windowed ViT block {t_win:.2f}s, 1 full-attention ViT block {t_full:.2f}s, 1 decoder layer S=2112 fwd {t_layer_f:.2f}s, lm_head fwd (1/16 slice x16) {t_lm_f:.2f}s"
+    if not train:
+        total = t_vit + 28 * t_layer_f + t_lm_f
+        return {"value": round(1.0 / total, 6), "unit": "samples/s", "cores": cores, "kind": "port",
+                "sample": f"oracle fp32 at 7B dims on {cores} host threads: {parts}; extrapolated 28+4 blocks, 28 layers -> {total:.1f}s per forward"}
+    # ---- backward legs, as the reference runs them: checkpointed layer = forward (no grad) + recompute + backward (train_joint.py:188)
+    xg = x.clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    hh = Q.llm_forward(L, xg, pos, None, cfg1)
+    hh.square().mean().backward()
+    t_layer_fb = time.perf_counter() - t0
+    wlg = wl.clone().requires_grad_(True)
+    hg = h[0].clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    torch.logsumexp((hg @ wlg.t()).float(), -1).mean().backward()
+    t_lm_fb = (time.perf_counter() - t0) * 16
+    # ---- SAM2-L: one frame through the frozen Hiera-L + FPN, mask decoder fwd+bwd
+    from oracle import sam2 as S
+    from rga3.model.sam2 import SAM2
+    torch.manual_seed(1)
+    sm = SAM2()
+    PS = {}
+    with torch.no_grad():
+        for k, v in sm.sam2_model.state_dict().items():
+            PS[k] = (torch.randn(v.shape, generator=g) * 0.02) if v.dim() >= 2 else (torch.ones(v.shape) if "norm" in k and k.endswith("weight") else torch.zeros(v.shape))
+    del sm
+    scfg = S.Sam2Cfg()
+    img = torch.randn(1, 3, 1024, 1024, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        bo = S.image_encoder_forward(PS, img, scfg)
+        t_enc = time.perf_counter() - t0
+    for k in PS:
+        if k.startswith("sam_mask_decoder."):
+            PS[k].requires_grad_(True)
+    feats = S.prepare_backbone_features(bo)
+    emb = torch.randn(1, 1, 256, generator=g, requires_grad=True)
+    t0 = time.perf_counter()
+    out = S.inject_language_embd_train(PS, feats, emb, scfg)
+    (out[1] if isinstance(out, (tuple, list)) else out).float().square().mean().backward()
+    t_dec = time.perf_counter() - t0
+    total = t_vit + 28 * (t_layer_f + t_layer_fb) + t_lm_fb + sam_frames * (t_enc + t_dec)
+    return {"value": round(1.0 / total, 6), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle fp32 at 7B / SAM2-L dims on {cores} host threads (of {os.cpu_count()}): {parts}, decoder layer recompute+backward {t_layer_fb:.2f}s, "
+                       f"lm_head+CE fwd+bwd (1/16 slice x16) {t_lm_fb:.2f}s, 1 SAM2-L frame Hiera-L+FPN {t_enc:.2f}s, mask decoder fwd+bwd {t_dec:.2f}s; extrapolated to "
+                       f"28+4 ViT blocks (fwd, frozen), 28 checkpointed layers (fwd + recompute + bwd), full-logits CE, {sam_frames} SAM2 frames -> {total:.1f}s per training sample"),
+            "reference_stack_note": "SURVEY.md 8(d): the reference itself (transformers 5.15 + model/sam2.py, fp32, 8 cores of the survey container) ran the same forward in about 195 s; "
+                                    "its Python cannot travel to this box"}
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args):
+    """Parent of a multi-GPU run: never touches the GPU (torch.cuda.device_count() does not initialise it on this image), starts N ranks of this file
+    through torch.distributed.run and exits with their code (reference launcher: run_torchrun.sh:6-12,23)."""
+    if args.mode != "ddp_selftest":
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus:
+            print(f"bench.py: {args.gpus} GPUs requested, {n_vis} visible", file=sys.stderr)
+            sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def ddp_selftest(args, rank, world):
+    """CPU / gloo run of the same launcher, rendezvous, gradient-exchange and timing code with a toy torch module in place of the model (no HIP kernels:
+    tests/test_bench_launcher.py drives `bench.py --gpus 2 --mode ddp_selftest` here, where there is no GPU).  Not a benchmark line."""
+    import torch.distributed as dist
+    from rga3.parallel.ddp import GradBucketReducer
+
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 8))
+    params = list(net.parameters())
+    reducer = GradBucketReducer(params, bucket_mb=0.02)
+    x = torch.randn(32, 64, generator=torch.Generator().manual_seed(rank))
+
+    def step():
+        reducer.begin_step()
+        reducer.begin_micro_step()
+        net(x).square().mean().backward()
+        reducer.finish()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    g0 = reducer.grad_view(params[0]).clone()
+    same = True
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        gs = [torch.empty_like(g0) for _ in range(world)]
+        dist.all_gather(gs, g0)
+        same = all(torch.equal(gs[0], t) for t in gs)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "metric": "ddp launcher self-test (toy module, CPU, gloo)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(el) / args.steps * 1e3, 3), "replicas_agree": bool(same), "buckets": len(reducer.buckets)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    sys.exit(0 if same else 1)
+
+
+# ------------------------------------------------------------------------------------------------ sam2 stream (configs[3])
 def sam2_stream(args, dev, rank, world, dist):
     """BASELINE configs[3]: one step = one 32-frame ref-VOS stream through SAM2-L's memory path -- language
     prompt on frame 0 only, then propagate (memory attention over the growing bank, mask decoder, memory encoder per frame).
@@ -176,10 +448,15 @@ def sam2_stream(args, dev, rank, world, dist):
         fps = world * T / (elapsed / args.steps)
         # algorithmic FLOPs per frame of the memory path: memory attention <= 0.61 T (cross-attention grows with the bank:
         # 4.19 M x KV, KV = 4096 x min(t, 7) + 4 x min(t, 16) pointer tokens), memory encoder 11.6 G, mask decoder 3.6 G
-        fl = 0.0
+        fl, by = 0.0, 0.0
         for tt in range(1, T):
             kv = 4096 * min(tt, 7) + 4 * min(tt, 16)
             fl += 54.8e9 + 68.7e9 + 4.19e6 * kv + 11.6e9 + 3.6e9
+            # algorithmic HBM bytes per frame (SURVEY.md 8(d) "Algorithmic bytes"): frame features in (64x64x256 + 128x128x64 + 256x256x32 bf16 = 7.3 MB), the bank
+            # (64-d bf16 memory + its position table, min(t, 7) slots) read once per frame, the new memory slot written (0.52 MB), the selected
+            # 1024x1024 f32 mask written (4.2 MB) and re-read by the memory encoder, weights of the three modules (11.5 M params bf16 = 23 MB, L2/MALL-resident)
+            by += 7.3e6 + 2 * (64 * 4096 * 2) * min(tt, 7) + 0.52e6 + 2 * 4.2e6 + 23e6
+        sec = elapsed / args.steps
         line = {"metric": "SAM2-L memory-attention mask-decoder stream, frames/sec (32-frame 1024x1024 ref-VOS stream, prompt on frame 0)", "value": round(fps, 2),
                 "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -187,75 +464,71 @@ def sam2_stream(args, dev, rank, world, dist):
                                        "embedding, frames 1.. propagate (memory attention over <= 7 memory frames + <= 16 object pointers, mask decoder, "
                                        "memory encoder); image features precomputed outside the timed region", "frames": T, "parallelism": f"replicas x{world}",
                            "prompt_every_frame_frames_per_s": round(world * T / (elapsed_prompt / args.steps), 2), "encoder_inclusive_frames_per_s": round(world * T / (elapsed_enc / args.steps), 2), "counts": sess.counts},
-                "roofline": {"bound": "mfma", "achieved": round(fl / (elapsed / args.steps) / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                             "frac": round(fl / (elapsed / args.steps) / PEAK_BF16, 4), "traffic": None,
-                             "note": "whole-stream algorithmic FLOPs / stream time; the streaming stages (bank concat, RoPE over the keys, mask upsample, "
-                                     "LayerNorm2d / dw-conv of the memory encoder) are HBM-bound, the attention cores MFMA-bound (SURVEY.md 8(d))"},
+                "roofline": {"bound": "mfma", "achieved": round(fl / sec / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                             "frac": round(fl / sec / PEAK_BF16, 4), "traffic": None,
+                             "note": "whole-stream algorithmic FLOPs / stream time; the attention cores are MFMA-bound, the streaming stages HBM-bound (SURVEY.md 8(d): report both roofs)"},
+                "roofline_hbm": {"bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(by / sec / PEAK_HBM, 4), "traffic": None,
+                                 "algorithmic_bytes_per_frame": round(by / (T - 1)),
+                                 "note": "whole-stream algorithmic HBM bytes (frame features, bank + position table once per frame, new memory slot, selected mask write + re-read, "
+                                         "module weights) / stream time"},
                 "cpu_baseline": None}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline():
-    """Oracle (fp32 restatement, 'port') on the host cores: one windowed + one full ViT block, one decoder layer and
-    a 1/16 lm_head slice at 7B dims, extrapolated to a whole forward (28 win + 4 full blocks, 28 layers, lm_head)."""
-    import torch.nn.functional as F
-    from oracle import qwen25vl as Q
+# ------------------------------------------------------------------------------------------------ main
+def measure_forward(model_fwd, inputs, args, rank, refine=True):
+    """configs[1]: K timed forwards (+ the GEMM-family instrumented pass and the output check on rank 0).  Returns (ms per step, roofline dict, verify dict)."""
+    from rga3.hip import ops, tuner
 
-    torch.set_num_threads(os.cpu_count())
-    cores = torch.get_num_threads()
-    g = torch.Generator().manual_seed(0)
-    R = lambda *s: torch.randn(*s, generator=g) * 0.02
-    vc, tc = Q.VisionCfg(depth=2, fullatt_block_indexes=(1,)), Q.TextCfg(num_hidden_layers=1, vocab_size=152064 // 16)
-    cfg = Q.QwenCfg(vision=vc, text=tc)
-    P = {"visual.patch_embed.proj.weight": R(1280, 1176), "visual.merger.ln_q.weight": torch.ones(1280),
-         "visual.merger.mlp.0.weight": R(5120, 5120), "visual.merger.mlp.0.bias": R(5120), "visual.merger.mlp.2.weight": R(3584, 5120),
-         "visual.merger.mlp.2.bias": R(3584)}
-    for i in range(2):
-        p = f"visual.blocks.{i}."
-        P.update({p + "norm1.weight": torch.ones(1280), p + "norm2.weight": torch.ones(1280), p + "attn.qkv.weight": R(3840, 1280),
-                  p + "attn.qkv.bias": R(3840), p + "attn.proj.weight": R(1280, 1280), p + "attn.proj.bias": R(1280),
-                  p + "mlp.gate_proj.weight": R(3420, 1280), p + "mlp.gate_proj.bias": R(3420), p + "mlp.up_proj.weight": R(3420, 1280),
-                  p + "mlp.up_proj.bias": R(3420), p + "mlp.down_proj.weight": R(1280, 3420), p + "mlp.down_proj.bias": R(1280)})
-    px = torch.randn(8192, 1176, generator=g)
-    grid = np.array([[8, 32, 32]])
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        Q.vit_forward(P, px, grid, cfg)
-        t_vit2 = time.perf_counter() - t0          # patch-embed + 1 windowed + 1 full block + merger
-        vc1 = Q.VisionCfg(depth=1, fullatt_block_indexes=())
-        t0 = time.perf_counter()
-        Q.vit_forward(P, px, grid, Q.QwenCfg(vision=vc1, text=tc))
-        t_vit1 = time.perf_counter() - t0          # patch-embed + 1 windowed block + merger
-        p = "model.layers.0."
-        L = {p + "input_layernorm.weight": torch.ones(3584), p + "post_attention_layernorm.weight": torch.ones(3584),
-             p + "self_attn.q_proj.weight": R(3584, 3584), p + "self_attn.q_proj.bias": R(3584), p + "self_attn.k_proj.weight": R(512, 3584),
-             p + "self_attn.k_proj.bias": R(512), p + "self_attn.v_proj.weight": R(512, 3584), p + "self_attn.v_proj.bias": R(512),
-             p + "self_attn.o_proj.weight": R(3584, 3584), p + "mlp.gate_proj.weight": R(18944, 3584), p + "mlp.up_proj.weight": R(18944, 3584),
-             p + "mlp.down_proj.weight": R(3584, 18944), "model.norm.weight": torch.ones(3584)}
-        x = torch.randn(1, 2112, 3584, generator=g)
-        pos = torch.arange(2112)[None, None].expand(3, 1, -1)
-        t0 = time.perf_counter()
-        h = Q.llm_forward(L, x, pos, None, cfg)
-        t_layer = time.perf_counter() - t0
-        wl = R(152064 // 16, 3584)
-        t0 = time.perf_counter()
-        (h @ wl.t()).float()
-        t_lm = (time.perf_counter() - t0) * 16
-    t_full_blk = t_vit2 - t_vit1
-    t_win_blk_plus = t_vit1                         # embed + merger + 1 windowed block
-    # embed+merger cost appears once; estimate windowed block as t_vit1 minus (embed+merger ~ measured via depth-0)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        Q.vit_forward(P, px, grid, Q.QwenCfg(vision=Q.VisionCfg(depth=0, fullatt_block_indexes=()), text=tc))
-        t_em = time.perf_counter() - t0
-    t_win = t_win_blk_plus - t_em
-    total = t_em + 28 * t_win + 4 * t_full_blk + 28 * t_layer + t_lm
-    return {"value": round(1.0 / total, 6), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle fp32 at 7B dims on {cores} host threads: patch-embed+merger {t_em:.2f}s, 1 windowed ViT block {t_win:.2f}s, "
-                       f"1 full-attention ViT block {t_full_blk:.2f}s, 1 decoder layer S=2112 {t_layer:.2f}s, lm_head (1/16 slice x16) {t_lm:.2f}s; "
-                       f"extrapolated 28+4 blocks, 28 layers -> {total:.1f}s per sample")}
+    def step():
+        with torch.no_grad():
+            return model_fwd(**inputs)
+
+    if refine and not args.no_refine:
+        rw, rr = (os.environ.get("RGA3_REFINE", "1.5,5").split(",") + ["5"])[:2]
+        ch = tuner.refine(step, reps=int(rr), within=float(rw))
+        if rank == 0 and ch:
+            print("tuner.refine changed %d shape(s): %s" % (len(ch), {str(k[:3]): v for k, v in ch.items()}), file=sys.stderr)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    if rank != 0:
+        return ms, None, None
+    with GemmTimer(ops) as gt:
+        for _ in range(args.steps):
+            step()
+        tot_ms = gt.total_ms()
+    n_launch = len(gt.ev) // args.steps
+    gemm_ms_step = tot_ms / args.steps
+    achieved = GEMM_FLOPS / (gemm_ms_step * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "gemm_nt_* family: gemm_nt_pp_kernel / gemm_nt_sk_kernel / gemm_nt_kernel (bf16 16x16x32 MFMA)",
+            "workload": "BASELINE.json configs[1]: Qwen2.5-VL-7B ViT+LLM forward, 16 frames 448x448 (grid [8,32,32]), S=2112, bf16 (measured in this process on the same weights)",
+            "achieved": round(achieved, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
+            "launches_per_step": n_launch, "avg_launch_ms": round(gemm_ms_step / max(n_launch, 1), 5), "gemm_ms_per_step": round(gemm_ms_step, 3),
+            "forward_ms_per_step": round(ms, 3), "forward_samples_per_s": round(1e3 / ms, 3),
+            "whole_forward_frac": round(TOTAL_FLOPS / (ms * 1e-3) / PEAK_BF16, 4), "flops_per_forward": TOTAL_FLOPS,
+            "algorithmic_bytes_per_launch": round(gt.bytes / max(len(gt.ev), 1))}
+    tr, src = _traffic("forward")
+    if tr is not None:
+        roof["traffic"], roof["traffic_source"] = tr, src
+    # ---- the timed output is checked: same forward on the first-generation single-phase 256x256 tiling (id 10) for every GEMM shape
+    lg = out.logits.float()
+    assert torch.isfinite(lg).all(), "non-finite logits"
+    with tuner.force(10):
+        ref = step().logits.float()
+    rel = float((lg - ref).norm() / ref.norm())
+    verify = {"logits_rel_l2_vs_tile10": round(rel, 6), "logits_abs_sum": round(float(lg.abs().sum()), 3), "logits_argmax_sum": int(lg.argmax(-1).sum()),
+              "stream_k_timeouts": ops.gemm_stream_k_timeouts()}
+    assert rel < 2e-3, f"timed forward disagrees with the tile-10 reference run: rel-L2 {rel}"
+    assert verify["stream_k_timeouts"] == 0, "stream-K hand-off timed out: results of this run are not trustworthy"
+    return ms, roof, verify
 
 
 def main():
@@ -264,23 +537,36 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["forward", "train", "train_full", "sam2_stream", "lora_fp8"], default="forward",
-                    help="forward = BASELINE configs[1] (default, the driver's metric); train = LLM fwd+bwd LoRA step with DDP gradient exchange; "
-                         "train_full = BASELINE configs[2] per GPU: full RGA3 (Qwen2.5-VL-7B + SAM2-L, 16 SAM frames) fwd+bwd + AdamW; "
-                         "lora_fp8 = BASELINE configs[4]: LoRA step, 32 frames 448x448 (S = 4160), grad-accum 4, e4m3 GEMMs for the frozen decoder weights; "
-                         "sam2_stream = BASELINE configs[3]: SAM2-L memory-attention mask-decoder stream over 32 frames 1024x1024, prompt on frame 0")
+    ap.add_argument("--mode", choices=["headline", "forward", "train", "train_full", "sam2_stream", "lora_fp8", "ddp_selftest"], default="headline",
+                    help="headline (default) = BASELINE metric: configs[2] per GPU, full RGA3 (Qwen2.5-VL-7B + SAM2-L, 16 SAM frames) fwd+bwd + AdamW as `value`, plus the "
+                         "configs[1] forward roofline in the same line; forward = configs[1] only; train = LLM-side LoRA step without SAM2; train_full = headline without "
+                         "the forward leg; lora_fp8 = configs[4]: LoRA step, 32 frames 448x448 (S = 4160), grad-accum 4, e4m3 GEMMs for the frozen decoder weights; "
+                         "sam2_stream = configs[3]: SAM2-L memory-attention mask-decoder stream over 32 frames 1024x1024, prompt on frame 0; "
+                         "ddp_selftest = launcher / gradient-exchange self-test on CPU with gloo (tests only)")
     ap.add_argument("--stream-frames", type=int, default=32)
     ap.add_argument("--grad-accum", type=int, default=4)
     ap.add_argument("--no-fp8", action="store_true", help="lora_fp8 mode with bf16 GEMMs (A/B)")
     ap.add_argument("--no-graph", action="store_true", help="sam2_stream mode: run every frame eagerly (A/B of the hipGraph replay)")
-    ap.add_argument("--no-refine", action="store_true", help="forward mode: skip the in-situ tile refinement (A/B)")
+    ap.add_argument("--no-refine", action="store_true", help="skip the in-situ tile refinement of the forward leg (A/B)")
     ap.add_argument("--refine", action="store_true", help="training modes, 1 GPU: run the in-situ tile refinement before the warmup")
+    ap.add_argument("--dense-embed-grad", action="store_true", help="exchange embed_tokens' gradient as a dense bucket (A/B of the sparse row exchange)")
     ap.add_argument("--sam-frames", type=int, default=16)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.mode == "ddp_selftest":
+        return ddp_selftest(args, rank, world)
+    n_vis = torch.cuda.device_count()
+    if n_vis < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        print(f"bench.py: {args.gpus} GPUs requested, {n_vis} visible", file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -294,76 +580,6 @@ def main():
     lib.load()  # fail loudly if the HIP extension is missing
     if args.mode == "sam2_stream":
         return sam2_stream(args, dev, rank, world, dist)
-    if args.mode == "train_full":
-        model, cfg, inputs = build_full(dev, rank, args.sam_frames)
-    else:
-        model, cfg = build_model(dev)
-        inputs = make_inputs_32f(cfg, dev, seed=rank) if args.mode == "lora_fp8" else make_inputs(cfg, dev, seed=rank)
-
-    accum = args.grad_accum if args.mode == "lora_fp8" else 1
-    if args.mode in ("train", "train_full", "lora_fp8"):
-        from rga3.model.qwen_train import add_lora
-        from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
-
-        add_lora(model, r=128, alpha=256, dropout=0.05, exclude=("sam_model", "grounding_encoder", "visual", "text_hidden_fcs"))  # reference defaults (train_joint.py)
-        model.train()   # LoRA dropout active (the LoRALinear modules are created in training mode by add_lora on a train() model)
-        full = args.mode == "train_full"
-        for n, p in model.named_parameters():   # trainable set of reference train_joint.py:237-251
-            p.requires_grad_(("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight") or (full and ("sam_mask_decoder" in n or "text_hidden_fcs" in n)))
-        with torch.no_grad():
-            for n, p in model.named_parameters():
-                if "lora_B" in n:
-                    p.normal_(0.0, 0.01)
-        if not full:
-            labels = torch.full_like(inputs["input_ids"], -100)
-            labels[:, -6:] = inputs["input_ids"][:, -6:]
-            inputs["labels"] = labels
-        trainables = [p for p in model.parameters() if p.requires_grad]
-        reducer = GradBucketReducer(trainables, bucket_mb=256.0)
-        opt = FusedAdamW(trainables, lr=4e-5, betas=(0.9, 0.95), weight_decay=0.0, max_grad_norm=1.0)
-
-        class _Out:
-            pass
-
-        if args.mode == "lora_fp8" and not args.no_fp8:
-            from rga3.model.qwen_train import set_fp8_frozen_gemms
-            set_fp8_frozen_gemms(True)
-
-        def step():
-            reducer.begin_step()
-            for mi in range(accum):   # gradient accumulation: gradients are exchanged once per optimizer step (DDP no_sync)
-                reducer.begin_micro_step()
-                out = model(**inputs)
-                if isinstance(out, dict):
-                    out = type("O", (), {"loss": out["loss"]})()
-                if mi + 1 < accum:
-                    with reducer.no_sync():
-                        (out.loss / accum).backward()
-                else:
-                    (out.loss / accum).backward()
-            reducer.finish()
-            opt.step(reducer.grad_view, reducer.flat_grads())
-            o = _Out()
-            o.logits = out.loss.detach().reshape(1)
-            return o
-    else:
-        def step():
-            with torch.no_grad():
-                return model(**inputs)
-
-    # in-situ tile refinement (untimed, before the warmup): every GEMM shape's tiling is re-decided by the time of the WHOLE step
-    # (rga3.hip.tuner.refine).  Default for the forward bench; the training modes launch ~60 shapes per step, so there it is opt-in
-    # (--refine, single GPU only: each rank decides from its own timings and the number of trial steps -- hence of gradient
-    # collectives -- would differ between ranks).
-    if (args.mode == "forward" and not args.no_refine) or (args.refine and world == 1 and args.mode != "sam2_stream"):
-        from rga3.hip import tuner
-        rw, rr = (os.environ.get("RGA3_REFINE", "1.5,5").split(",") + ["5"])[:2]
-        ch = tuner.refine(step, reps=int(rr) if args.mode == "forward" else 3, within=float(rw))
-        if rank == 0 and ch:
-            print("tuner.refine changed %d shape(s): %s" % (len(ch), {str(k[:3]): v for k, v in ch.items()}), file=sys.stderr)
-
-    for _ in range(args.warmup):
-        step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -371,77 +587,139 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    full = args.mode in ("headline", "train_full")
+    fwd_roof = fwd_verify = None
+    fwd_ms = None
+    if full:
+        model, cfg, inputs = build_full(dev, rank, args.sam_frames)
+    else:
+        model, cfg = build_model(dev)
+        inputs = make_inputs(cfg, dev, seed=rank, n_video=4096, grid=(16, 32, 32)) if args.mode == "lora_fp8" else make_inputs(cfg, dev, seed=rank)
+
+    # ---- configs[1] forward leg (before LoRA is attached: the plain Qwen2.5-VL-7B forward on the very weights the training step then uses)
+    if args.mode in ("headline", "forward"):
+        from rga3.model.qwen2_5_vl import Qwen2_5_VLForConditionalGeneration
+        fin = make_inputs(cfg, dev, seed=rank)
+        model.eval()
+        fwd_ms, fwd_roof, fwd_verify = measure_forward(lambda **kw: Qwen2_5_VLForConditionalGeneration.forward(model, **kw), fin, args, rank)
+        del fin
+        if args.mode == "forward":
+            barrier()
+            t = torch.tensor([fwd_ms], device=dev, dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+            if rank == 0:
+                cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(train=False)
+                line = {"metric": "video-QA samples/sec at 7B/16-frame (configs[1]: visual-encoder+LLM forward)", "value": round(world * 1e3 / ms, 4),
+                        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                        "config": {"workload": "BASELINE.json configs[1]: Qwen2.5-VL-7B ViT+LLM forward, 16 frames 448x448 (grid [8,32,32]), S=2112, "
+                                               "bf16, 1 sample/GPU, random-init weights", "per_gpu_batch": 1, "seq_len": 2112, "parallelism": f"replicas x{world}",
+                                   "flops_per_sample": TOTAL_FLOPS},
+                        "roofline": fwd_roof, "verify": fwd_verify, "cpu_baseline": cpu}
+                print(json.dumps(line), flush=True)
+            if dist is not None:
+                dist.destroy_process_group()
+            return
+
+    # ---- training step
+    accum = args.grad_accum if args.mode == "lora_fp8" else 1
+    trainables, reducer, opt = make_trainable(model, full, reducer_kw={"sparse": not args.dense_embed_grad})
+    if not full:
+        labels = torch.full_like(inputs["input_ids"], -100)
+        labels[:, -6:] = inputs["input_ids"][:, -6:]
+        inputs["labels"] = labels
+    if args.mode == "lora_fp8" and not args.no_fp8:
+        from rga3.model.qwen_train import set_fp8_frozen_gemms
+        set_fp8_frozen_gemms(True)
+    losses = []
+
+    def step(sync=True):
+        reducer.begin_step()
+        for mi in range(accum):   # gradient accumulation: gradients are exchanged once per optimizer step (DDP no_sync)
+            reducer.begin_micro_step()
+            out = model(**inputs)
+            loss = out["loss"] if isinstance(out, dict) else out.loss
+            if mi + 1 < accum or not sync:
+                with reducer.no_sync():
+                    (loss / accum).backward()
+            else:
+                (loss / accum).backward()
+        if sync:
+            reducer.finish()
+        else:
+            with reducer.no_sync():
+                reducer.finish()
+        opt.step(reducer.grad_view, reducer.flat_grads())
+        losses.append(loss.detach())
+        return loss
+
+    if args.refine and world == 1:
+        from rga3.hip import tuner
+        tuner.refine(step, reps=3, within=1.5)
+    for _ in range(args.warmup):
+        step()
     barrier()
+    del losses[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(out.logits.float()).all(), "non-finite logits"
+    lv = torch.stack([l.float().reshape(()) for l in losses]).cpu()
+    assert torch.isfinite(lv).all(), "non-finite loss"
     ms = elapsed / args.steps * 1e3
     value = world * accum / (elapsed / args.steps)
 
-    # ---- instrumented pass: HIP events around every GEMM launch on the launch stream
-    roof = None
-    if rank == 0 and args.mode == "forward":
-        ev = []
-        alg_bytes = [0]
-        real_gemm = ops.gemm
+    # ---- communication report (N > 1): step time without the exchange, stand-alone bus bandwidth of the buckets
+    comm = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            step(sync=False)
+        barrier()
+        local_ms = (time.perf_counter() - t0) / max(3, args.steps // 2) * 1e3
+        nbytes = sum(f.numel() * f.element_size() for f in reducer.flat)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for f in reducer.flat:
+                dist.all_reduce(f)
+        barrier()
+        ar_s = (time.perf_counter() - t0) / 3
+        tt = torch.tensor([local_ms, ar_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        local_ms, ar_s = float(tt[0]), float(tt[1])
+        comm = {"dense_bucket_bytes_per_step": nbytes, "sparse_rows_bytes_per_step": reducer.sparse_bytes_last, "buckets": len(reducer.flat),
+                "allreduce_standalone_ms": round(ar_s * 1e3, 3), "bus_GB_per_s": round(2 * (world - 1) / world * nbytes / ar_s / 1e9, 1),
+                "step_ms_without_exchange": round(local_ms, 3), "exposed_comm_ms": round(ms - local_ms, 3),
+                "xgmi_peak_GB_per_s_per_gpu": 7 * 153}
 
-        def timed_gemm(*a, **k):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = real_gemm(*a, **k)
-            e.record()
-            ev.append((s, e))
-            alg_bytes[0] += 2 * (a[0].numel() + a[1].numel()) + r.numel() * r.element_size()
-            return r
-
-        import rga3.model.qwen2_5_vl as qm
-        ops.gemm = timed_gemm
-        try:
-            for _ in range(args.steps):
+    # ---- GEMM-family instrumented pass over the same step (rank 0)
+    roof_tr = None
+    if rank == 0 and world == 1:
+        with GemmTimer(ops) as gt:
+            for _ in range(max(2, args.steps // 2)):
                 step()
-            torch.cuda.synchronize()
-        finally:
-            ops.gemm = real_gemm
-        tot_ms = sum(s.elapsed_time(e) for s, e in ev)
-        n_launch = len(ev) // args.steps
-        gemm_ms_step = tot_ms / args.steps
-        achieved = GEMM_FLOPS / (gemm_ms_step * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_* family: gemm_nt_pp_kernel / gemm_nt_sk_kernel / gemm_nt_kernel (bf16 16x16x32 MFMA)", "achieved": round(achieved, 1), "peak": PEAK_BF16 / 1e12,
-                "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
-                "launches_per_step": n_launch, "avg_launch_ms": round(gemm_ms_step / max(n_launch, 1), 5),
-                "gemm_ms_per_step": round(gemm_ms_step, 3),
-                "whole_forward_frac": round(TOTAL_FLOPS / (ms * 1e-3) / PEAK_BF16, 4),
-                "algorithmic_bytes_per_launch": round(alg_bytes[0] / max(len(ev), 1))}
-        # HBM traffic cannot be sampled inside the timed run (PMC needs rocprofv3): it comes from the committed two-pass
-        # FETCH_SIZE / WRITE_SIZE collection of this same command, summarised by tools/pmc_traffic.py.
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_forward_gemm_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            roof["traffic"] = round(tj["traffic_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/r01_bench_forward_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
-
-    if rank == 0 and os.environ.get("RGA3_TUNE_DUMP"):
-        from rga3.hip import tuner
-        rows = []
-        for k, v in tuner.timings().items():
-            Mb, N, K = k[0], k[1], k[2]
-            rows.append({"key": [str(x) for x in k], "best": tuner.table().get(k), "tf": {str(t): round(2.0 * Mb * 256 * N * K / ms / 1e9, 1) for t, ms in v.items()}})
-        json.dump(rows, open(os.environ["RGA3_TUNE_DUMP"], "w"), indent=1)
-
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and args.mode == "forward":
-        cpu = cpu_baseline()
+            tot_ms = gt.total_ms()
+        nst = max(2, args.steps // 2)
+        g_ms = tot_ms / nst
+        roof_tr = {"launches_per_step": len(gt.ev) // nst, "gemm_ms_per_step": round(g_ms, 3), "gemm_flops_per_step": gt.flops / nst,
+                   "achieved": round(gt.flops / nst / (g_ms * 1e-3) / 1e12, 1), "frac": round(gt.flops / nst / (g_ms * 1e-3) / PEAK_BF16, 4),
+                   "note": "all GEMM-family launches of the training step (NT, TN weight-gradient, split-K), FLOPs = sum of 2*M*N*K of the launched shapes"}
+    if rank == 0:
+        assert ops.gemm_stream_k_timeouts() == 0, "stream-K hand-off timed out: results of this run are not trustworthy"
+    n_train = sum(p.numel() for p in trainables)
 
     if rank == 0 and args.mode == "lora_fp8":
-        n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
         fl = accum * (21.6 + 62.6 - 4.6 + 57.9) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + dX at S = 4160; activations are kept, nothing is recomputed
+        peak = PEAK_BF16 if args.no_fp8 else 2 * PEAK_BF16
         line = {"metric": "video-QA samples/sec (fwd+bwd) at 7B/32-frame -- LoRA fine-tune step, grad-accum %d, %s GEMMs for the frozen decoder weights" % (
                     accum, "bf16" if args.no_fp8 else "fp8 e4m3"), "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -452,38 +730,32 @@ def main():
                                        "one bucketed RCCL all-reduce per optimizer step, AdamW" % accum,
                            "per_gpu_batch": 1, "grad_accum": accum, "seq_len": 4160, "parallelism": f"dp{world}", "trainable_params": n_train,
                            "approx_flops_per_step": fl},
-                "roofline": {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": 2 * PEAK_BF16 / 1e12 if not args.no_fp8 else PEAK_BF16 / 1e12,
-                             "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / (2 * PEAK_BF16 if not args.no_fp8 else PEAK_BF16), 4), "traffic": None,
-                             "note": "whole-step algorithmic FLOPs / step time against the dense fp8 (5 PF) or bf16 (2.5 PF) MFMA peak"},
-                "cpu_baseline": None}
+                "roofline": {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / peak, 4),
+                             "traffic": None, "gemm_family": roof_tr, "note": "whole-step algorithmic FLOPs / step time against the dense fp8 (5 PF) or bf16 (2.5 PF) MFMA peak"},
+                "loss_first_last": [round(float(lv[0]), 5), round(float(lv[-1]), 5)], "comm": comm, "cpu_baseline": None}
         print(json.dumps(line), flush=True)
-    elif rank == 0 and args.mode in ("train", "train_full"):
-        n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        fl = (10.8 + 30.8 - 2.3 + 28.5) * 1e12   # ViT fwd + LLM fwd (labelled-row LM head) + dX; activations are kept, nothing is recomputed
-        if args.mode == "train_full":
-            fl += (1.82 * args.sam_frames + 3 * 0.0036 * args.sam_frames) * 1e12   # frozen Hiera-L fwd + mask decoder fwd+bwd
-        line = {"metric": ("video-QA samples/sec (fwd+bwd) at 7B/16-frame — full RGA3 step (Qwen2.5-VL-7B + SAM2-L + mask losses)" if args.mode == "train_full"
+    elif rank == 0:
+        fl = train_flops(args.sam_frames) if full else (10.8 + 30.8 - 2.3 + 28.5) * 1e12
+        rfb = {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / PEAK_BF16, 4),
+               "traffic": None, "flops_per_step": fl, "gemm_family": roof_tr, "note": "whole-step algorithmic FLOPs (SURVEY.md 8(d); activations kept, nothing recomputed) / step time"}
+        tr, src = _traffic("train_full")
+        if tr is not None:
+            rfb["traffic"], rfb["traffic_source"] = tr, src
+        cpu = None
+        if full and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(train=True, sam_frames=args.sam_frames)
+        line = {"metric": ("video-QA samples/sec (fwd+bwd) at 7B/16-frame — full RGA3 training step (Qwen2.5-VL-7B + SAM2-L + mask losses + AdamW)" if full
                            else "video-QA samples/sec (fwd+bwd) at 7B/16-frame — LLM-side LoRA training step (no SAM2 mask path)"), "value": round(value, 4),
                 "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": ("BASELINE.json configs[2] per GPU: " if args.mode == "train_full" else "") +
+                "config": {"workload": ("BASELINE.json configs[2] per GPU: " if full else "") +
                                        "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd (layer activations kept in HBM, no recompute), LoRA r128 (alpha 256, dropout 0.05) q/v + lm_head + embed_tokens "
-                                       "trainable, AdamW step, bucketed RCCL all-reduce; 16 frames 448x448, S=2112, 1 sample/GPU" +
-                                       (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)"
-                                        if args.mode == "train_full" else ""), "per_gpu_batch": 1,
-                           "seq_len": 2112, "parallelism": f"dp{world}", "trainable_params": n_train, "approx_flops_per_sample": fl},
-                "roofline": {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                             "frac": round(fl / (ms * 1e-3) / PEAK_BF16, 4), "traffic": None, "note": "whole-step algorithmic FLOPs / step time"},
-                "cpu_baseline": None}
-        print(json.dumps(line), flush=True)
-    elif rank == 0:
-        line = {"metric": "video-QA samples/sec at 7B/16-frame (configs[1]: visual-encoder+LLM forward)", "value": round(value, 4),
-                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "BASELINE.json configs[1]: Qwen2.5-VL-7B ViT+LLM forward, 16 frames 448x448 (grid [8,32,32]), S=2112, "
-                                       "bf16, 1 sample/GPU, random-init weights", "per_gpu_batch": 1, "seq_len": 2112, "parallelism": f"replicas x{world}",
-                           "flops_per_sample": TOTAL_FLOPS},
-                "roofline": roof, "cpu_baseline": cpu}
+                                       "trainable, AdamW step, bucketed RCCL all-reduce (embed_tokens rows exchanged sparsely); 16 frames 448x448, S=2112, 1 sample/GPU" +
+                                       (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)" if full else ""),
+                           "per_gpu_batch": 1, "seq_len": 2112, "parallelism": f"dp{world}", "trainable_params": n_train, "flops_per_sample": fl},
+                "roofline": fwd_roof if fwd_roof is not None else rfb, "roofline_fwd_bwd": rfb,
+                "verify": dict(fwd_verify or {}, loss_first_last=[round(float(lv[0]), 5), round(float(lv[-1]), 5)]),
+                "comm": comm, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -203,6 +203,18 @@ int rga3_adamw_step(void* param, float* master, const void* grad, float* m, floa
                     float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* *out += sum(g^2) (fp32 atomic): global gradient norm for clipping (train_joint.py:300 gradient_clipping 1.0) */
 int rga3_sumsq_accum(const void* g, float* out, int64_t n, void* stream);
+/* out[0] = (accumulate ? out[0] : 0) + sum(g^2), DETERMINISTIC: per-block partial sums into the caller's `partials` (>= 1 floats, <= 2048 used), then one
+ * block adds them in a fixed order -- data-parallel replicas must derive bit-identical clipping factors (same call site as rga3_sumsq_accum). */
+int rga3_sumsq_det(const void* g, int64_t n, float* partials, int64_t partials_cap, float* out, int accumulate, void* stream);
+/* rga3_adamw_step with 16-byte accesses and the clipping factor min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) derived ON THE DEVICE from the norm
+ * rga3_sumsq_det left there (sumsq == NULL: no clipping): the optimizer step of train_joint.py:300-324, 534-535 without a device -> host sync.
+ * All pointers 16-byte aligned. */
+int rga3_adamw_step_clip(void* param, float* master, const void* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int step, const float* sumsq, float max_norm, void* stream);
+/* dst[idx[i], :] += scale * src[i, :] on bf16 rows, idx UNIQUE within the call: applies one rank's (row ids, rows) contribution to the
+ * embed_tokens gradient (the sparse replacement of the 1.09 GB dense bucket of the reference's ZeRO-2 exchange, train_joint.py:325-334). */
+int rga3_scatter_add_rows(void* dst, const int64_t* idx, const void* src, int64_t n, int64_t dim, int64_t ld_dst, int64_t ld_src, float scale,
+                          void* stream);
 
 /* ---- mask-path backward (trainable sam_mask_decoder + text_hidden_fcs, train_joint.py:237-251) ---------------- */
 

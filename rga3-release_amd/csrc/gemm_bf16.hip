@@ -41,7 +41,6 @@ struct GemmArgs {
     int group_m;  // tile rows per group of the tile order (see launchers)
     void* ws;     // caller workspace for the stream-K / split-K tilings (may be null)
     long ws_bytes;
-    int dbg;  // RGA3_GEMM_DBG (timing ablations only): bit0 = skip the global stores, bit1 = skip the whole epilogue
 };
 
 // 16 bytes of zeros in device memory: source for staging chunks that lie beyond K in the last K-tile
@@ -77,7 +76,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     // so the accumulator registers are never modified after the main loop (a post-loop "acc += slab" makes the register
     // allocator keep two copies of the 128 accumulators and spill).
     constexpr int PD = 1;  // m-tiles of slab reads in flight ahead of use (2 would hide more latency but spills in the persistent kernel)
-    if (p.dbg & 2) return;
     f32x4 pn[PD][NTL];
     auto load_part = [&](int i) {
 #pragma unroll
@@ -178,7 +176,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
         //      quads of n-tile jo+1 to the odd rows, so every lane owns 8 consecutive columns (16 B) of one row:
         //      a wave-store covers 16 rows x 64 contiguous bytes.
         const int row = m0 + wm * WTM + i * 16 + c;
-        const bool row_ok = row < p.M && !(p.dbg & 1);
+        const bool row_ok = row < p.M;
         if constexpr (OUT_F32) {
 #pragma unroll
             for (int jo = 0; jo < OUT_NT; ++jo) {
@@ -1419,8 +1417,6 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.ws = workspace; a.ws_bytes = workspace_bytes;
-    static const int dbg_flags = [] { const char* e = getenv("RGA3_GEMM_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg_flags;
     hipStream_t st = (hipStream_t)stream;
     RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
     int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
@@ -1449,7 +1445,7 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = 0; a.ldw = 0; a.ldc = ldc; a.ldr = 0;
     a.ntm = (int)cdiv(M, 128); a.ntn = (int)cdiv(N, 128); a.group_m = 1;
-    a.ws = nullptr; a.ws_bytes = 0; a.dbg = 0;
+    a.ws = nullptr; a.ws_bytes = 0;
     TnArgs t;
     t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
     const int nk = (int)cdiv(K, 32);

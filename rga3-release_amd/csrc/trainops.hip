@@ -178,6 +178,94 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const unsigned short* __rest
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- deterministic global gradient norm: per-block partial sums (16 B per lane) into a caller buffer, then ONE block adds them in a fixed
+//      tree order.  (sumsq_kernel's float atomics add in arrival order: data-parallel replicas would clip by slightly different factors and drift.)
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const unsigned short* __restrict__ g, float* __restrict__ partials, long n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long n8 = n / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float f[8];
+        un8(*(const u32x4*)(g + i * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e] * f[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {   // ragged tail
+        const float x = bf2f(g[n8 * 8 + threadIdx.x]);
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partials, int np, float* __restrict__ out, int accumulate) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0];
+}
+
+// ---- AdamW, 8 elements per lane (16-byte bf16 / 2 x 16-byte f32 accesses); the clip factor min(1, max_norm / (sqrt(*sumsq) + 1e-6)) is derived
+//      on the device from the norm sumsq_* left there (torch.nn.utils.clip_grad_norm_ / DeepSpeed gradient_clipping semantics, train_joint.py:324)
+__global__ __launch_bounds__(256) void adamw8_kernel(unsigned short* __restrict__ p, float* __restrict__ master, const unsigned short* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                     float wd, float bc1, float bc2, const float* __restrict__ sumsq, float max_norm) {
+    float gscale = 1.f;
+    if (sumsq) gscale = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
+    const long n8 = n / 8;
+    const float decay = 1.f - lr * wd, ibc1 = 1.f / bc1, ibc2 = 1.f / bc2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float gr[8], w[8], mi[8], vi[8];
+        un8(*(const u32x4*)(g + i * 8), gr);
+        *(f32x4*)(w) = *(const f32x4*)(master + i * 8);     *(f32x4*)(w + 4) = *(const f32x4*)(master + i * 8 + 4);
+        *(f32x4*)(mi) = *(const f32x4*)(m + i * 8);         *(f32x4*)(mi + 4) = *(const f32x4*)(m + i * 8 + 4);
+        *(f32x4*)(vi) = *(const f32x4*)(v + i * 8);         *(f32x4*)(vi + 4) = *(const f32x4*)(v + i * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = gr[e] * gscale;
+            mi[e] = b1 * mi[e] + (1.f - b1) * x;
+            vi[e] = b2 * vi[e] + (1.f - b2) * x * x;
+            w[e] = w[e] * decay - lr * (mi[e] * ibc1) / (sqrtf(vi[e] * ibc2) + eps);
+        }
+        *(f32x4*)(master + i * 8) = *(f32x4*)(w);           *(f32x4*)(master + i * 8 + 4) = *(f32x4*)(w + 4);
+        *(f32x4*)(m + i * 8) = *(f32x4*)(mi);               *(f32x4*)(m + i * 8 + 4) = *(f32x4*)(mi + 4);
+        *(f32x4*)(v + i * 8) = *(f32x4*)(vi);               *(f32x4*)(v + i * 8 + 4) = *(f32x4*)(vi + 4);
+        *(u32x4*)(p + i * 8) = pk8_(w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {   // ragged tail, scalar
+        const long i = n8 * 8 + threadIdx.x;
+        const float x = bf2f(g[i]) * gscale;
+        const float mm = b1 * m[i] + (1.f - b1) * x, vv = b2 * v[i] + (1.f - b2) * x * x;
+        const float w = master[i] * decay - lr * (mm * ibc1) / (sqrtf(vv * ibc2) + eps);
+        m[i] = mm; v[i] = vv; master[i] = w; p[i] = f2bf(w);
+    }
+}
+
+// dst[idx[i]] += scale * src[i] on bf16 rows (one rounding per call); idx unique within the call (embedding-row gradient exchange)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(unsigned short* __restrict__ dst, const long* __restrict__ idx, const unsigned short* __restrict__ src,
+                                                               long n, int dim, long ld_dst, long ld_src, float scale) {
+    const int nch = dim / 8;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n * nch; t += (long)gridDim.x * 256) {
+        const long r = t / nch;
+        const int ch = (int)(t % nch);
+        float a[8], b[8];
+        unsigned short* d = dst + idx[r] * ld_dst + ch * 8;
+        un8(*(const u32x4*)d, a);
+        un8(*(const u32x4*)(src + r * ld_src + ch * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += scale * b[e];
+        *(u32x4*)d = pk8_(a);
+    }
+}
+
 static inline unsigned g1(long total, long cap = 256L * 32) {
     long b = cdiv(total, 256);
     if (b < 1) b = 1;
@@ -292,5 +380,39 @@ extern "C" int rga3_sumsq_accum(const void* g, float* out, int64_t n, void* stre
     RGA3_CHECK_ARG(g && out && n > 0, "sumsq_accum: bad args");
     hipLaunchKernelGGL(sumsq_kernel, dim3(g1(n, 2048)), dim3(256), 0, (hipStream_t)stream, (cus)g, out, (long)n);
     RGA3_CHECK_LAUNCH("sumsq_accum");
+    return 0;
+}
+
+extern "C" int rga3_sumsq_det(const void* g, int64_t n, float* partials, int64_t partials_cap, float* out, int accumulate, void* stream) {
+    RGA3_CHECK_ARG(g && partials && out && n > 0 && partials_cap >= 1, "sumsq_det: bad args");
+    RGA3_CHECK_ARG(((uintptr_t)g & 15) == 0, "sumsq_det: gradient pointer must be 16-byte aligned");
+    long nb = cdiv(n, 8 * 256 * 4);
+    if (nb < 1) nb = 1;
+    if (nb > partials_cap) nb = partials_cap;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (cus)g, partials, (long)n);
+    RGA3_CHECK_LAUNCH("sumsq_partials");
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, (int)nb, out, accumulate);
+    RGA3_CHECK_LAUNCH("sumsq_finish");
+    return 0;
+}
+
+extern "C" int rga3_adamw_step_clip(void* param, float* master, const void* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, int step, const float* sumsq, float max_norm, void* stream) {
+    RGA3_CHECK_ARG(param && master && grad && m && v && n > 0 && step >= 1, "adamw_step_clip: bad args");
+    RGA3_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_step_clip: pointers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw8_kernel, dim3(g1(cdiv(n, 8), 256L * 16)), dim3(256), 0, (hipStream_t)stream, (us)param, master, (cus)grad, m, v, (long)n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2, sumsq, max_norm);
+    RGA3_CHECK_LAUNCH("adamw_step_clip");
+    return 0;
+}
+
+extern "C" int rga3_scatter_add_rows(void* dst, const int64_t* idx, const void* src, int64_t n, int64_t dim, int64_t ld_dst, int64_t ld_src, float scale,
+                                     void* stream) {
+    RGA3_CHECK_ARG(dst && idx && src && n > 0 && dim > 0 && dim % 8 == 0 && ld_dst % 8 == 0 && ld_src % 8 == 0, "scatter_add_rows: bad args");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(g1(n * (dim / 8))), dim3(256), 0, (hipStream_t)stream, (us)dst, (const long*)idx, (cus)src, (long)n, (int)dim,
+                       (long)ld_dst, (long)ld_src, scale);
+    RGA3_CHECK_LAUNCH("scatter_add_rows");
     return 0;
 }

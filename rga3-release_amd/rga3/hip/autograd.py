@@ -45,6 +45,19 @@ def linear(a, w, bias=None, residual=None, act="none", out_f32=False):
     return LinearFn.apply(a, w, bias, residual, act, out_f32)
 
 
+class DropoutFn(torch.autograd.Function):
+    """Inverted dropout with the counter-hash mask of (seed, element index): backward re-applies the same mask from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):

@@ -518,6 +518,44 @@ def sumsq_accum_(g, out):
     _lib.check(_lib.load().rga3_sumsq_accum(g.data_ptr(), out.data_ptr(), g.numel(), _stream()), "sumsq_accum")
 
 
+def sumsq_det_(g, partials, out, accumulate: bool):
+    """out[0] = (accumulate ? out[0] : 0) + sum(g^2), bit-reproducible (fixed summation order)."""
+    _need_cuda(g, partials, out)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous() and out.dtype == partials.dtype == torch.float32
+    _lib.check(_lib.load().rga3_sumsq_det(g.data_ptr(), g.numel(), partials.data_ptr(), partials.numel(), out.data_ptr(), int(bool(accumulate)), _stream()), "sumsq_det")
+
+
+def adamw_step_clip_(param, master, grad, m, v, lr, beta1, beta2, eps, weight_decay, step: int, sumsq=None, max_norm: float = 0.0):
+    """AdamW with the clipping factor min(1, max_norm / (sqrt(sumsq) + 1e-6)) taken from device memory (sumsq None: no clipping)."""
+    _need_cuda(param, master, grad, m, v, sumsq)
+    assert param.dtype == grad.dtype == torch.bfloat16 and master.dtype == m.dtype == v.dtype == torch.float32
+    assert param.is_contiguous() and grad.is_contiguous() and master.is_contiguous()
+    _lib.check(_lib.load().rga3_adamw_step_clip(param.data_ptr(), master.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(), float(lr),
+                                                float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _ptr(sumsq), float(max_norm), _stream()),
+               "adamw_step_clip")
+
+
+def scatter_add_rows_(dst, idx, src, scale: float = 1.0):
+    """dst[idx[i]] += scale * src[i] (bf16 rows, idx unique within the call)."""
+    _need_cuda(dst, idx, src)
+    assert dst.dtype == src.dtype == torch.bfloat16 and idx.dtype == torch.int64 and dst.dim() == 2 and src.dim() == 2
+    assert dst.stride(1) == 1 and src.stride(1) == 1 and dst.shape[1] == src.shape[1] and idx.numel() == src.shape[0]
+    if idx.numel():
+        _lib.check(_lib.load().rga3_scatter_add_rows(dst.data_ptr(), idx.data_ptr(), src.data_ptr(), idx.numel(), dst.shape[1], dst.stride(0), src.stride(0),
+                                                     float(scale), _stream()), "scatter_add_rows")
+    return dst
+
+
+def check_gemm_health(device=None):
+    """Raise if a stream-K hand-off ever gave up in this process (a wrong C would have been written silently); synchronises the device.  Called at the
+    end of bench.py's timed regions and by the training tests."""
+    n = gemm_stream_k_timeouts(device)
+    if n:
+        for t in _gemm_ws.values():     # recovery: re-arm every flag word so later launches do not read a stale slab
+            t[:4096].zero_()
+        raise _lib.Rga3Error(f"stream-K GEMM hand-off timed out {n} time(s): results since the last check are not trustworthy (workspace flags re-zeroed)")
+
+
 # ------------------------------------------------------------------------------------------------ mask-path backward kernels
 def layernorm_bwd(x, weight, dy, eps: float, want_param_grads=True):
     _need_cuda(x, weight, dy)

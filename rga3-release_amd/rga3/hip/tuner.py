@@ -22,12 +22,36 @@ _times = {}   # key -> {tile: ms of 3 launches} (diagnostic, see table())
 _enabled = os.environ.get("RGA3_GEMM_TUNE", "1") != "0"
 
 
+_forced = [None]
+
+
+class force:
+    """``with tuner.force(10): ...`` runs every tuned GEMM on one explicit tiling (bench.py re-runs its timed forward on the first-generation
+    single-phase 256x256 kernel, id 10, and compares the outputs)."""
+
+    def __init__(self, tile: int):
+        self.tile = int(tile)
+
+    def __enter__(self):
+        self.old, _forced[0] = _forced[0], self.tile
+        return self
+
+    def __exit__(self, *exc):
+        _forced[0] = self.old
+
+
+def forced():
+    return _forced[0]
+
+
 def key_of(M, N, K, act, out_f32, has_bias, has_res):
     return ((M + 255) // 256, N, K, act, out_f32, has_bias, has_res)
 
 
 def pick(key, run, extra=()):
     """run(tile) launches the GEMM once with that tiling.  Returns the cached / measured best tile id."""
+    if _forced[0] is not None:
+        return _forced[0]
     if not _enabled:
         return -1
     t = _cache.get(key)

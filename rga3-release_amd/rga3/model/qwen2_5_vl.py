@@ -519,6 +519,8 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         self.visual = VisionTransformer(config.vision_config)
         self.model = TextModel(config)
         self.lm_head = Linear(config.hidden_size, config.vocab_size, bias=False)
+        if config.tie_word_embeddings:   # Qwen2.5-VL-3B: the output embedding IS the input embedding (HF tie_weights)
+            self.lm_head.weight = self.model.embed_tokens.weight
         self.rope_deltas = None
         self.gradient_checkpointing = False
 
@@ -559,7 +561,7 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
             return nn.Parameter(n, requires_grad=w.requires_grad)
         self.model.embed_tokens.weight = grow(self.model.embed_tokens.weight)
         self.model.embed_tokens.num_embeddings = new_num_tokens
-        self.lm_head.weight = grow(self.lm_head.weight)
+        self.lm_head.weight = self.model.embed_tokens.weight if self.config.tie_word_embeddings else grow(self.lm_head.weight)
         self.lm_head.out_features = new_num_tokens
         self.config.vocab_size = new_num_tokens
         return self.model.embed_tokens

@@ -327,11 +327,19 @@ class DecoderLayerFn(torch.autograd.Function):
 
 
 class EmbedFn(torch.autograd.Function):
-    """x = embed_tokens[ids]; backward builds the dense table gradient from CSR segment sums over duplicate ids."""
+    """x = embed_tokens[ids]; backward reduces the rows of duplicate ids by CSR segment sums (no atomics).  With a GradBucketReducer that registered
+    the table as a sparse parameter (rga3.parallel.ddp) the gradient leaves as (unique row ids, summed rows) -- the 1.09 GB dense table gradient is never
+    built, and data-parallel ranks exchange <= S rows each; otherwise the dense table gradient is returned to autograd."""
 
     @staticmethod
     def forward(ctx, weight, ids_dev, ids_np, grad_rows_np):
+        from ..parallel.ddp import sparse_sink_for
+
         ctx.ids_np, ctx.grad_rows_np, ctx.shape = ids_np, grad_rows_np, weight.shape
+        ctx.sink = sparse_sink_for(weight)
+        ctx.weight = weight
+        if ctx.sink is not None:
+            ctx.sink.announce_sparse(weight, np.unique(ids_np[grad_rows_np]).astype(np.int64))
         return ops.gather_rows(weight, ids_dev)
 
     @staticmethod
@@ -343,8 +351,12 @@ class EmbedFn(torch.autograd.Function):
         off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         dev = dx.device
         seg = ops.segment_sum_rows(dx.contiguous(), torch.from_numpy(rows[order].astype(np.int64)).to(dev), torch.from_numpy(off).to(dev))
+        uniq_dev = torch.from_numpy(uniq.astype(np.int64)).to(dev)
+        if ctx.sink is not None:
+            ctx.sink.add_sparse(ctx.weight, uniq_dev, seg)
+            return None, None, None, None
         dW = torch.zeros(ctx.shape, dtype=dx.dtype, device=dev)
-        ops.scatter_rows_(dW, torch.from_numpy(uniq.astype(np.int64)).to(dev), seg)
+        ops.scatter_rows_(dW, uniq_dev, seg)
         return dW, None, None, None
 
 

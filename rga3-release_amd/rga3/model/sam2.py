@@ -37,7 +37,21 @@ def _ag():
 
 def _lin(l, x, residual=None, act="none"):
     if _ag():
-        return AG.linear(x, l.weight, l.bias, residual, act)
+        lora = getattr(l, "lora_A", None)
+        if lora is None:
+            return AG.linear(x, l.weight, l.bias, residual, act)
+        # a LoRA-wrapped projection (the reference's target filter has a missing comma, train_joint.py:207-208, so PEFT also wraps the q_proj / v_proj
+        # of SAM2's mask decoder and memory attention): base(x) + scaling * B(A(dropout(x))), gradients to A and B (and to the base weight if the
+        # trainer's substring rule re-enabled it)
+        if act != "none":
+            raise NotImplementedError("LoRA on a projection with a fused activation")
+        base = AG.linear(x, l.weight, l.bias, residual, "none")
+        xin = x
+        if l.training and l.dropout_p > 0.0:
+            from .qwen_train import next_dropout_seed
+            xin = AG.DropoutFn.apply(x.contiguous(), l.dropout_p, next_dropout_seed(0, 2))
+        t = AG.linear(xin, l.lora_A["default"].weight)
+        return AG.linear(t, l.lora_B["default"].weight * l.scaling, None, base)
     return l(x, residual=residual, act=act)
 
 
@@ -1043,8 +1057,8 @@ class VideoSession:
 def load_sam2_checkpoint(model: SAM2VideoPredictor, path: str):
     """reference sam2.py:30-85: accept {'model': sd} / {'state_dict': sd} / sd, rename '.gamma' -> '.g_weight', strict."""
     ck = torch.load(path, map_location="cpu", weights_only=True)
-    sd = ck.get("model", ck.get("state_dict", ck)) if isinstance(ck, dict) else ck
-    sd = {k.replace("gamma", "g_weight"): v for k, v in sd.items()}
+    sd = ck.get("state_dict", ck.get("model", ck)) if isinstance(ck, dict) else ck     # 'state_dict' before 'model', as the reference checks them (:47-52)
+    sd = {k.replace(".gamma", ".g_weight"): v for k, v in sd.items()}                  # the reference's name_map (:70)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     if missing or unexpected:
         raise RuntimeError(f"SAM2 checkpoint mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")

@@ -7,22 +7,48 @@ ZeRO partitioning; only the trainable set (~1.15 B params: embed_tokens, lm_head
 exchanged.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 256 MB) so each collective
 amortises its launch and RCCL can stripe rings across links; under gradient accumulation the exchange happens once per
 optimizer step (no_sync), which ZeRO-2 cannot do.
+
+Collective order is rank-independent BY CONSTRUCTION: bucket i is launched only after buckets 0..i-1, and every bucket is
+launched on every rank in every synchronising step (a bucket some of whose parameters got no gradient on this rank — a
+sample without [SEG] skips SAM2, a step without labelled rows drops the lm_head gradient — waits for finish(), where
+the remaining buckets go out in index order with zeros in the untouched slices).  NCCL and gloo pair collectives by issue
+order, so any data-dependent launch order would silently pair different buckets across ranks.
+
+embed_tokens (545 M of the 1.15 B trainable elements) is exchanged SPARSELY: one sample touches <= S rows of the table, and
+its gradient is the last one backward produces, so a dense 1.09 GB bucket could not overlap anything.  Each
+rank contributes (unique row ids, summed rows) — <= 15 MB — through one all-gather, and every rank applies the N
+contributions in rank order (bitwise-identical result on all ranks).
 """
 from __future__ import annotations
 
 import contextlib
+import math
+import weakref
 from typing import Iterable, List
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
+_ALIGN = 8   # bucket slices start at multiples of 8 elements (16 B for bf16): the optimizer kernels use 16-byte accesses
+
+# id(parameter) -> reducer that takes that parameter's gradient as (row ids, rows) instead of a dense tensor (see rga3.model.qwen_train.EmbedFn)
+_sparse_sinks: "weakref.WeakValueDictionary[int, GradBucketReducer]" = weakref.WeakValueDictionary()
+
+
+def sparse_sink_for(param):
+    return _sparse_sinks.get(id(param))
+
 
 class GradBucketReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, process_group=None):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, process_group=None, sparse_params=(), sparse: bool = True):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.sync = True
+        self.sparse_params: List[torch.nn.Parameter] = [p for p in sparse_params if p.requires_grad] if sparse else []
+        sp_ids = {id(p) for p in self.sparse_params}
+        self.all_params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.params: List[torch.nn.Parameter] = [p for p in self.all_params if id(p) not in sp_ids]
         # buckets in REVERSE parameter order (gradients arrive roughly back to front)
         cap = int(bucket_mb * (1 << 20))
         self.buckets = []
@@ -38,26 +64,37 @@ class GradBucketReducer:
             self.buckets.append(cur)
         self.flat, self.slices, self.pending, self.handles = [], {}, [], []
         for bi, b in enumerate(self.buckets):
-            n = sum(p.numel() for p in b)
-            flat = torch.zeros(n, dtype=b[0].dtype, device=b[0].device)
-            self.flat.append(flat)
             off = 0
             for p in b:
                 self.slices[p] = (bi, off, p.numel())
-                off += p.numel()
+                off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            self.flat.append(torch.zeros(off, dtype=b[0].dtype, device=b[0].device))
             self.pending.append(len(b))
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._avg = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        # ---- sparse parameters: a persistent dense gradient buffer (zero outside the rows touched this step) + the exchange state
+        self._sp = {}
+        for p in self.sparse_params:
+            assert p.dim() == 2
+            self._sp[id(p)] = {"p": p, "dense": torch.zeros_like(p.data), "union": np.zeros(0, dtype=np.int64), "last_ids": None, "counts": None}
+            _sparse_sinks[id(p)] = self
+        self.sparse_bytes_last = 0
+        self.begin_step()
 
+    # ---------------------------------------------------------------------------------------------- views for the optimizer
     def grad_view(self, p):
+        st = self._sp.get(id(p))
+        if st is not None:
+            return st["dense"]
         bi, off, n = self.slices[p]
         return self.flat[bi][off:off + n].view_as(p)
 
     def flat_grads(self):
-        """The flat buckets themselves: together they hold exactly the gradients of ``params`` (every element belongs to one slice),
-        so a reduction over all gradients (the clipping norm) can run once per bucket instead of once per tensor."""
-        return list(self.flat)
+        """Flat tensors that together hold exactly the gradients of ``params`` (padding elements are zero), so a reduction over all gradients
+        (the clipping norm) can run once per bucket instead of once per tensor."""
+        return list(self.flat) + [st["dense"].view(-1) for st in self._sp.values()]
 
+    # ---------------------------------------------------------------------------------------------- dense buckets
     def _on_grad(self, p):
         bi, off, n = self.slices[p]
         if p.grad is not None:   # (a graphed backward hands an undefined gradient to parameters its forward never used: nothing to add)
@@ -68,27 +105,30 @@ class GradBucketReducer:
                 self._written.add(p)
             p.grad = None  # the bucket slice is the gradient from here on (no second copy kept)
         self.pending[bi] -= 1
-        if self.pending[bi] == 0:
-            self._launch(bi)
+        self._launch_ready()
+
+    def _launch_ready(self):
+        """Launch, in index order, every bucket whose gradients are all in: bucket i never goes out before bucket i-1 (rank-independent order)."""
+        while self._next < len(self.buckets) and self.pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
-        self._accum_started[bi] = True
-        if self.sync and self.world > 1 and not self._launched[bi]:
-            self._launched[bi] = True
+        if self.sync and self.world > 1:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self.handles.append((bi, dist.all_reduce(self.flat[bi], op=op, group=self.pg, async_op=True)))
 
     def begin_step(self):
         """Call before the first micro-step of an optimizer step."""
-        self._accum_started = [False] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
         self._written = set()
         self.handles = []
-        self.pending = [len(b) for b in self.buckets]
+        self.begin_micro_step()
+        for st in self._sp.values():
+            self._clear_rows(st)
 
     def begin_micro_step(self):
         self.pending = [len(b) for b in self.buckets]
-        self._launched = [False] * len(self.buckets)
+        self._next = 0
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -100,54 +140,235 @@ class GradBucketReducer:
             self.sync = old
 
     def finish(self):
-        """Wait for the outstanding collectives; afterwards grad_view(p) holds the averaged gradient.  Buckets some of whose parameters got
-        no gradient in this step (parameters the loss does not reach: e.g. the IoU / object-score heads of the mask decoder, which only feed an
-        argmax) never count down to zero during backward: they are exchanged here (their untouched slices hold zeros)."""
+        """Launch what backward left (buckets holding a parameter without a gradient on this rank: their untouched slices are zeroed first), exchange
+        the sparse rows, wait for everything; afterwards grad_view(p) holds the averaged gradient."""
         for p in self.params:    # a parameter without a gradient in this step must not hand last step's slice to the optimizer
             if p not in self._written:
                 bi, off, n = self.slices[p]
                 self.flat[bi][off:off + n].zero_()
-        if self.sync and self.world > 1:
-            for bi in range(len(self.buckets)):
-                if not self._launched[bi]:
-                    self._launch(bi)
+        if self.sync:
+            while self._next < len(self.buckets):
+                self._launch(self._next)
+                self._next += 1
+            for st in self._sp.values():
+                self._exchange_sparse(st)
+        else:   # a local-only step (finish() under no_sync): nothing is exchanged; the rows touched are still remembered for the clean-up
+            for st in self._sp.values():
+                st["last_ids"] = torch.from_numpy(st["union"]).to(st["dense"].device)
         for bi, h in self.handles:
             h.wait()
             if not self._avg and self.world > 1:
                 self.flat[bi].div_(self.world)
         self.handles = []
 
+    # ---------------------------------------------------------------------------------------------- sparse rows
+    def _clear_rows(self, st):
+        """Zero the rows of the dense buffer that the previous optimizer step touched (the buffer is zero everywhere else)."""
+        if st["last_ids"] is not None and st["last_ids"].numel():
+            from ..hip import ops
+            d = st["dense"]
+            if d.is_cuda:
+                ops.scatter_rows_(d, st["last_ids"], torch.zeros((st["last_ids"].numel(), d.shape[1]), dtype=d.dtype, device=d.device))
+            else:
+                d[st["last_ids"]] = 0
+        st["last_ids"] = None
+        st["union"] = np.zeros(0, dtype=np.int64)
+
+    def announce_sparse(self, p, uniq_ids_np):
+        """Forward of a micro-step: the rows this rank will contribute are known on the host.  The size of the running union is exchanged now, on a
+        side stream, so that finish() can size the all-gather without waiting for the GPU."""
+        st = self._sp[id(p)]
+        st["union"] = np.union1d(st["union"], uniq_ids_np)
+        if self.world == 1:
+            return
+        dev = p.device
+        n = torch.tensor([st["union"].size], dtype=torch.int64)
+        if dev.type == "cuda":
+            side = st.setdefault("side", torch.cuda.Stream(device=dev))
+            n = n.pin_memory()
+            host = torch.empty(self.world, dtype=torch.int64).pin_memory()
+            with torch.cuda.stream(side):
+                nd = n.to(dev, non_blocking=True)
+                out = torch.empty(self.world, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(out, nd, group=self.pg)
+                host.copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            st["counts"] = (host, ev, (n, nd, out))
+        else:
+            outs = [torch.empty(1, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(outs, n, group=self.pg)
+            st["counts"] = (torch.cat(outs), None, None)
+
+    def add_sparse(self, p, ids_dev, rows):
+        """Backward of a micro-step: accumulate (unique row ids, summed rows) of this rank into the dense buffer."""
+        st = self._sp[id(p)]
+        _scatter_add(st["dense"], ids_dev, rows, 1.0)
+
+    def _exchange_sparse(self, st):
+        d = st["dense"]
+        dev = d.device
+        ids_np = st["union"]
+        ids = torch.from_numpy(ids_np).to(dev)
+        if self.world == 1:
+            st["last_ids"] = ids
+            self.sparse_bytes_last = 0
+            return
+        host, ev, _keep = st["counts"]
+        if ev is not None:
+            ev.synchronize()
+        cap = (int(host.max()) + 63) // 64 * 64
+        H = d.shape[1]
+        # send buffer: this rank's rows at its union ids, padded with the scratch row id V (ids) / zeros (rows)
+        send_ids = torch.full((cap,), d.shape[0], dtype=torch.int64, device=dev)
+        send_ids[:ids.numel()] = ids
+        send_rows = torch.zeros((cap, H), dtype=d.dtype, device=dev)
+        if ids.numel():
+            send_rows[:ids.numel()] = _gather(d, ids)
+        all_ids = torch.empty((self.world * cap,), dtype=torch.int64, device=dev)
+        all_rows = torch.empty((self.world * cap, H), dtype=d.dtype, device=dev)
+        dist.all_gather_into_tensor(all_ids, send_ids, group=self.pg)
+        dist.all_gather_into_tensor(all_rows, send_rows, group=self.pg)
+        self.sparse_bytes_last = self.world * cap * (8 + H * d.element_size())
+        # local rows out, then the N contributions in rank order (every id list is unique within itself): identical bits on every rank
+        if ids.numel():
+            _zero_rows(d, ids)
+        counts = host.tolist()
+        touched = []
+        for r in range(self.world):
+            n = int(counts[r])
+            if n:
+                rid = all_ids[r * cap:r * cap + n]
+                _scatter_add(d, rid, all_rows[r * cap:r * cap + n], 1.0 / self.world)
+                touched.append(rid)
+        st["last_ids"] = torch.cat(touched) if touched else None
+
     def remove(self):
         for h in self._hooks:
             h.remove()
+        for p in self.sparse_params:
+            if _sparse_sinks.get(id(p)) is self:
+                del _sparse_sinks[id(p)]
+
+
+def _gather(d, ids):
+    if d.is_cuda:
+        from ..hip import ops
+        return ops.gather_rows(d, ids)
+    return d[ids]
+
+
+def _zero_rows(d, ids):
+    if d.is_cuda:
+        from ..hip import ops
+        ops.scatter_rows_(d, ids, torch.zeros((ids.numel(), d.shape[1]), dtype=d.dtype, device=d.device))
+    else:
+        d[ids] = 0
+
+
+def _scatter_add(d, ids, rows, scale):
+    """d[ids[i]] += scale * rows[i]; ids unique within the call."""
+    if ids.numel() == 0:
+        return
+    if d.is_cuda:
+        from ..hip import ops
+        ops.scatter_add_rows_(d, ids, rows, scale)
+    else:   # CPU tests (gloo): same arithmetic order — one rounding to the storage dtype per contribution
+        d[ids] = (d[ids].float() + rows.float() * scale).to(d.dtype)
+
+
+class WarmupCosineLR:
+    """DeepSpeed's WarmupCosineLR as configured by reference train_joint.py:308-317 (total_num_steps = epochs * steps_per_epoch, warmup_min_ratio 0,
+    cos_min_ratio 0.03, warmup_num_steps = 3 % of the total, warmup_type "linear").  DeepSpeed 0.16.3 is not in this image: restated from its
+    published lr_schedules.py (parity unpinned).  The engine steps the scheduler AFTER each optimizer step and the scheduler does not step at
+    construction, so optimizer step 0 runs at the configured lr and step k >= 1 at lr * ratio(last_batch_iteration = k - 1)."""
+
+    def __init__(self, total_num_steps: int, warmup_num_steps: int, warmup_min_ratio: float = 0.0, cos_min_ratio: float = 0.03, warmup_type: str = "linear"):
+        self.total, self.warm = int(total_num_steps), max(2, int(warmup_num_steps))
+        self.warm_min, self.cos_min, self.warmup_type = float(warmup_min_ratio), float(cos_min_ratio), warmup_type
+        if warmup_type not in ("linear", "log"):
+            raise ValueError(f"warmup_type {warmup_type!r}")
+
+    def ratio(self, it: int) -> float:
+        if it < 0:
+            return 0.0
+        if it < self.warm:
+            r = it / self.warm if self.warmup_type == "linear" else math.log(it + 1) / math.log(self.warm)
+            return self.warm_min + r * (1.0 - self.warm_min)
+        real_last, real_total = it - self.warm + 1, self.total - self.warm
+        r = (1.0 + math.cos(math.pi * real_last / real_total)) / 2.0
+        return max(0.0, self.cos_min + (1.0 - self.cos_min) * r)
+
+    def scale_at(self, step: int) -> float:
+        """Factor on the configured lr for optimizer step ``step`` (0-based)."""
+        return 1.0 if step == 0 else self.ratio(step - 1)
 
 
 class FusedAdamW:
     """AdamW over (bf16 param, bf16 grad) pairs with fp32 master weights and moments in one HIP kernel per tensor, global-norm
-    clipping folded into the kernel's gradient scale (train_joint.py:300-324: lr 4e-5, betas (0.9, 0.95), wd 0, clip 1.0)."""
+    clipping folded into the kernel's gradient scale (train_joint.py:300-324: lr 4e-5, betas (0.9, 0.95), wd 0, clip 1.0).  The clipping norm
+    never visits the host: a deterministic two-stage sum of squares leaves it in device memory and the update kernel derives its scale from it."""
 
-    def __init__(self, params, lr=4e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0):
+    def __init__(self, params, lr=4e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, schedule: WarmupCosineLR = None):
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.schedule = schedule
         self.master = [p.detach().float().clone() for p in self.params]
         self.m = [torch.zeros_like(x) for x in self.master]
         self.v = [torch.zeros_like(x) for x in self.master]
         self.t = 0
+        dev = self.params[0].device
+        self._acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._partials = torch.zeros(2048, dtype=torch.float32, device=dev)
+
+    def current_lr(self) -> float:
+        return self.lr * self.schedule.scale_at(self.t) if self.schedule is not None else self.lr
+
+    def resync_master(self):
+        """Re-read the fp32 master weights from the (bf16) parameters — call after loading a checkpoint into the model once the optimizer exists."""
+        with torch.no_grad():
+            for w, p in zip(self.master, self.params):
+                w.copy_(p.detach().float())
+
+    def state_dict(self):
+        """Optimizer state for resume (reference: DeepSpeed save_checkpoint / load_checkpoint with optimizer + scheduler state, train_joint.py:352-366, 426-461)."""
+        return {"t": self.t, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "max_grad_norm": self.max_norm,
+                "schedule": None if self.schedule is None else dict(total=self.schedule.total, warm=self.schedule.warm, warm_min=self.schedule.warm_min,
+                                                                    cos_min=self.schedule.cos_min, warmup_type=self.schedule.warmup_type),
+                "master": [w.detach().cpu() for w in self.master], "m": [x.detach().cpu() for x in self.m], "v": [x.detach().cpu() for x in self.v]}
+
+    def load_state_dict(self, sd, write_params: bool = True):
+        if len(sd["master"]) != len(self.params) or any(a.shape != b.shape for a, b in zip(sd["master"], self.master)):
+            raise ValueError("optimizer state does not match the parameter list (count or shapes differ)")
+        self.t, self.lr, self.betas, self.eps, self.wd, self.max_norm = int(sd["t"]), sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"], sd["max_grad_norm"]
+        sc = sd.get("schedule")
+        self.schedule = None if sc is None else WarmupCosineLR(sc["total"], sc["warm"], sc["warm_min"], sc["cos_min"], sc["warmup_type"])
+        with torch.no_grad():
+            for dst, src in ((self.master, sd["master"]), (self.m, sd["m"]), (self.v, sd["v"])):
+                for a, b in zip(dst, src):
+                    a.copy_(b)
+            if write_params:   # the bf16 parameters are the rounded masters
+                for p, w in zip(self.params, self.master):
+                    p.data.copy_(w.to(p.dtype))
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global gradient norm of the last step() (device scalar, no sync)."""
+        return self._acc.sqrt()
 
     def step(self, grad_of, flat_grads=None):
         """grad_of(p) -> gradient tensor (e.g. GradBucketReducer.grad_view).  flat_grads: optional list of flat tensors that together
         hold exactly these gradients (GradBucketReducer.flat_grads()): the clipping norm then takes one launch per bucket."""
         from ..hip import ops
 
+        lr = self.current_lr()
         self.t += 1
         grads = [grad_of(p).contiguous() for p in self.params]
-        scale = 1.0
-        if self.max_norm is not None:
-            acc = torch.zeros(1, dtype=torch.float32, device=self.params[0].device)
+        clip = self.max_norm is not None
+        if clip:
+            first = True
             for g in (flat_grads if flat_grads is not None else grads):
-                ops.sumsq_accum_(g.reshape(-1), acc)
-            norm = float(acc.sqrt())
-            scale = min(1.0, self.max_norm / (norm + 1e-6))
+                ops.sumsq_det_(g.reshape(-1), self._partials, self._acc, accumulate=not first)
+                first = False
         for p, w, g, m, v in zip(self.params, self.master, grads, self.m, self.v):
-            ops.adamw_step_(p.data, w, g, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, scale)
-        return scale
+            ops.adamw_step_clip_(p.data, w, g, m, v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                                 self._acc if clip else None, self.max_norm if clip else 0.0)

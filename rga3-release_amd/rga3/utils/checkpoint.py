@@ -78,7 +78,8 @@ def load_checkpoint(model: torch.nn.Module, path: str, strict: bool = True, dtyp
             del shard
     late = ("grounding_encoder.", "text_hidden_fcs.", ".lora_A.", ".lora_B.")
     missing = [k for k in own if k not in seen]
-    hard_missing = [k for k in missing if not any(t in k for t in late)]
+    tied = bool(getattr(getattr(model, "config", None), "tie_word_embeddings", False))   # HF omits the tied lm_head from the checkpoint (Qwen2.5-VL-3B)
+    hard_missing = [k for k in missing if not any(t in k for t in late) and not (tied and k == "lm_head.weight" and "model.embed_tokens.weight" in seen)]
     if strict and (hard_missing or unexpected):
         raise RuntimeError(f"checkpoint mismatch: missing {hard_missing[:5]} (+{max(len(hard_missing) - 5, 0)}), unexpected {unexpected[:5]} (+{max(len(unexpected) - 5, 0)})")
     return missing, unexpected
@@ -92,6 +93,8 @@ def save_checkpoint(model_or_state, path: str, max_shard_bytes: int = 5 * 2**30,
     os.makedirs(path, exist_ok=True)
     shards, cur, size = [], {}, 0
     for k, v in sd.items():
+        if k == "lm_head.weight" and "model.embed_tokens.weight" in sd and v.data_ptr() == sd["model.embed_tokens.weight"].data_ptr():
+            continue   # tied output embedding: one tensor, stored once under embed_tokens (HF layout; safetensors refuses shared storage)
         nb = v.numel() * v.element_size()
         if cur and size + nb > max_shard_bytes:
             shards.append(cur)

@@ -97,3 +97,65 @@ def test_lora_merge_formula_and_names():
     for k in before:
         if not any(k == h + ".weight" for h in hits):
             assert torch.equal(before[k], after[k]), k
+
+
+def test_tied_word_embeddings_round_trip(tmp_path):
+    """Qwen2.5-VL-3B ties lm_head to embed_tokens and HF omits the tied tensor from the checkpoint: strict load must accept that, the
+    module must alias the two, and save must store the tensor once."""
+    from safetensors import safe_open
+
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
+
+    cfg = dict(TINY, tie_word_embeddings=True)
+    torch.manual_seed(4)
+    m = UniGRModel(UniGRConfig(**cfg))
+    assert m.lm_head.weight is m.model.embed_tokens.weight
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_(0, 0.1)
+    m.save_pretrained(str(tmp_path))
+    with safe_open(str(tmp_path / "model.safetensors"), "pt") as f:
+        keys = set(f.keys())
+    assert "model.embed_tokens.weight" in keys and "lm_head.weight" not in keys
+    m2 = UniGRModel.from_pretrained(str(tmp_path), config=UniGRConfig.from_pretrained(str(tmp_path), train_mask_decoder=True))
+    assert m2.lm_head.weight is m2.model.embed_tokens.weight
+    assert torch.equal(m2.lm_head.weight, m.model.embed_tokens.weight)
+    m2.resize_token_embeddings(40)
+    assert m2.lm_head.weight is m2.model.embed_tokens.weight and m2.lm_head.weight.shape[0] == 40
+
+
+def test_load_sam2_checkpoint_pt(tmp_path):
+    """The SAM2 .pt loader of reference model/sam2.py:30-85: {'model': sd} / {'state_dict': sd} / bare sd, '.gamma' -> '.g_weight' (and only with the
+    leading dot), strict on missing and unexpected keys."""
+    from rga3.model.sam2 import SAM2, load_sam2_checkpoint
+
+    tiny = dict(image_size=128, embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4), memattn_layers=2)
+    torch.manual_seed(5)
+    src = SAM2(**tiny).sam2_model
+    with torch.no_grad():
+        for p in src.parameters():
+            p.normal_(0, 0.1)
+    sd = src.state_dict()
+    gkeys = [k for k in sd if k.endswith(".g_weight")]
+    assert gkeys, "the memory encoder's layer-scale parameters are stored as .g_weight"
+    upstream = {k.replace(".g_weight", ".gamma"): v.clone() for k, v in sd.items()}   # what sam2_hiera_*.pt holds
+    for wrap in ("model", "state_dict", None):
+        path = str(tmp_path / f"sam2_{wrap}.pt")
+        torch.save({wrap: upstream} if wrap else upstream, path)
+        dst = SAM2(**tiny).sam2_model
+        load_sam2_checkpoint(dst, path)
+        for k, v in sd.items():
+            assert torch.equal(dst.state_dict()[k], v), k
+    # through the wrapper's constructor argument, as initialize_sam_modules passes config.sam_pretrained (reference qwen_2_5_vl_sam2.py:119)
+    m = SAM2(ckpt_path=str(tmp_path / "sam2_model.pt"), **tiny)
+    assert torch.equal(m.sam2_model.state_dict()[gkeys[0]], sd[gkeys[0]])
+    # strictness
+    bad = dict(upstream)
+    bad.pop(next(iter(bad)))
+    torch.save({"model": bad}, str(tmp_path / "missing.pt"))
+    with pytest.raises(RuntimeError):
+        load_sam2_checkpoint(SAM2(**tiny).sam2_model, str(tmp_path / "missing.pt"))
+    extra = dict(upstream, **{"not.a.key": torch.zeros(1)})
+    torch.save({"model": extra}, str(tmp_path / "extra.pt"))
+    with pytest.raises(RuntimeError):
+        load_sam2_checkpoint(SAM2(**tiny).sam2_model, str(tmp_path / "extra.pt"))

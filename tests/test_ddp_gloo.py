@@ -80,3 +80,102 @@ def test_bucketed_allreduce_two_ranks():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]  # identical on both ranks
+
+
+def _worker_divergent(rank, world, port, q):
+    """the set of parameters that receive a gradient differs between ranks (a sample without [SEG] skips SAM2 on one rank only).
+    Three equal-size buckets; rank 1 never reaches parameter b.  Launch order must stay bucket 0, 1, 2 on both ranks."""
+    sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rga3.parallel.ddp import GradBucketReducer
+
+    torch.manual_seed(0)
+    a, b, c = (torch.nn.Parameter(torch.randn(64)) for _ in range(3))
+    red = GradBucketReducer([a, b, c], bucket_mb=64 * 4 / (1 << 20))   # one parameter per bucket, all the same size
+    assert len(red.buckets) == 3
+    x = torch.randn(64, generator=torch.Generator().manual_seed(5 + rank))
+    oks = []
+    for step in range(2):
+        red.begin_step()
+        red.begin_micro_step()
+        loss = (a * x).sum() * 1.0 + (c * x * 3.0).sum()
+        if rank == 0:
+            loss = loss + (b * x * 2.0).sum()
+        loss.backward()
+        red.finish()
+        xs = [torch.randn(64, generator=torch.Generator().manual_seed(5 + r)) for r in range(world)]
+        ref_a = sum(xs) / world
+        ref_b = 2.0 * xs[0] / world              # only rank 0 contributes
+        ref_c = 3.0 * sum(xs) / world
+        oks.append(torch.allclose(red.grad_view(a), ref_a, atol=1e-6) and torch.allclose(red.grad_view(b), ref_b, atol=1e-6)
+                   and torch.allclose(red.grad_view(c), ref_c, atol=1e-6))
+    q.put((rank, all(oks), [red.grad_view(p).sum().item() for p in (a, b, c)]))
+    red.remove()
+    dist.destroy_process_group()
+
+
+def _worker_sparse(rank, world, port, q):
+    """Sparse row exchange of an embedding-table gradient (announce in forward, add in backward, all-gather in finish) against the dense average;
+    overlapping and disjoint ids, gradient accumulation over two micro-steps, two optimizer steps (rows of step 1 must be gone in step 2)."""
+    sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from rga3.parallel.ddp import GradBucketReducer, sparse_sink_for
+
+    V, H = 50, 16
+    table = torch.nn.Parameter(torch.zeros(V, H))
+    w = torch.nn.Parameter(torch.ones(4))
+    red = GradBucketReducer([table, w], bucket_mb=1.0, sparse_params=[table])
+    assert sparse_sink_for(table) is red and len(red.buckets) == 1
+    ok = True
+    for step in range(2):
+        red.begin_step()
+        dense_ref = torch.zeros(world, V, H)
+        for mi in range(2):
+            for r in range(world):   # every rank can rebuild everyone's contribution
+                g = torch.Generator().manual_seed(100 * step + 10 * r + mi)
+                ids = np.unique(torch.randint(0, V if r == 0 else V // 2, (5 + 3 * r,), generator=g).numpy()).astype(np.int64)
+                rows = torch.randn(len(ids), H, generator=g)
+                dense_ref[r][torch.from_numpy(ids)] += rows
+                if r == rank:
+                    mine = (ids, rows)
+            ctx = red.no_sync() if mi == 0 else __import__("contextlib").nullcontext()
+            with ctx:
+                red.begin_micro_step()
+                red.announce_sparse(table, mine[0])
+                (w * (rank + 1.0)).sum().backward()
+                red.add_sparse(table, torch.from_numpy(mine[0]), mine[1])
+        red.finish()
+        ref = dense_ref.mean(0)
+        ok = ok and torch.allclose(red.grad_view(table), ref, atol=1e-6)
+        ok = ok and torch.allclose(red.grad_view(w), torch.full((4,), 2.0 * (1 + world) / 2), atol=1e-6)   # two micro-steps, mean over ranks of (rank + 1)
+    q.put((rank, bool(ok), [red.grad_view(table).sum().item(), red.sparse_bytes_last]))
+    red.remove()
+    dist.destroy_process_group()
+
+
+def _run(worker):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() * 7 + hash(worker.__name__)) % 2000)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_rank_divergent_unused_parameter_keeps_bucket_order():
+    res = _run(_worker_divergent)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]
+
+
+def test_sparse_row_exchange_two_ranks():
+    res = _run(_worker_sparse)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]   # bitwise-identical sums on both ranks
