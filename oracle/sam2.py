@@ -329,7 +329,7 @@ def conv_transpose_2x2(x, w, b):
     return F.conv_transpose2d(x, w, b, stride=2)
 
 
-def mask_decoder(P, image_embeddings, image_pe, sparse, dense, high_res_features, cfg: Sam2Cfg, multimask_output=True):
+def mask_decoder(P, image_embeddings, image_pe, sparse, dense, high_res_features, cfg: Sam2Cfg, multimask_output=True, internals=None):
     """S:2021-2160 MaskDecoder.forward/predict_masks (pred_obj_scores, high-res feats, multimask token for obj ptr)."""
     pre = "sam_mask_decoder."
     out_tokens = torch.cat([P[pre + "obj_score_token.weight"], P[pre + "iou_token.weight"], P[pre + "mask_tokens.weight"]], dim=0)
@@ -346,6 +346,8 @@ def mask_decoder(P, image_embeddings, image_pe, sparse, dense, high_res_features
     up = F.gelu(layer_norm_2d(up, P, pre + "output_upscaling.1"))
     up = F.gelu(conv_transpose_2x2(up, P[pre + "output_upscaling.3.weight"], P[pre + "output_upscaling.3.bias"]) + feat_s0)
     hyper = torch.stack([mlp(mask_toks[:, i], P, f"{pre}output_hypernetworks_mlps.{i}", 3) for i in range(4)], dim=1)
+    if internals is not None:   # fixture construction only (tests/golden/blobfit.py): the two factors of the mask product
+        internals.update(mask_toks=mask_toks, upscaled=up)
     bb, cc, hh, ww = up.shape
     masks = (hyper @ up.view(bb, cc, hh * ww)).view(bb, -1, hh, ww)
     iou = mlp(iou_tok, P, pre + "iou_prediction_head", 3, sigmoid_output=True)
@@ -365,13 +367,13 @@ def prompt_encoder_no_points(P, B, cfg: Sam2Cfg):
     return sparse, dense, dense_pe
 
 
-def forward_sam_heads(P, backbone_features, high_res_features, language_embd, cfg: Sam2Cfg, multimask_output=True):
+def forward_sam_heads(P, backbone_features, high_res_features, language_embd, cfg: Sam2Cfg, multimask_output=True, internals=None):
     """S:3262-3431 (language path: no points, no mask prompt)."""
     B = backbone_features.shape[0]
     sparse, dense, dense_pe = prompt_encoder_no_points(P, B, cfg)
     if language_embd is not None:
         sparse = torch.cat([sparse, language_embd], dim=1)
-    low_multi, ious, toks, obj_logits = mask_decoder(P, backbone_features, dense_pe, sparse, dense, high_res_features, cfg, multimask_output)
+    low_multi, ious, toks, obj_logits = mask_decoder(P, backbone_features, dense_pe, sparse, dense, high_res_features, cfg, multimask_output, internals)
     is_obj = obj_logits > 0
     low_multi = low_multi.float()
     high_multi = F.interpolate(low_multi, size=(cfg.image_size, cfg.image_size), mode="bilinear", align_corners=False)

@@ -194,3 +194,48 @@ def test_frame_graphs_dropped_when_weights_change(model, dev):
             w.copy_(keep)
             for p in model.sam2_model.sam_mask_decoder.output_hypernetworks_mlps.parameters():
                 p.mul_(2.0)
+
+
+def test_lora_on_sam2_projections_train_equals_eval_and_gets_gradients(dev, G):
+    """the reference's LoRA target filter (train_joint.py:199-212, missing comma) also wraps q_proj / v_proj of SAM2's mask decoder.
+    With non-zero lora_B the autograd (training) forward must equal the fused no_grad forward, and lora_A / lora_B must receive gradients."""
+    from rga3.model.qwen_train import LoRALinear, add_lora
+    from rga3.model.sam2 import SAM2
+
+    m = SAM2(**TINY)
+    m.sam2_model.load_state_dict(det_params(G), strict=True)
+    m = m.to(torch.bfloat16).to(dev)
+    hits = add_lora(m, r=8, alpha=16, dropout=0.0)      # default exclude = the reference's (buggy) list
+    dec_hits = [h for h in hits if "sam_mask_decoder" in h]
+    assert dec_hits and all(h.endswith(("q_proj", "v_proj")) for h in hits)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0, 0.05)
+    m.eval()
+    img, emb = images(2).to(torch.bfloat16).to(dev), lang(2).to(torch.bfloat16).to(dev)
+    with torch.no_grad():
+        st = m.get_sam2_embeddings_train(img)
+        low_e, high_e = m.inject_language_embd_train(st, emb)
+        # the LoRA update must matter for this check to mean anything
+        for n, p in m.named_parameters():
+            if "lora_B" in n:
+                p.mul_(0.0)
+        low_0, _ = m.inject_language_embd_train(st, emb)
+        torch.manual_seed(0)
+        for n, p in m.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0, 0.05)
+        low_e, high_e = m.inject_language_embd_train(st, emb)
+    assert rel(low_e, low_0) > 1e-3
+    for n, p in m.named_parameters():
+        p.requires_grad_("lora_" in n or "sam_mask_decoder" in n)
+    with torch.enable_grad():
+        low_t, high_t = m.inject_language_embd_train(st, emb)
+        high_t.float().square().mean().backward()
+    assert rel(low_t.detach(), low_e) < 1e-2
+    got = {n: p.grad for n, p in m.named_parameters() if "lora_" in n and "sam_mask_decoder" in n}
+    assert got and all(g is not None and torch.isfinite(g.float()).all() for g in got.values())
+    assert any(float(g.float().abs().max()) > 0 for n, g in got.items() if "lora_A" in n)
+    assert any(float(g.float().abs().max()) > 0 for n, g in got.items() if "lora_B" in n)
+    assert isinstance(m.sam2_model.sam_mask_decoder.transformer.layers[0].self_attn.q_proj, LoRALinear)

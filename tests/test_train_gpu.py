@@ -284,10 +284,11 @@ def test_fused_adamw_with_bucket_norm_matches_torch(dev):
             p.grad = g.clone()
             red._on_grad(p)
         red.finish()
-        scale = opt.step(red.grad_view, red.flat_grads() if use_flat else None)
-        outs.append(([p.detach().float().clone() for p in ps], scale))
+        opt.step(red.grad_view, red.flat_grads() if use_flat else None)
+        norm = float(opt.grad_norm())      # the clipping norm stays on the device during step(); reading it here is the test's own sync
+        outs.append(([p.detach().float().clone() for p in ps], min(1.0, 1.0 / (norm + 1e-6))))
         red.remove()
-    assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * outs[0][1]
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[0][1]
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.equal(a, b)
     ref = [torch.nn.Parameter(p.detach().float().clone()) for p in make()]
@@ -323,3 +324,71 @@ def test_stored_activations_equal_recompute(dev):
     assert abs(res[False][0] - res[True][0]) <= 2e-3 * abs(res[True][0])
     for n in res[True][1]:
         assert rel_l2(res[False][1][n], res[True][1][n]) < 2e-2, n
+
+
+def test_deterministic_sumsq_and_scatter_add_rows(dev):
+    """rga3_sumsq_det: same bits on every call (fixed summation order; the clip factor must be identical on all data-parallel ranks), value equal to
+    the fp64 sum; ragged length.  rga3_scatter_add_rows: dst[idx] += scale * src with one bf16 rounding, other rows untouched."""
+    from rga3.hip import ops
+
+    torch.manual_seed(0)
+    for n in (8 * 1000 + 3, 5_000_000):
+        g = (torch.randn(n, device=dev) * 0.7).to(torch.bfloat16)
+        part = torch.zeros(2048, dtype=torch.float32, device=dev)
+        outs = []
+        for _ in range(3):
+            acc = torch.full((1,), 123.0, dtype=torch.float32, device=dev)
+            ops.sumsq_det_(g, part, acc, accumulate=False)
+            outs.append(acc.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        ref = float((g.double() ** 2).sum())
+        assert abs(float(outs[0]) - ref) <= 1e-5 * ref
+        ops.sumsq_det_(g, part, acc, accumulate=True)
+        assert abs(float(acc) - 2 * ref) <= 1e-5 * 2 * ref
+    V, H = 300, 64
+    dst = (torch.randn(V, H, device=dev)).to(torch.bfloat16)
+    idx = torch.randperm(V, device=dev)[:37]
+    src = torch.randn(37, H, device=dev).to(torch.bfloat16)
+    want = dst.clone()
+    want[idx] = (dst[idx].float() + 0.25 * src.float()).to(torch.bfloat16)
+    ops.scatter_add_rows_(dst, idx, src, 0.25)
+    assert torch.equal(dst, want)
+
+
+def test_embedding_gradient_through_sparse_sink_equals_dense(dev):
+    """EmbedFn hands (unique ids, summed rows) to a GradBucketReducer that registered the table as a sparse parameter; the buffer the optimizer reads
+    must equal the dense table gradient of the un-registered path, over two micro-steps with repeated ids, and the rows of one optimizer step must be
+    gone in the next."""
+    from rga3.model.qwen_train import EmbedFn
+    from rga3.parallel.ddp import GradBucketReducer
+
+    torch.manual_seed(1)
+    V, H = 500, 128
+    w = torch.nn.Parameter((torch.randn(V, H, device=dev) * 0.1).to(torch.bfloat16))
+    batches = []
+    for mi in range(2):
+        ids = torch.randint(0, 40, (64,))
+        ids[10:30] = 499          # "vision placeholder" positions, excluded from the table gradient
+        rows = np.flatnonzero(ids.numpy() != 499)
+        dy = (torch.randn(64, H, device=dev)).to(torch.bfloat16)
+        batches.append((ids, rows, dy))
+
+    def run(sink_on):
+        red = GradBucketReducer([w], bucket_mb=1.0, sparse_params=[w], sparse=sink_on)
+        res = []
+        for step in range(2):
+            red.begin_step()
+            for mi, (ids, rows, dy) in enumerate(batches[: 2 - step]):    # second optimizer step: one micro-step only
+                red.begin_micro_step()
+                x = EmbedFn.apply(w, ids.to(dev), ids.numpy(), rows)
+                x.backward(dy)
+            red.finish()
+            res.append(red.grad_view(w).float().clone())
+        red.remove()
+        return res
+
+    dense, sparse = run(False), run(True)
+    for a, b in zip(dense, sparse):
+        assert torch.allclose(a, b, atol=2e-2, rtol=2e-2)     # accumulation across micro-steps rounds at different points (bf16 add vs bf16 add of sums)
+        assert torch.equal(a != 0, b != 0)
+    assert float(sparse[1].abs().sum()) < float(sparse[0].abs().sum())
