@@ -36,9 +36,11 @@ def shifted_seg_mask(ids, seg_idx):
     return torch.cat([m[:, 1:], torch.zeros_like(m)[:, 0].unsqueeze(1)], dim=1)
 
 
-def model_forward(P, PS, qcfg, scfg, batch, weights, seg_token_idx, out_dim=256):
-    """Training branch (inference=False).  P: Qwen+head params, PS: SAM2 params (names without the
-    'grounding_encoder.sam2_model.' prefix).  weights = (ce, dice, bce)."""
+def model_forward(P, PS, qcfg, scfg, batch, weights, seg_token_idx, out_dim=256, inference=False):
+    """reference :149-321.  P: Qwen+head params, PS: SAM2 params (names without the 'grounding_encoder.sam2_model.' prefix).
+    weights = (ce, dice, bce).  inference=True is the branch validate() drives (reference :236-257, train_joint.py:586-648): batch size 1
+    (the reference squeezes dim 0 of images_sam), SAM2 video inference with the language prompt on every frame, bilinear to the label size,
+    sigmoid > 0.5; a sample without [SEG] is prompted with the zero embedding."""
     images_sam = batch["images_sam"].float()
     B, T = images_sam.shape[:2]
     r = Q.forward(P, qcfg, batch["input_ids"], batch.get("attention_mask"), position_ids=batch.get("position_ids"), labels=batch["labels"],
@@ -54,6 +56,16 @@ def model_forward(P, PS, qcfg, scfg, batch, weights, seg_token_idx, out_dim=256)
         a, b = int(off[i]), int(off[i + 1])
         embs += [torch.zeros(1, out_dim) if a == b else pred[a:b]] * T
     lang = torch.cat(embs, dim=0).unsqueeze(1)
+    if inference:
+        assert B == 1, "reference :243 squeezes the batch dimension"
+        le = lang.reshape(B, T, 1, out_dim)
+        pred_masks, logits = [], []
+        for i in range(B):
+            masks, _ = S.language_embd_inference(PS, images_sam[0], [le[i][t] for t in range(T)], scfg)
+            m = F.interpolate(masks, size=tuple(batch["label_list"][i].shape), mode="bilinear", align_corners=False)[:, 0]
+            pred_masks.append(m.sigmoid() > 0.5)
+            logits.append(m)
+        return {"pred_masks": pred_masks, "gt_masks": batch["masks_list"], "mask_logits": logits, "seg_token_offset": off}
     feats = S.prepare_backbone_features(S.image_encoder_forward(PS, images_sam.flatten(0, 1), scfg))
     _, high, _ = S.inject_language_embd_train(PS, feats, lang, scfg)
     high = high.reshape(B, T, scfg.image_size, scfg.image_size)

@@ -17,6 +17,7 @@ import torch
 warnings.filterwarnings("ignore")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 sys.modules["qwen_vl_utils"] = types.SimpleNamespace(process_vision_info=lambda *a, **k: None)
@@ -32,6 +33,7 @@ for _m in ("torchvision", "torchvision.transforms", "torchvision.transforms.func
             sys.modules[_m] = types.SimpleNamespace(resize=None, to_pil_image=None, transforms=None, functional=None, pyplot=None)
 
 from oracle.detweights import det_state_dict, det_tensor  # noqa: E402
+from tests.blob_inputs import object_video  # noqa: E402
 
 import model.sam2 as RS  # noqa: E402  (the reference)
 
@@ -41,7 +43,8 @@ TINY = dict(image_size=128, embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), glob
             pos_bkg=(7, 7), d_model=256, mem_dim=64, memattn_layers=2, memattn_ff=64)
 
 
-def build_tiny_predictor(image_size=None):
+def build_tiny_predictor(image_size=None, overrides=None):
+    """overrides: {name: tensor} poured over the name-derived weights (the fitted mask-head read-out, tests/golden/blobfit.py)."""
     t = dict(TINY)
     if image_size is not None:
         t["image_size"] = image_size
@@ -74,6 +77,7 @@ def build_tiny_predictor(image_size=None):
     pred = pred.float().eval()
     shapes = {k: tuple(v.shape) for k, v in pred.state_dict().items()}
     sd = det_state_dict(shapes, seed=2)
+    sd.update(overrides or {})
     pred.load_state_dict(sd, strict=True)
     # the SAM2 wrapper hard-codes SAM2-L sizes in its constructor (sam2.py:87-146); wrap the tiny predictor in it without running it
     wrap = RS.SAM2.__new__(RS.SAM2)
@@ -133,13 +137,20 @@ def main():
     # definition (sum(seg & gt) / sum(seg | gt), empty union -> 1) is restated in the product's metrics and pinned by hand cases.
 
     # ------------------------------------------------------------------ G2/G3: tiny SAM2 built from the reference classes
-    wrap, shapes = build_tiny_predictor()
+    T = 5
+    imgs, obj = object_video("sam_images", T, 128, seed=3)     # an ellipse drifting over a smooth background (tests/blob_inputs.py)
+    emb = det_tensor("lang_embd", (T, 1, 256), 1.0, seed=4)
+    # fit the mask head's read-out to that object on frames 0-2 (frames 3-4 and the memory path are then genuinely predicted)
+    import blobfit as BF
+    from tests.sam2_tiny import tiny_cfg
+    _, shapes = build_tiny_predictor()
+    fitted = BF.fit(det_state_dict(shapes, seed=2), tiny_cfg(), imgs[:3], emb[:3], obj[:3])
+    for k, v in fitted.items():
+        out["fit::" + k] = v.numpy()
+    wrap, shapes = build_tiny_predictor(overrides=fitted)
     pred = wrap.sam2_model
     out["param_names"] = np.array(sorted(shapes))
     out["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
-    T = 5
-    imgs = det_tensor("sam_images", (T, 3, 128, 128), 1.0, seed=3)
-    emb = det_tensor("lang_embd", (T, 1, 256), 1.0, seed=4)
 
     with torch.no_grad():
         # G2: image encoder levels
@@ -192,6 +203,11 @@ def main():
         for h in hs:
             h.remove()
 
+    # margins of what was just pinned (printed for the record: a threshold test needs |logit| well away from 0 on most pixels)
+    for key in ("g3_train_high", "g3_infer_all_masks", "g3_prop0_masks"):
+        m = torch.from_numpy(out[key]).reshape(-1, 128, 128)
+        print(key, "margin(|x| > 5% max) per frame:", [round(float((x.abs() > 0.05 * x.abs().max()).float().mean()), 3) for x in m],
+              "IoU with the object:", [round(float(((x > 0) & o).sum() / ((x > 0) | o).sum().clamp(min=1)), 3) for x, o in zip(m, obj)])
     np.savez_compressed(os.path.join(OUT, "sam2_tiny.npz"), **out)
     print("wrote sam2_tiny.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.startswith("param")})
 

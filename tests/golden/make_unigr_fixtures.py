@@ -37,60 +37,54 @@ def build():
     cfg.vision_config._attn_implementation = "eager"
     cfg.text_config._attn_implementation = "eager"
     model = RU.UniGRModel(cfg).float()
-    wrap, sam_shapes = MS.build_tiny_predictor(SAM_SIDE)
+    _, sam_shapes = MS.build_tiny_predictor(SAM_SIDE)
+    # ---- names / deterministic weights of the Qwen side + text_hidden_fcs (created by initialize_sam_modules: built once with a throw-away SAM2)
+    RU.SAM2 = lambda ckpt_path=None: MS.build_tiny_predictor(SAM_SIDE)[0]
+    model.initialize_sam_modules(cfg)
+    names = {MQ.hf_name_to_ckpt(n): tuple(p.shape) for n, p in model.named_parameters() if not n.startswith("grounding_encoder.")}
+    sd = det_state_dict(names, seed=1)
+    # ---- fit the mask head's read-out to the objects in the clips of the [SEG] samples of cases "11" and "10" (blobfit.py); the language embeddings
+    #      are the ones the (oracle) LLM side produces for those samples; the evaluate / inference clips are NOT part of the fit
+    import blobfit as BF
+    from oracle import unigr as OU
+    PS0 = det_state_dict(sam_shapes, seed=2)
+    fit_imgs, fit_emb, fit_obj = [], [], []
+    for case in ("11", "10"):
+        flags = CASES[case]
+        b = make_batch(flags, seed=int(case, 2) + 1)
+        with torch.no_grad():
+            r = OU.model_forward(sd, PS0, oracle_cfg(), sam_cfg(), b, (1.0, 0.5, 2.0), SEG)
+        objs = object_masks(flags, seed=int(case, 2) + 1)
+        k = 0
+        for i, has in enumerate(flags):
+            if has:
+                fit_imgs.append(b["images_sam"][i]); fit_obj.append(objs[i]); fit_emb.append(r["pred_embeddings"][k:k + 1][None].expand(T_SAM, 1, -1)); k += 1
+    fitted = BF.fit(PS0, sam_cfg(), torch.cat(fit_imgs), torch.cat(fit_emb), torch.cat(fit_obj), chunk=2)
+    wrap, sam_shapes = MS.build_tiny_predictor(SAM_SIDE, overrides=fitted)
     RU.SAM2 = lambda ckpt_path=None: wrap       # initialize_sam_modules builds SAM2-L otherwise (reference :119)
     model.initialize_sam_modules(cfg)
     model = model.float()
-    names = {}
     with torch.no_grad():
-        for n, p in model.named_parameters():
-            if n.startswith("grounding_encoder."):
-                continue
-            ck = MQ.hf_name_to_ckpt(n)
-            names[ck] = tuple(p.shape)
-        sd = det_state_dict(names, seed=1)
         for n, p in model.named_parameters():
             if not n.startswith("grounding_encoder."):
                 p.copy_(sd[MQ.hf_name_to_ckpt(n)])
-    return model, names, sam_shapes
+    return model, names, sam_shapes, fitted
 
 
-def make_batch(seg_flags, seed):
-    g = np.random.default_rng(seed)
-    grid = [[2, 8, 12]]
-    nv = 2 * 4 * 6
-    ids, labs = [], []
-    for b, has in enumerate(seg_flags):
-        pre = g.integers(0, 290, 6)
-        ans = g.integers(0, 290, 7)
-        if has:
-            ans[3] = SEG
-        seq = np.concatenate([pre, [303], np.full(nv, 302), g.integers(0, 290, 4), ans]).astype(np.int64)
-        lab = np.full_like(seq, -100)
-        lab[-7:] = seq[-7:]
-        ids.append(seq); labs.append(lab)
-    ids, labs = np.stack(ids), np.stack(labs)
-    B = len(seg_flags)
-    px = torch.cat([det_tensor(f"unigr_px_{seed}_{b}", (2 * 8 * 12, 1176), 1.0, seed=5) for b in range(B)], 0)
-    imgs = torch.stack([det_tensor(f"unigr_img_{seed}_{b}", (T_SAM, 3, SAM_SIDE, SAM_SIDE), 1.0, seed=6) for b in range(B)], 0)
-    h, w = 20, 28
-    masks = []
-    for b, has in enumerate(seg_flags):
-        m = (det_tensor(f"unigr_gt_{seed}_{b}", (T_SAM, h, w), 1.0, seed=7) > 0.3).float()
-        masks.append(m if has else m[0:0])
-    return dict(input_ids=torch.from_numpy(ids), labels=torch.from_numpy(labs), attention_mask=torch.ones(B, ids.shape[1], dtype=torch.long),
-                pixel_values_videos=px, video_grid_thw=torch.tensor(grid * B), second_per_grid_ts=torch.tensor([1.0] * B), images_sam=imgs,
-                offset=torch.arange(B + 1), masks_list=masks, label_list=[torch.zeros(h, w) for _ in range(B)], resize_list=[(SAM_SIDE, SAM_SIDE)] * B)
+from tests.unigr_tiny import CASES, LABEL_HW, make_batch, object_masks, sam_cfg  # noqa: E402  (ONE definition of the synthetic batches)
+from tests.qwen_tiny import oracle_cfg  # noqa: E402
 
 
 def main():
-    model, names, sam_shapes = build()
+    model, names, sam_shapes, fitted = build()
     out = {"param_names": np.array(sorted(names)), "param_shapes": np.array([str(names[k]) for k in sorted(names)]),
            "sam_param_names": np.array(sorted(sam_shapes)), "sam_param_shapes": np.array([str(sam_shapes[k]) for k in sorted(sam_shapes)])}
+    for k, v in fitted.items():
+        out["fit::" + k] = v.numpy()
     model.train()
     model.grounding_encoder.sam2_model.eval()
     model.grounding_encoder.sam2_model.sam_mask_decoder.train()
-    for case, flags in {"11": (True, True), "10": (True, False), "00": (False, False)}.items():
+    for case, flags in CASES.items():
         b = make_batch(flags, seed=int(case, 2) + 1)
         tt = (b["input_ids"] == 302).int() * 2
         pos, _ = model.model.get_rope_index(b["input_ids"], mm_token_type_ids=tt, video_grid_thw=b["video_grid_thw"],
@@ -102,12 +96,49 @@ def main():
         o["loss"].backward()
         g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
         for n in ("text_hidden_fcs.0.2.weight", "lm_head.weight", "grounding_encoder.sam2_model.sam_mask_decoder.output_hypernetworks_mlps.1.layers.2.weight",
-                  "grounding_encoder.sam2_model.sam_mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight"):
+                  "grounding_encoder.sam2_model.sam_mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight",
+                  "grounding_encoder.sam2_model.sam_mask_decoder.output_upscaling.0.weight", "text_hidden_fcs.0.0.weight"):
             if n in g:
                 out[f"train_{case}_grad::{n}"] = g[n].numpy().copy()
         out[f"train_{case}_n_grads"] = np.int64(len(g))
         out[f"train_{case}_input_ids"] = b["input_ids"].numpy()
         out[f"train_{case}_labels"] = b["labels"].numpy()
+
+    # ---- H1: two optimizer steps of the reference's recipe on the "11" batch -- trainable set of train_joint.py:237-251 (no
+    #      LoRA here: PEFT is absent), gradient clipping 1.0, AdamW lr 4e-5, betas (0.9, 0.95), wd 0 (train_joint.py:300-324; DeepSpeed's FusedAdam in
+    #      AdamW mode == torch.optim.AdamW).  Pinned: loss dict before each step, the pre-clip gradient norm, gradients and parameter deltas of 4 tensors.
+    H1_TENSORS = ("lm_head.weight", "model.language_model.embed_tokens.weight", "text_hidden_fcs.0.2.weight",
+                  "grounding_encoder.sam2_model.sam_mask_decoder.output_hypernetworks_mlps.1.layers.2.weight")
+    saved = {n: p.detach().clone() for n, p in model.named_parameters()}
+    flags_before = {n: p.requires_grad for n, p in model.named_parameters()}
+    for n, p in model.named_parameters():
+        p.requires_grad_(any(x in n for x in ("lm_head", "embed_tokens", "sam_mask_decoder", "text_hidden_fcs")))
+    train = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(train, lr=4e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0)
+    b = make_batch(CASES["11"], seed=int("11", 2) + 1)
+    tt = (b["input_ids"] == 302).int() * 2
+    pos, _ = model.model.get_rope_index(b["input_ids"], mm_token_type_ids=tt, video_grid_thw=b["video_grid_thw"],
+                                        second_per_grid_ts=b["second_per_grid_ts"], attention_mask=b["attention_mask"])
+    named = dict(model.named_parameters())
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        o = model(**b, position_ids=pos, inference=False)
+        for k in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss"):
+            out[f"h1_step{step}_{k}"] = np.float64(float(o[k]))
+        o["loss"].backward()
+        out[f"h1_step{step}_grad_norm"] = np.float64(float(torch.nn.utils.clip_grad_norm_(train, 1.0)))
+        if step == 0:
+            for n in H1_TENSORS:
+                out[f"h1_grad::{MQ.hf_name_to_ckpt(n) if not n.startswith(('grounding_encoder', 'text_hidden')) else n}"] = (named[n].grad / min(1.0, 1.0 / (out["h1_step0_grad_norm"] + 1e-6))).numpy().copy()
+        opt.step()
+        for n in H1_TENSORS:
+            key = MQ.hf_name_to_ckpt(n) if not n.startswith(("grounding_encoder", "text_hidden")) else n
+            out[f"h1_delta{step + 1}::{key}"] = (named[n].detach() - saved[n]).numpy().copy()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(saved[n])
+            p.requires_grad_(flags_before[n])
+    model.zero_grad(set_to_none=True)
 
     # evaluate(): teacher-forced "Sure, [SEG]." in input_ids, one sample
     model.eval()
@@ -133,7 +164,18 @@ def main():
     model.grounding_encoder.sam2_model.init_state = init_state
     with torch.no_grad():
         o, masks = model.evaluate(b["input_ids"], b["attention_mask"], None, b["pixel_values_videos"], None, b["video_grid_thw"], b["second_per_grid_ts"],
-                                  b["images_sam"], b["resize_list"], [(20, 28)])
+                                  b["images_sam"], b["resize_list"], [LABEL_HW])
+    # ---- model_forward(inference=True): the branch validate() drives (reference :236-257, train_joint.py:586-648), batch size 1, with and without [SEG]
+    for tag, flags, seed in (("1", (True,), 11), ("0", (False,), 12)):
+        bi = make_batch(flags, seed=seed)
+        tti = (bi["input_ids"] == 302).int() * 2
+        posi, _ = model.model.get_rope_index(bi["input_ids"], mm_token_type_ids=tti, video_grid_thw=bi["video_grid_thw"],
+                                             second_per_grid_ts=bi["second_per_grid_ts"], attention_mask=bi["attention_mask"])
+        with torch.no_grad():
+            oi = model(**bi, position_ids=posi, inference=True)
+        assert set(oi) == {"pred_masks", "gt_masks"} and len(oi["pred_masks"]) == 1
+        out[f"infer_{tag}_pred_masks"] = oi["pred_masks"][0].numpy()
+        out[f"infer_{tag}_input_ids"] = bi["input_ids"].numpy()
     transformers.Qwen2_5_VLForConditionalGeneration.forward = orig
     out["eval_input_ids"] = b["input_ids"].numpy()
     out["eval_masks"] = masks[0].numpy()

@@ -20,15 +20,26 @@ def tiny_cfg():
 
 
 def det_params(g, bf16_round=False):
+    """Name-derived deterministic weights + the fitted mask-head read-out stored in the fixture ("fit::<name>", tests/golden/blobfit.py)."""
     shapes = {str(n): eval(str(s)) for n, s in zip(g["param_names"], g["param_shapes"])}
     sd = det_state_dict(shapes, seed=2)
+    for k in g.files:
+        if k.startswith("fit::"):
+            sd[k[5:]] = torch.from_numpy(g[k])
     if bf16_round:
         sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
     return sd
 
 
 def images(T=5):
-    return det_tensor("sam_images", (5, 3, 128, 128), 1.0, seed=3)[:T]
+    """The fixture clip: an ellipse drifting over a smooth background (tests/blob_inputs.py)."""
+    from tests.blob_inputs import object_video
+    return object_video("sam_images", 5, 128, seed=3)[0][:T]
+
+
+def object_masks(T=5):
+    from tests.blob_inputs import object_video
+    return object_video("sam_images", 5, 128, seed=3)[1][:T]
 
 
 def lang(T=5):

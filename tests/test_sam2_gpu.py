@@ -1,7 +1,8 @@
 """GPU parity of the product SAM2 (rga3/model/sam2.py on HIP kernels, bf16) against the fp32 oracle run on the same
 bf16-rounded weights, and against the golden vectors captured from the reference's own classes.
-Tolerances: feature / mask-logit rel-L2 <= 2e-2 .. 3e-2 (deep bf16 chains), mask IoU >= 0.99,
-argmax-IoU index bit-exact where the IoU margin exceeds bf16 noise."""
+Tolerances (as stated): feature / mask-logit rel-L2 <= 2e-2, mask IoU >= 0.99, argmax-IoU index bit-exact.
+The fixture clips show an object and the mask head's read-out is fitted to it (tests/blob_inputs.py, tests/golden/blobfit.py): the reference's masks
+are blobs with |logit| >> 0 on > 98 % of the pixels, so the thresholded comparisons mean something."""
 import numpy as np
 import pytest
 import torch
@@ -71,16 +72,19 @@ def test_train_path_masks(model, dev, P, G):
         feats = S.prepare_backbone_features(S.image_encoder_forward(P, img.float(), cfg))
         rlow, rhigh, ro = S.inject_language_embd_train(P, feats, emb.float(), cfg)
     assert low.shape == (3, 1, 32, 32) and high.shape == (3, 1, 128, 128) and high.dtype == torch.float32
-    assert rel(o["low_res_multimasks"], ro["low_res_multimasks"]) < 3e-2
+    assert rel(o["low_res_multimasks"], ro["low_res_multimasks"]) < 2e-2
     assert rel(o["ious"], ro["ious"]) < 1e-2
     top2 = ro["ious"].topk(2, -1).values
-    decided = (top2[:, 0] - top2[:, 1]) > 0.02
-    assert torch.equal(o["best_iou_inds"].cpu()[decided], ro["best_iou_inds"][decided])
-    same = (o["best_iou_inds"].cpu() == ro["best_iou_inds"])
-    assert rel(high[same.to(high.device)], rhigh[same]) < 3e-2
-    assert rel(o["obj_ptr"][same.to(high.device)], ro["obj_ptr"][same]) < 3e-2
-    for i in torch.nonzero(same).flatten().tolist():
-        assert iou(high[i] > 0, torch.from_numpy(G["g3_train_high"][i]) > 0) >= 0.97  # vs the reference's fp32 masks (unrounded weights)
+    assert bool(((top2[:, 0] - top2[:, 1]) > 0.05).all())          # the fixture's IoU head is decisive ...
+    assert torch.equal(o["best_iou_inds"].cpu(), ro["best_iou_inds"])   # ... so the argmax index is bit-exact on every frame
+    assert np.array_equal(o["best_iou_inds"].cpu().numpy(), G["g3_heads_best"])
+    assert rel(high, rhigh) < 2e-2
+    assert rel(o["obj_ptr"], ro["obj_ptr"]) < 2e-2
+    rh = torch.from_numpy(G["g3_train_high"])
+    assert float((rh.abs() > 0.05 * rh.abs().amax((1, 2, 3), keepdim=True)).float().mean()) > 0.98   # blobs, not speckle
+    for i in range(3):
+        assert iou(high[i] > 0, rhigh[i] > 0) >= 0.99
+        assert iou(high[i] > 0, rh[i] > 0) >= 0.99  # vs the reference's own fp32 masks (unrounded weights)
 
 
 def test_inference_prompt_every_frame(model, dev, P, G):
@@ -93,12 +97,15 @@ def test_inference_prompt_every_frame(model, dev, P, G):
     assert masks.shape == (5, 1, 128, 128)
     assert sess.counts["enc"] == 5 and sess.counts["memattn"] == 0 and sess.counts["memenc"] == 0   # reference: enc=10, memenc=5 (dead work)
     same = [int(sess.cond[t]["best_iou_inds"]) == int(rs.out["cond_frame_outputs"][t]["best_iou_inds"]) if "best_iou_inds" in rs.out["cond_frame_outputs"][t] else True for t in range(5)]
+    assert all(same)
     ious = [iou(masks[t] > 0, rmasks[t] > 0) for t in range(5)]
-    # random-weight masks are speckle (logits hover around 0): exact agreement is required outside the bf16 noise band
     margin = rmasks.abs() > 0.05 * rmasks.abs().max()
-    assert margin.float().mean() > 0.5
-    assert torch.equal((masks.cpu() > 0)[margin], (rmasks > 0)[margin])
-    assert np.mean(ious) >= 0.97, ious
+    assert margin.float().mean() > 0.98                                       # blobs with a real margin
+    assert torch.equal((masks.cpu() > 0)[margin], (rmasks > 0)[margin])       # bit-exact outside the band at the blob edges
+    assert rel(masks, rmasks) < 2e-2
+    assert min(ious) >= 0.99, ious
+    gm = torch.from_numpy(G["g3_infer_all_masks"])                            # the reference's own output (fp32, unrounded weights, 2x encoder passes)
+    assert min(iou(masks[t] > 0, gm[t] > 0) for t in range(5)) >= 0.99
 
 
 def test_frame0_prompt_propagation(model, dev, P, G):
@@ -115,8 +122,13 @@ def test_frame0_prompt_propagation(model, dev, P, G):
         rres = rs.propagate()
     assert sess.counts["memattn"] == 4 and sess.counts["enc"] == 5
     masks, rmasks = torch.cat([m for _, m in res]), torch.cat([m for _, m in rres])
-    assert rel(masks, rmasks) < 6e-2
-    assert np.mean([iou(masks[t] > 0, rmasks[t] > 0) for t in range(5)]) >= 0.98
+    assert rel(masks, rmasks) < 2e-2
+    assert min(iou(masks[t] > 0, rmasks[t] > 0) for t in range(5)) >= 0.99
+    gm = torch.from_numpy(G["g3_prop0_masks"])                                # the reference's own propagate_in_video output
+    assert float((gm.abs() > 0.05 * gm.abs().max()).float().mean()) > 0.98
+    assert min(iou(masks[t] > 0, gm[t] > 0) for t in range(5)) >= 0.99
+    ptr = torch.stack([(sess.cond if t == 0 else sess.non_cond)[t]["obj_ptr"].float().cpu().reshape(-1) for t in range(5)])
+    assert rel(ptr, torch.from_numpy(G["g3_prop0_obj_ptrs"]).reshape(5, -1)) < 2e-2
 
 
 def test_graph_replay_equals_eager_stream(model, dev):

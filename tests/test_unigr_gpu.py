@@ -7,7 +7,7 @@ import torch
 
 from oracle import unigr as U
 from tests.qwen_tiny import oracle_cfg, product_cfg_kwargs
-from tests.unigr_tiny import CASES, SAM_TINY, SEG, gold, make_batch, params, sam_cfg
+from tests.unigr_tiny import CASES, LABEL_HW, SAM_TINY, SEG, gold, make_batch, params, sam_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -85,17 +85,16 @@ def test_evaluate_masks(model, dev, G):
     P, PS = params(G, bf16_round=True)
     d = to_dev(b, dev)
     with torch.no_grad():
-        _, rmasks, _, rlogits = U.evaluate(P, PS, oracle_cfg(), sam_cfg(), bb, SEG, [(20, 28)])
+        _, rmasks, _, rlogits = U.evaluate(P, PS, oracle_cfg(), sam_cfg(), bb, SEG, [LABEL_HW])
         o, masks = model.evaluate(d["input_ids"], d["attention_mask"], None, d["pixel_values_videos"], None, d["video_grid_thw"], d["second_per_grid_ts"],
-                                  d["images_sam"], d["resize_list"], [(20, 28)])
+                                  d["images_sam"], d["resize_list"], [LABEL_HW])
     assert len(masks) == 1 and masks[0].dtype == torch.bool and masks[0].shape == rmasks[0].shape
-    # random-weight masks are speckle: many logits sit inside the bf16 noise band, so bit-exactness is required where the
-    # oracle's |logit| margin exceeds the noise and the IoU is reported over everything
+    # the clip shows an object and the mask head's read-out is fitted to such objects (on OTHER clips): blob masks with a real margin
     margin = rlogits[0].abs() > 0.05 * rlogits[0].abs().max()
-    assert margin.float().mean() > 0.5
-    assert torch.equal(masks[0].cpu()[margin], rmasks[0][margin])
-    assert iou(masks[0], rmasks[0]) >= 0.96
-    assert iou(masks[0], torch.from_numpy(G["eval_masks"])) >= 0.95  # vs the reference's own bool masks (fp32, unrounded weights)
+    assert margin.float().mean() > 0.97
+    assert torch.equal(masks[0].cpu()[margin], rmasks[0][margin])      # bit-exact outside the band at the blob edges
+    assert iou(masks[0], rmasks[0]) >= 0.99
+    assert iou(masks[0], torch.from_numpy(G["eval_masks"])) >= 0.99  # vs the reference's own bool masks (fp32, unrounded weights)
 
 
 def test_training_gradients_through_mask_path(dev, G):
@@ -168,9 +167,10 @@ def test_training_gradients_through_mask_path(dev, G):
     # bf16 activations AND bf16 intermediate gradients through ~40 ops: the per-tensor error against fp32 autograd is rounding noise
     # that moves by a few percent under any rounding-level change of a kernel (measured across equivalent builds on one device: median
     # 0.04-0.08, worst tensor 0.10-0.15).  A wrong backward formula or a dropped term shows as >= 0.5 on the tensors it feeds.
-    bad = {k: e for k, e in errs.items() if e > 0.2}
+    # stated tolerance (VERDICT r1 / SURVEY.md 8(d)): bf16 backward against fp32 autograd, <= 3e-2 per tensor
+    bad = {k: round(e, 4) for k, e in errs.items() if e > 3e-2}
     assert not bad, (bad, sorted(errs.values())[-5:])
-    assert float(np.median(list(errs.values()))) < 0.1
+    assert float(np.median(list(errs.values()))) < 2e-2
     # the direction of the whole mask-path gradient is stable: cosine of the concatenated decoder + text_hidden_fcs gradients
     ga = torch.cat([g_.float().cpu().flatten() for k, (g_, r_) in pairs.items() if k in errs and ("sam_mask_decoder" in k or "text_hidden_fcs" in k)])
     gr = torch.cat([r_.float().cpu().flatten() for k, (g_, r_) in pairs.items() if k in errs and ("sam_mask_decoder" in k or "text_hidden_fcs" in k)])
@@ -178,7 +178,84 @@ def test_training_gradients_through_mask_path(dev, G):
     assert cos > 0.99, cos
     # the reference's own gradients (fp32, unrounded weights) for four tensors
     for k in ("text_hidden_fcs.0.2.weight", "lm_head.weight", "grounding_encoder.sam2_model.sam_mask_decoder.output_hypernetworks_mlps.1.layers.2.weight",
-              "grounding_encoder.sam2_model.sam_mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight"):
+              "grounding_encoder.sam2_model.sam_mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight",
+              "grounding_encoder.sam2_model.sam_mask_decoder.output_upscaling.0.weight", "text_hidden_fcs.0.0.weight"):
         gk = f"train_{case}_grad::{k}"
         if gk in G.files:
-            assert rl(got[k], torch.from_numpy(G[gk])) < 0.15, k
+            assert rl(got[k], torch.from_numpy(G[gk])) < 4e-2, k
+
+
+@pytest.mark.parametrize("tag,flags,seed", [("1", (True,), 11), ("0", (False,), 12)])
+def test_model_forward_inference_branch(model, dev, G, tag, flags, seed):
+    """model_forward(inference=True): what validate() drives (reference qwen_2_5_vl_sam2.py:236-257, train_joint.py:586-648).  Bool masks against the
+    oracle branch on the same bf16-rounded weights and against the reference's own masks; the second case has no [SEG] (zero-embedding prompt)."""
+    b = make_batch(flags, seed=seed)
+    bb = dict(b, pixel_values_videos=b["pixel_values_videos"].to(torch.bfloat16).float(), images_sam=b["images_sam"].to(torch.bfloat16).float())
+    P, PS = params(G, bf16_round=True)
+    with torch.no_grad():
+        ref = U.model_forward(P, PS, oracle_cfg(), sam_cfg(), bb, (1.0, 0.5, 2.0), SEG, inference=True)
+        out = model(**to_dev(b, dev), inference=True)
+    assert set(out) == {"pred_masks", "gt_masks"} and len(out["pred_masks"]) == 1
+    pm, rm, lg = out["pred_masks"][0], ref["pred_masks"][0], ref["mask_logits"][0]
+    assert pm.dtype == torch.bool and tuple(pm.shape) == tuple(rm.shape) == (2, *LABEL_HW)
+    margin = lg.abs() > 0.05 * lg.abs().max()
+    assert margin.float().mean() > 0.97
+    assert torch.equal(pm.cpu()[margin], rm[margin])
+    assert iou(pm, rm) >= 0.99
+    assert iou(pm, torch.from_numpy(G[f"infer_{tag}_pred_masks"])) >= 0.99
+    assert all(torch.equal(a.cpu(), b_) for a, b_ in zip(out["gt_masks"], b["masks_list"]))
+
+
+def test_two_optimizer_steps_h1(dev, G):
+    """SURVEY.md 8(a) row H1 on the GPU: model(**batch) -> backward -> GradBucketReducer -> FusedAdamW (clip 1.0, lr 4e-5, betas (0.9, 0.95), wd 0: reference
+    train_joint.py:300-324, 521-535), two steps on the "11" batch, against what the reference model + torch.optim.AdamW produced (tests/golden/unigr_tiny.npz h1_*):
+    loss dict before each step, pre-clip gradient norm, fp32 master-weight deltas of four tensors."""
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
+    from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
+
+    cfg = UniGRConfig(train_mask_decoder=True, out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=SEG,
+                      sam_pretrained=None, sam_config=SAM_TINY, **product_cfg_kwargs())
+    m = UniGRModel(cfg)
+    m.initialize_sam_modules(cfg)
+    P0, PS0 = params(G)
+    sd = dict(P0)
+    sd.update({"grounding_encoder.sam2_model." + k: v for k, v in PS0.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(torch.bfloat16).to(dev)
+    for n, p in m.named_parameters():
+        p.requires_grad_(any(x in n for x in ("lm_head", "embed_tokens", "sam_mask_decoder", "text_hidden_fcs")))   # train_joint.py:237-251 (no LoRA in the fixture)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    train = [p for p in m.parameters() if p.requires_grad]
+    red = GradBucketReducer(train, bucket_mb=0.25, sparse_params=[m.model.embed_tokens.weight])
+    opt = FusedAdamW(train, lr=4e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+    # masters start from the UNROUNDED fixture weights, as the reference's fp32 parameters do (the bf16 parameters are their roundings)
+    with torch.no_grad():
+        for n, w in zip(names, opt.master):
+            w.copy_(sd[n].to(dev))
+    w0 = {n: w.clone() for n, w in zip(names, opt.master)}
+    b = to_dev(make_batch(CASES["11"], seed=4), dev)
+    for step in range(2):
+        red.begin_step()
+        red.begin_micro_step()
+        out = m(**b, inference=False)
+        for k in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss"):
+            r = float(G[f"h1_step{step}_{k}"])
+            assert abs(float(out[k]) - r) <= 3e-2 * abs(r) + 5e-3, (step, k, float(out[k]), r)
+        out["loss"].backward()
+        red.finish()
+        opt.step(red.grad_view, red.flat_grads())
+        gn, rn = float(opt.grad_norm()), float(G[f"h1_step{step}_grad_norm"])
+        assert abs(gn - rn) <= 4e-2 * rn, (step, gn, rn)
+        for key in [k for k in G.files if k.startswith(f"h1_delta{step + 1}::")]:
+            n = key.split("::")[1]
+            d = (opt.master[names.index(n)] - w0[n]).float().cpu().numpy()
+            ref = G[key]
+            g0 = G["h1_grad::" + n]
+            # Adam's first steps move every element by about +-lr whatever the gradient's size: the sign must agree wherever the reference gradient is
+            # clearly non-zero; elements with a gradient at the bf16 noise level may go either way
+            strong = np.abs(g0) > 0.05 * np.abs(g0).max()
+            assert strong.mean() > 0.02, n
+            assert (np.abs(d - ref)[strong] <= 0.1 * np.abs(ref)[strong] + 1e-7).mean() > 0.98, (n, step)
+            cos = float((d * ref).sum() / (np.linalg.norm(d) * np.linalg.norm(ref) + 1e-30))
+            assert cos > (0.9 if step == 0 else 0.85), (n, step, cos)
+    red.remove()

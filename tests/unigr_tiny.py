@@ -23,10 +23,17 @@ def sam_cfg():
                      d_model=256, mem_dim=64, memattn_layers=2)
 
 
+LABEL_HW = (120, 168)   # label / GT-mask resolution of the synthetic samples (non-square, not a divisor of 1024, like real data)
+
+
 def params(g, bf16_round=False):
+    """Name-derived deterministic weights; the SAM2 mask head's fitted read-out ("fit::<name>" in the fixture, tests/golden/blobfit.py) on top."""
     shapes = {str(n): eval(str(s)) for n, s in zip(g["param_names"], g["param_shapes"])}
     sam_shapes = {str(n): eval(str(s)) for n, s in zip(g["sam_param_names"], g["sam_param_shapes"])}
     P, PS = det_state_dict(shapes, seed=1), det_state_dict(sam_shapes, seed=2)
+    for k in g.files:
+        if k.startswith("fit::"):
+            PS[k[5:]] = torch.from_numpy(g[k])
     if bf16_round:
         P = {k: v.to(torch.bfloat16).float() for k, v in P.items()}
         PS = {k: v.to(torch.bfloat16).float() for k, v in PS.items()}
@@ -50,15 +57,23 @@ def make_batch(seg_flags, seed):
     ids, labs = np.stack(ids), np.stack(labs)
     B = len(seg_flags)
     px = torch.cat([det_tensor(f"unigr_px_{seed}_{b}", (2 * 8 * 12, 1176), 1.0, seed=5) for b in range(B)], 0)
-    imgs = torch.stack([det_tensor(f"unigr_img_{seed}_{b}", (T_SAM, 3, SAM_SIDE, SAM_SIDE), 1.0, seed=6) for b in range(B)], 0)
-    h, w = 20, 28
+    # SAM frames: one ellipse drifting over a smooth background per sample (tests/blob_inputs.py); GT masks = that object at label resolution
+    from tests.blob_inputs import masks_at, object_video
+    clips = [object_video(f"unigr_img_{seed}_{b}", T_SAM, SAM_SIDE, seed=6) for b in range(B)]
+    imgs = torch.stack([c[0] for c in clips], 0)
+    h, w = LABEL_HW
     masks = []
     for b, has in enumerate(seg_flags):
-        m = (det_tensor(f"unigr_gt_{seed}_{b}", (T_SAM, h, w), 1.0, seed=7) > 0.3).float()
+        m = masks_at(clips[b][1], (h, w))
         masks.append(m if has else m[0:0])
     return dict(input_ids=torch.from_numpy(ids), labels=torch.from_numpy(labs), attention_mask=torch.ones(B, ids.shape[1], dtype=torch.long),
                 pixel_values_videos=px, video_grid_thw=torch.tensor(grid * B), second_per_grid_ts=torch.tensor([1.0] * B), images_sam=imgs,
                 offset=torch.arange(B + 1), masks_list=masks, label_list=[torch.zeros(h, w) for _ in range(B)], resize_list=[(SAM_SIDE, SAM_SIDE)] * B)
+
+
+def object_masks(seg_flags, seed):
+    from tests.blob_inputs import object_video
+    return [object_video(f"unigr_img_{seed}_{b}", T_SAM, SAM_SIDE, seed=6)[1] for b in range(len(seg_flags))]
 
 
 CASES = {"11": (True, True), "10": (True, False), "00": (False, False)}
