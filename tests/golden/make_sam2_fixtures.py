@@ -78,6 +78,7 @@ def build_tiny_predictor(image_size=None, overrides=None):
     shapes = {k: tuple(v.shape) for k, v in pred.state_dict().items()}
     sd = det_state_dict(shapes, seed=2)
     sd.update(overrides or {})
+    sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}   # bf16-representable weights: reference (fp32 compute), oracle and product see identical numbers
     pred.load_state_dict(sd, strict=True)
     # the SAM2 wrapper hard-codes SAM2-L sizes in its constructor (sam2.py:87-146); wrap the tiny predictor in it without running it
     wrap = RS.SAM2.__new__(RS.SAM2)
@@ -139,12 +140,14 @@ def main():
     # ------------------------------------------------------------------ G2/G3: tiny SAM2 built from the reference classes
     T = 5
     imgs, obj = object_video("sam_images", T, 128, seed=3)     # an ellipse drifting over a smooth background (tests/blob_inputs.py)
-    emb = det_tensor("lang_embd", (T, 1, 256), 1.0, seed=4)
+    imgs = imgs.to(torch.bfloat16).float()
+    emb = det_tensor("lang_embd", (T, 1, 256), 1.0, seed=4).to(torch.bfloat16).float()
     # fit the mask head's read-out to that object on frames 0-2 (frames 3-4 and the memory path are then genuinely predicted)
     import blobfit as BF
     from tests.sam2_tiny import tiny_cfg
     _, shapes = build_tiny_predictor()
-    fitted = BF.fit(det_state_dict(shapes, seed=2), tiny_cfg(), imgs[:3], emb[:3], obj[:3])
+    fitted = BF.fit({k: v.to(torch.bfloat16).float() for k, v in det_state_dict(shapes, seed=2).items()}, tiny_cfg(), imgs[:3], emb[:3], obj[:3])
+    fitted = {k: v.to(torch.bfloat16).float() for k, v in fitted.items()}
     for k, v in fitted.items():
         out["fit::" + k] = v.numpy()
     wrap, shapes = build_tiny_predictor(overrides=fitted)

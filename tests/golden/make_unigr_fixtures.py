@@ -42,12 +42,12 @@ def build():
     RU.SAM2 = lambda ckpt_path=None: MS.build_tiny_predictor(SAM_SIDE)[0]
     model.initialize_sam_modules(cfg)
     names = {MQ.hf_name_to_ckpt(n): tuple(p.shape) for n, p in model.named_parameters() if not n.startswith("grounding_encoder.")}
-    sd = det_state_dict(names, seed=1)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in det_state_dict(names, seed=1).items()}   # bf16-representable, like every weight of these fixtures
     # ---- fit the mask head's read-out to the objects in the clips of the [SEG] samples of cases "11" and "10" (blobfit.py); the language embeddings
     #      are the ones the (oracle) LLM side produces for those samples; the evaluate / inference clips are NOT part of the fit
     import blobfit as BF
     from oracle import unigr as OU
-    PS0 = det_state_dict(sam_shapes, seed=2)
+    PS0 = {k: v.to(torch.bfloat16).float() for k, v in det_state_dict(sam_shapes, seed=2).items()}
     fit_imgs, fit_emb, fit_obj = [], [], []
     for case in ("11", "10"):
         flags = CASES[case]
@@ -60,6 +60,7 @@ def build():
             if has:
                 fit_imgs.append(b["images_sam"][i]); fit_obj.append(objs[i]); fit_emb.append(r["pred_embeddings"][k:k + 1][None].expand(T_SAM, 1, -1)); k += 1
     fitted = BF.fit(PS0, sam_cfg(), torch.cat(fit_imgs), torch.cat(fit_emb), torch.cat(fit_obj), chunk=2)
+    fitted = {k: v.to(torch.bfloat16).float() for k, v in fitted.items()}
     wrap, sam_shapes = MS.build_tiny_predictor(SAM_SIDE, overrides=fitted)
     RU.SAM2 = lambda ckpt_path=None: wrap       # initialize_sam_modules builds SAM2-L otherwise (reference :119)
     model.initialize_sam_modules(cfg)

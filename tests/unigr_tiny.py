@@ -34,9 +34,10 @@ def params(g, bf16_round=False):
     for k in g.files:
         if k.startswith("fit::"):
             PS[k[5:]] = torch.from_numpy(g[k])
-    if bf16_round:
-        P = {k: v.to(torch.bfloat16).float() for k, v in P.items()}
-        PS = {k: v.to(torch.bfloat16).float() for k, v in PS.items()}
+    # every weight of the fixture is bf16-representable (the generator pours the SAME rounded values into the reference's fp32 modules), so product,
+    # oracle and reference compute on identical numbers; bf16_round is kept for callers of the old signature and changes nothing
+    P = {k: v.to(torch.bfloat16).float() for k, v in P.items()}
+    PS = {k: v.to(torch.bfloat16).float() for k, v in PS.items()}
     return P, PS
 
 
@@ -56,11 +57,11 @@ def make_batch(seg_flags, seed):
         ids.append(seq); labs.append(lab)
     ids, labs = np.stack(ids), np.stack(labs)
     B = len(seg_flags)
-    px = torch.cat([det_tensor(f"unigr_px_{seed}_{b}", (2 * 8 * 12, 1176), 1.0, seed=5) for b in range(B)], 0)
+    px = torch.cat([det_tensor(f"unigr_px_{seed}_{b}", (2 * 8 * 12, 1176), 1.0, seed=5) for b in range(B)], 0).to(torch.bfloat16).float()
     # SAM frames: one ellipse drifting over a smooth background per sample (tests/blob_inputs.py); GT masks = that object at label resolution
     from tests.blob_inputs import masks_at, object_video
     clips = [object_video(f"unigr_img_{seed}_{b}", T_SAM, SAM_SIDE, seed=6) for b in range(B)]
-    imgs = torch.stack([c[0] for c in clips], 0)
+    imgs = torch.stack([c[0] for c in clips], 0).to(torch.bfloat16).float()   # inputs are bf16-representable too
     h, w = LABEL_HW
     masks = []
     for b, has in enumerate(seg_flags):
