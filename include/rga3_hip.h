@@ -232,6 +232,10 @@ int rga3_pixel_shuffle2x_bwd(const void* dout, void* dg, int64_t F, int H, int W
 /* dlogits = coef_bce * d(sum_n mean BCE) + coef_dice * d(sum_n dice_n) (model/qwen_2_5_vl_sam2.py:17-60) from the forward sums */
 int rga3_bce_dice_grad(const float* logits, const float* targets, const float* sums4, float* dlogits, int64_t n_masks, int64_t hw,
                        float coef_bce, float coef_dice, void* stream);
+/* the same with the two upstream gradients read from DEVICE memory (f32 scalars): autograd hands them over as device tensors, and reading them on the
+ * host would be a device -> host sync in the middle of backward */
+int rga3_bce_dice_grad_dev(const float* logits, const float* targets, const float* sums4, float* dlogits, int64_t n_masks, int64_t hw,
+                           const float* coef_bce_dev, const float* coef_dice_dev, void* stream);
 
 /* ---- SAM-side input pipeline: Pillow-exact antialiased bicubic resize + normalise + bf16, replacing
  * DirectResize.apply_image + preprocess + .bfloat16() (reference utils/utils.py:230-256, inference_mevis.py:175-180).

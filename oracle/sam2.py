@@ -346,10 +346,12 @@ def mask_decoder(P, image_embeddings, image_pe, sparse, dense, high_res_features
     up = F.gelu(layer_norm_2d(up, P, pre + "output_upscaling.1"))
     up = F.gelu(conv_transpose_2x2(up, P[pre + "output_upscaling.3.weight"], P[pre + "output_upscaling.3.bias"]) + feat_s0)
     hyper = torch.stack([mlp(mask_toks[:, i], P, f"{pre}output_hypernetworks_mlps.{i}", 3) for i in range(4)], dim=1)
-    if internals is not None:   # fixture construction only (tests/golden/blobfit.py): the two factors of the mask product
-        internals.update(mask_toks=mask_toks, upscaled=up)
-    bb, cc, hh, ww = up.shape
-    masks = (hyper @ up.view(bb, cc, hh * ww)).view(bb, -1, hh, ww)
+    masks = (hyper @ up.view(up.shape[0], up.shape[1], -1)).view(up.shape[0], -1, up.shape[2], up.shape[3])
+    if internals is not None:   # fixture construction (tests/golden/blobfit.py) and gradient localisation (tools/grad_locate.py): intermediates of the head
+        internals.update(mask_toks=mask_toks, upscaled=up, hs=hs, src=src, tokens=tokens, hyper=hyper, masks=masks)
+        for t in (hs, src, up, hyper, masks, tokens):
+            if t.requires_grad:
+                t.retain_grad()
     iou = mlp(iou_tok, P, pre + "iou_prediction_head", 3, sigmoid_output=True)
     obj_logits = mlp(hs[:, 0], P, pre + "pred_obj_score_head", 3)
     if multimask_output:
@@ -393,13 +395,13 @@ def forward_sam_heads(P, backbone_features, high_res_features, language_embd, cf
                 obj_ptr=obj_ptr, object_score_logits=obj_logits, best_iou_inds=best)
 
 
-def inject_language_embd_train(P, feats, language_embd, cfg: Sam2Cfg):
+def inject_language_embd_train(P, feats, language_embd, cfg: Sam2Cfg, internals=None):
     """S:343-375: frames independent, + no_mem_embed, multimask always on (S:3128-3136)."""
     vf, _, sizes = feats
     B = vf[-1].shape[1]
     high = [x.permute(1, 2, 0).view(x.shape[1], x.shape[2], *s) for x, s in zip(vf[:-1], sizes[:-1])]
     pix = (vf[-1] + P["no_mem_embed"]).permute(1, 2, 0).view(B, cfg.d_model, *sizes[-1])
-    o = forward_sam_heads(P, pix, high, language_embd, cfg, True)
+    o = forward_sam_heads(P, pix, high, language_embd, cfg, True, internals)
     return o["low_res_masks"], o["high_res_masks"], o
 
 

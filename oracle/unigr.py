@@ -36,7 +36,7 @@ def shifted_seg_mask(ids, seg_idx):
     return torch.cat([m[:, 1:], torch.zeros_like(m)[:, 0].unsqueeze(1)], dim=1)
 
 
-def model_forward(P, PS, qcfg, scfg, batch, weights, seg_token_idx, out_dim=256, inference=False):
+def model_forward(P, PS, qcfg, scfg, batch, weights, seg_token_idx, out_dim=256, inference=False, internals=None):
     """reference :149-321.  P: Qwen+head params, PS: SAM2 params (names without the 'grounding_encoder.sam2_model.' prefix).
     weights = (ce, dice, bce).  inference=True is the branch validate() drives (reference :236-257, train_joint.py:586-648): batch size 1
     (the reference squeezes dim 0 of images_sam), SAM2 video inference with the language prompt on every frame, bilinear to the label size,
@@ -67,7 +67,13 @@ def model_forward(P, PS, qcfg, scfg, batch, weights, seg_token_idx, out_dim=256,
             logits.append(m)
         return {"pred_masks": pred_masks, "gt_masks": batch["masks_list"], "mask_logits": logits, "seg_token_offset": off}
     feats = S.prepare_backbone_features(S.image_encoder_forward(PS, images_sam.flatten(0, 1), scfg))
-    _, high, _ = S.inject_language_embd_train(PS, feats, lang, scfg)
+    if internals is not None and lang.requires_grad:
+        lang.retain_grad()
+        internals["lang"] = lang
+    _, high, _ = S.inject_language_embd_train(PS, feats, lang, scfg, internals)
+    if internals is not None:
+        high.retain_grad()
+        internals["high"] = high
     high = high.reshape(B, T, scfg.image_size, scfg.image_size)
     bce = dice = 0
     n_tot = 0

@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void pixel_shuffle_bwd_kernel(const unsigned s
 
 // dlogits of  cb * sum_n mean_hw BCE(x, t) + cd * sum_n dice_n  given the per-mask forward sums {bce, sum p t, sum p, sum t}
 __global__ __launch_bounds__(256) void bce_dice_grad_kernel(const float* __restrict__ x, const float* __restrict__ tg, const float* __restrict__ sums,
-                                                            float* __restrict__ dx, long n_masks, long hw, float cb, float cd) {
+                                                            float* __restrict__ dx, long n_masks, long hw, float cb, float cd,
+                                                            const float* __restrict__ cbp, const float* __restrict__ cdp) {
+    if (cbp) cb *= cbp[0];   // upstream gradients of the two loss sums, read on the device (no device -> host sync in backward)
+    if (cdp) cd *= cdp[0];
     const long total = n_masks * hw;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long n = i / hw;
@@ -347,7 +350,16 @@ extern "C" int rga3_bce_dice_grad(const float* logits, const float* targets, con
                                   float coef_bce, float coef_dice, void* stream) {
     RGA3_CHECK_ARG(logits && targets && sums4 && dlogits && n_masks > 0 && hw > 0, "bce_dice_grad: bad args");
     hipLaunchKernelGGL(bce_dice_grad_kernel, dim3(gd(n_masks * hw)), dim3(256), 0, (hipStream_t)stream, logits, targets, sums4, dlogits, (long)n_masks,
-                       (long)hw, coef_bce, coef_dice);
+                       (long)hw, coef_bce, coef_dice, (const float*)nullptr, (const float*)nullptr);
     RGA3_CHECK_LAUNCH("bce_dice_grad");
+    return 0;
+}
+
+extern "C" int rga3_bce_dice_grad_dev(const float* logits, const float* targets, const float* sums4, float* dlogits, int64_t n_masks, int64_t hw,
+                                      const float* coef_bce_dev, const float* coef_dice_dev, void* stream) {
+    RGA3_CHECK_ARG(logits && targets && sums4 && dlogits && coef_bce_dev && coef_dice_dev && n_masks > 0 && hw > 0, "bce_dice_grad_dev: bad args");
+    hipLaunchKernelGGL(bce_dice_grad_kernel, dim3(gd(n_masks * hw)), dim3(256), 0, (hipStream_t)stream, logits, targets, sums4, dlogits, (long)n_masks,
+                       (long)hw, 1.f, 1.f, coef_bce_dev, coef_dice_dev);
+    RGA3_CHECK_LAUNCH("bce_dice_grad_dev");
     return 0;
 }

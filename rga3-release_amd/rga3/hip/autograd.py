@@ -167,7 +167,7 @@ class MaskLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gb, gd):
         pred, target, s = ctx.saved_tensors
-        return ops.bce_dice_grad(pred, target, s, float(gb), float(gd)), None
+        return ops.bce_dice_grad(pred, target, s, gb, gd), None   # gb / gd stay on the device
 
 
 class GatherRowsFn(torch.autograd.Function):

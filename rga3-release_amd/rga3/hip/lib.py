@@ -68,6 +68,7 @@ SIGNATURES = {
     "rga3_bilinear_bwd": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "rga3_pixel_shuffle2x_bwd": [_p, _p, _i64, _i, _i, _i, _p],
     "rga3_bce_dice_grad": [_p, _p, _p, _p, _i64, _i64, _f, _f, _p],
+    "rga3_bce_dice_grad_dev": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p],
 }
 
 _lib = None

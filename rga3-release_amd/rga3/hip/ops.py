@@ -614,10 +614,16 @@ def pixel_shuffle2x_bwd(dout, F: int, H: int, W: int):
     return dg
 
 
-def bce_dice_grad(logits, targets, sums, coef_bce: float, coef_dice: float):
+def bce_dice_grad(logits, targets, sums, coef_bce, coef_dice):
+    """coef_*: python floats, or f32 device scalars (the upstream gradients as autograd delivers them: read on the device, no host sync)."""
     _need_cuda(logits, targets, sums)
     assert logits.dtype == targets.dtype == sums.dtype == torch.float32 and logits.is_contiguous() and targets.is_contiguous()
     d = torch.empty_like(logits)
+    if isinstance(coef_bce, torch.Tensor):
+        cb, cd = coef_bce.reshape(1).float().contiguous(), coef_dice.reshape(1).float().contiguous()
+        _lib.check(_lib.load().rga3_bce_dice_grad_dev(logits.data_ptr(), targets.data_ptr(), sums.data_ptr(), d.data_ptr(), logits.shape[0], logits[0].numel(),
+                                                      cb.data_ptr(), cd.data_ptr(), _stream()), "bce_dice_grad_dev")
+        return d
     _lib.check(_lib.load().rga3_bce_dice_grad(logits.data_ptr(), targets.data_ptr(), sums.data_ptr(), d.data_ptr(), logits.shape[0], logits[0].numel(),
                                               float(coef_bce), float(coef_dice), _stream()), "bce_dice_grad")
     return d

@@ -567,42 +567,52 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         return self.model.embed_tokens
 
     # -- multimodal embedding assembly ---------------------------------------------------------------------
-    def _embed(self, ids_packed_np, ids_packed_dev, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw):
+    def _embed(self, pl, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw):
+        """embed_tokens rows + vision features written over the placeholder rows (HF masked_scatter, modeling_qwen2_5_vl.py:1206-1223).  The index tensors
+        live in the host plan `pl` (built once per distinct input: every host -> device copy of an index array is a stream sync)."""
         w = self.model.embed_tokens.weight
         c = self.config
+        ids_packed_np, ids_packed_dev = pl["ids_packed_np"], pl["ids_packed"]
         if torch.is_grad_enabled() and w.requires_grad:
             from .qwen_train import EmbedFn
-            text_rows = np.flatnonzero((ids_packed_np != c.image_token_id) & (ids_packed_np != c.video_token_id))
-            x = EmbedFn.apply(w, ids_packed_dev, ids_packed_np, text_rows)
+            if "text_rows" not in pl:
+                pl["text_rows"] = np.flatnonzero((ids_packed_np != c.image_token_id) & (ids_packed_np != c.video_token_id))
+            x = EmbedFn.apply(w, ids_packed_dev, ids_packed_np, pl["text_rows"], pl)
         else:
             x = ops.gather_rows(w, ids_packed_dev)
         for px, grid, tok in ((pixel_values, image_grid_thw, c.image_token_id), (pixel_values_videos, video_grid_thw, c.video_token_id)):
             if px is None:
                 continue
             emb = self.visual(px, _np(grid))
-            where = np.flatnonzero(ids_packed_np == tok)
-            if where.size != emb.shape[0]:
-                raise ValueError(f"vision features and placeholder tokens do not match: tokens {where.size}, features {emb.shape[0]}")
-            ops.scatter_rows_(x, torch.from_numpy(where).to(x.device), emb)
+            key = ("where", tok)
+            if key not in pl:
+                where = np.flatnonzero(ids_packed_np == tok)
+                pl[key] = (where.size, torch.from_numpy(where).to(x.device))
+            n_where, where_dev = pl[key]
+            if n_where != emb.shape[0]:
+                raise ValueError(f"vision features and placeholder tokens do not match: tokens {n_where}, features {emb.shape[0]}")
+            ops.scatter_rows_(x, where_dev, emb)
         return x
 
-    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
-                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, pixel_values=None,
-                pixel_values_videos=None, image_grid_thw=None, video_grid_thw=None, rope_deltas=None, cache_position=None,
-                second_per_grid_ts=None, **kwargs):
+    def _host_plan(self, input_ids, attention_mask, position_ids, labels, image_grid_thw, video_grid_thw, second_per_grid_ts, past_len, dev):
+        """Everything the forward derives ON THE HOST from the integer inputs (token ids, masks, labels, grids): mRoPE position ids, the packing of valid
+        tokens, cu_seqlens, and their device copies.  Reading device tensors back is a device -> host sync that stops the host running ahead of the
+        GPU; the plan of the last call is therefore kept and reused when the SAME tensor objects come back unmodified (same Python objects, same
+        autograd version counters: an evaluation loop over a fixed clip, gradient-accumulation micro-steps, benchmark steps).  New tensors -> new plan."""
         c = self.config
-        if inputs_embeds is not None:
-            raise NotImplementedError("inputs_embeds entry is not part of the RGA3 hot path")
-        dev = self.device
+        tens = (input_ids, attention_mask, position_ids, labels, image_grid_thw, video_grid_thw, second_per_grid_ts)
+        sig = tuple((id(t), t._version, tuple(t.shape)) if isinstance(t, torch.Tensor) else (None if t is None else repr(t)) for t in tens) + (past_len, str(dev), c.mrope_temporal_rule)
+        hit = self.__dict__.get("_plan_cache")
+        if hit is not None and hit[0] == sig and all((r() is t) if r is not None else True for r, t in zip(hit[1], tens)):
+            return hit[2]
         ids_np = input_ids.detach().cpu().numpy()
         B, S = ids_np.shape
-        cache = past_key_values if isinstance(past_key_values, KVCache) else None
-        past_len = cache.get_seq_length() if cache is not None else 0
         if attention_mask is not None:
             am_np = attention_mask.detach().cpu().numpy().astype(bool)
         else:
             am_np = np.ones((B, S + past_len), dtype=bool)
         am_cur = am_np[:, -S:]
+        rope_deltas = None
         # ---- 3-axis positions
         if position_ids is None:
             if past_len == 0:
@@ -610,7 +620,7 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
                                                c.vision_config.tokens_per_second, _np(image_grid_thw), _np(video_grid_thw),
                                                _np(second_per_grid_ts), am_cur if attention_mask is not None else None,
                                                c.mrope_temporal_rule)
-                self.rope_deltas = torch.from_numpy(deltas).to(dev)
+                rope_deltas = torch.from_numpy(deltas).to(dev)
             else:  # decode step: 1-D positions shifted by the prefill's rope delta (modeling_qwen2_5_vl.py:1160-1172)
                 base = am_np.cumsum(-1)[:, -S:] - 1
                 d = self.rope_deltas.cpu().numpy() if self.rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
@@ -627,12 +637,35 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         ids_packed = input_ids.reshape(-1)[keep_dev] if input_ids.is_cuda else torch.from_numpy(ids_packed_np).to(dev)
         pos3 = torch.from_numpy(pos_np.reshape(3, -1)[:, flat_keep]).to(dev)
         cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
-        x = self._embed(ids_packed_np, ids_packed, pixel_values if past_len == 0 else None, image_grid_thw,
-                        pixel_values_videos if past_len == 0 else None, video_grid_thw)
+        plan = dict(ids_np=ids_np, am_cur=am_cur, lens=lens, flat_keep=flat_keep, ids_packed_np=ids_packed_np, keep_dev=keep_dev, ids_packed=ids_packed,
+                    pos3=pos3, cu=cu, rope_deltas=rope_deltas, labels_np=None if labels is None else labels.detach().cpu().numpy())
+        if past_len == 0:   # decode steps change every call: not worth keeping
+            import weakref
+            self.__dict__["_plan_cache"] = (sig, tuple(weakref.ref(t) if isinstance(t, torch.Tensor) else None for t in tens), plan)
+        return plan
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, pixel_values=None,
+                pixel_values_videos=None, image_grid_thw=None, video_grid_thw=None, rope_deltas=None, cache_position=None,
+                second_per_grid_ts=None, **kwargs):
+        c = self.config
+        if inputs_embeds is not None:
+            raise NotImplementedError("inputs_embeds entry is not part of the RGA3 hot path")
+        dev = self.device
+        cache = past_key_values if isinstance(past_key_values, KVCache) else None
+        past_len = cache.get_seq_length() if cache is not None else 0
+        pl = self._host_plan(input_ids, attention_mask, position_ids, labels, image_grid_thw, video_grid_thw, second_per_grid_ts, past_len, dev)
+        ids_np, am_cur, lens, flat_keep, ids_packed_np = pl["ids_np"], pl["am_cur"], pl["lens"], pl["flat_keep"], pl["ids_packed_np"]
+        keep_dev, ids_packed, pos3, cu = pl["keep_dev"], pl["ids_packed"], pl["pos3"], pl["cu"]
+        B, S = ids_np.shape
+        if pl["rope_deltas"] is not None:
+            self.rope_deltas = pl["rope_deltas"]
+        x = self._embed(pl, pixel_values if past_len == 0 else None, image_grid_thw, pixel_values_videos if past_len == 0 else None, video_grid_thw)
+        self.__dict__["_last_plan"] = pl
         trainable = torch.is_grad_enabled() and labels is not None and cache is None and any(p.requires_grad for p in self.parameters())
         if trainable:
             from .qwen_train import lm_train_forward
-            loss, hn = lm_train_forward(self, x, pos3, cu, int(lens.max()), labels.detach().cpu().numpy(), am_cur, flat_keep, lens)
+            loss, hn = lm_train_forward(self, x, pos3, cu, int(lens.max()), pl["labels_np"], am_cur, flat_keep, lens, plan=pl)
             if flat_keep.size == B * S:
                 full = hn
             else:
@@ -655,19 +688,21 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
 
         loss = None
         if labels is not None:
-            loss = self._shifted_ce(logits_p, labels, am_cur, flat_keep, lens)
+            loss = self._shifted_ce(logits_p, pl["labels_np"], am_cur, flat_keep, lens, pl)
         return CausalLMOutput(loss=loss, logits=unpack(logits_p), past_key_values=cache,
                               hidden_states=tuple(unpack(t) for t in hs) if hs is not None else None, rope_deltas=self.rope_deltas)
 
-    def _shifted_ce(self, logits_p, labels, am_cur, flat_keep, lens):
+    def _shifted_ce(self, logits_p, labels, am_cur, flat_keep, lens, pl=None):
         """Mean CE of token t's logits against label t+1 over labels != -100 (HF ForCausalLMLoss)."""
-        lab = labels.detach().cpu().numpy()
-        B, S = lab.shape
-        nxt = np.full((B, S), -100, dtype=np.int64)
-        nxt[:, :-1] = lab[:, 1:]
-        tgt = torch.from_numpy(nxt.reshape(-1)[flat_keep]).to(logits_p.device)
+        pl = pl if pl is not None else {}
+        if "ce_targets" not in pl:
+            lab = labels if isinstance(labels, np.ndarray) else labels.detach().cpu().numpy()
+            B, S = lab.shape
+            nxt = np.full((B, S), -100, dtype=np.int64)
+            nxt[:, :-1] = lab[:, 1:]
+            pl["ce_targets"] = (torch.from_numpy(nxt.reshape(-1)[flat_keep]).to(logits_p.device), int((nxt.reshape(-1)[flat_keep] != -100).sum()))
+        tgt, n = pl["ce_targets"]
         row_loss = ops.cross_entropy_rows(logits_p, tgt)
-        n = int((nxt.reshape(-1)[flat_keep] != -100).sum())
         return row_loss.sum() / max(n, 1)
 
     # -- generation (greedy / sampling) --------------------------------------------------------------------

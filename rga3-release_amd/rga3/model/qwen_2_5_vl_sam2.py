@@ -131,14 +131,17 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
         return self.model_forward(**kwargs)
 
     # ---- helpers ------------------------------------------------------------------------------------------
-    def _seg_embeddings(self, hidden_last: torch.Tensor, seg_token_mask_np: np.ndarray):
+    def _seg_embeddings(self, hidden_last: torch.Tensor, seg_token_mask_np: np.ndarray, pl=None):
         """text_hidden_fcs on the gathered rows (value-identical to MLP-then-gather, reference :215-218)."""
         B, S, H = hidden_last.shape
         where = np.flatnonzero(seg_token_mask_np.reshape(-1))
         counts = seg_token_mask_np.sum(-1).astype(np.int64)
         if where.size == 0:
             return torch.zeros((0, self.config.out_dim), dtype=hidden_last.dtype, device=hidden_last.device), counts
-        idx = torch.from_numpy(where).to(hidden_last.device)
+        pl = pl if pl is not None else {}
+        if "seg_rows" not in pl:
+            pl["seg_rows"] = torch.from_numpy(where).to(hidden_last.device)
+        idx = pl["seg_rows"]
         fc = self.text_hidden_fcs[0]
         if torch.is_grad_enabled():
             rows = AG.GatherRowsFn.apply(hidden_last.reshape(B * S, H), idx)
@@ -166,8 +169,10 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
                                  output_hidden_states=True, pixel_values=pixel_values, pixel_values_videos=pixel_values_videos,
                                  image_grid_thw=image_grid_thw, video_grid_thw=video_grid_thw, second_per_grid_ts=second_per_grid_ts)
         ce_loss = output.loss * self.config.ce_loss_weight
-        seg_mask = self._shifted_seg_mask(labels.detach().cpu().numpy(), self.config.seg_token_idx)
-        pred_embeddings, counts = self._seg_embeddings(output.hidden_states[-1], seg_mask)
+        pl = self.__dict__.get("_last_plan") or {}   # host plan of the forward just run: holds the labels' host copy (no second device -> host read)
+        labels_np = pl["labels_np"] if pl.get("labels_np") is not None else labels.detach().cpu().numpy()
+        seg_mask = self._shifted_seg_mask(labels_np, self.config.seg_token_idx)
+        pred_embeddings, counts = self._seg_embeddings(output.hidden_states[-1], seg_mask, pl)
         seg_token_offset = np.concatenate([[0], np.cumsum(counts)])[np.asarray(offset.detach().cpu() if isinstance(offset, torch.Tensor) else offset)]
         gm = self.grounding_encoder
         out_dim = self.config.out_dim
@@ -189,7 +194,7 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
                 pred_masks.append(masks > 0)  # sigmoid(x) > 0.5
             return {"pred_masks": pred_masks, "gt_masks": masks_list}
 
-        has_seg = counts[np.asarray(offset[:-1].cpu() if isinstance(offset, torch.Tensor) else offset[:-1])] > 0 if False else (np.diff(seg_token_offset) > 0)
+        has_seg = np.diff(seg_token_offset) > 0
         mask_bce_loss = torch.zeros((), device=device)
         mask_dice_loss = torch.zeros((), device=device)
         num_masks = 0

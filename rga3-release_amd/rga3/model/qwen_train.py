@@ -332,32 +332,37 @@ class EmbedFn(torch.autograd.Function):
     built, and data-parallel ranks exchange <= S rows each; otherwise the dense table gradient is returned to autograd."""
 
     @staticmethod
-    def forward(ctx, weight, ids_dev, ids_np, grad_rows_np):
+    def forward(ctx, weight, ids_dev, ids_np, grad_rows_np, plan=None):
         from ..parallel.ddp import sparse_sink_for
 
-        ctx.ids_np, ctx.grad_rows_np, ctx.shape = ids_np, grad_rows_np, weight.shape
+        ctx.shape = weight.shape
         ctx.sink = sparse_sink_for(weight)
         ctx.weight = weight
+        plan = plan if plan is not None else {}
+        if "embed_bwd" not in plan:     # CSR of duplicate ids, built (and uploaded) once per distinct input: host -> device copies are stream syncs
+            rows = grad_rows_np                          # packed positions whose embedding came from the table (not vision placeholders)
+            ids = ids_np[rows]
+            order = np.argsort(ids, kind="stable")
+            uniq, counts = np.unique(ids[order], return_counts=True)
+            off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            dev = weight.device
+            plan["embed_bwd"] = (torch.from_numpy(rows[order].astype(np.int64)).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(uniq.astype(np.int64)).to(dev),
+                                 uniq.astype(np.int64))
+        ctx.csr = plan["embed_bwd"]
         if ctx.sink is not None:
-            ctx.sink.announce_sparse(weight, np.unique(ids_np[grad_rows_np]).astype(np.int64))
+            ctx.sink.announce_sparse(weight, ctx.csr[3])
         return ops.gather_rows(weight, ids_dev)
 
     @staticmethod
     def backward(ctx, dx):
-        rows = ctx.grad_rows_np                      # packed positions whose embedding came from the table (not vision placeholders)
-        ids = ctx.ids_np[rows]
-        order = np.argsort(ids, kind="stable")
-        uniq, counts = np.unique(ids[order], return_counts=True)
-        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        dev = dx.device
-        seg = ops.segment_sum_rows(dx.contiguous(), torch.from_numpy(rows[order].astype(np.int64)).to(dev), torch.from_numpy(off).to(dev))
-        uniq_dev = torch.from_numpy(uniq.astype(np.int64)).to(dev)
+        rows_dev, off_dev, uniq_dev, _ = ctx.csr
+        seg = ops.segment_sum_rows(dx.contiguous(), rows_dev, off_dev)
         if ctx.sink is not None:
             ctx.sink.add_sparse(ctx.weight, uniq_dev, seg)
-            return None, None, None, None
-        dW = torch.zeros(ctx.shape, dtype=dx.dtype, device=dev)
+            return None, None, None, None, None
+        dW = torch.zeros(ctx.shape, dtype=dx.dtype, device=dx.device)
         ops.scatter_rows_(dW, uniq_dev, seg)
-        return dW, None, None, None
+        return dW, None, None, None, None
 
 
 class NormHeadCEFn(torch.autograd.Function):
@@ -389,8 +394,7 @@ class NormHeadCEFn(torch.autograd.Function):
         h, lm_w, norm_w, hv, dlogits, rows = ctx.saved_tensors
         n = ctx.n
         with torch.no_grad():
-            if float(gloss) != 1.0:
-                dlogits = (dlogits.float() * float(gloss)).to(dlogits.dtype)
+            dlogits = (dlogits.float() * gloss).to(dlogits.dtype)   # upstream gradient applied on the device ([labelled rows, V]: a few rows); no host read
             dW = ops.gemm_tn(dlogits, hv) if lm_w.requires_grad else None    # [V, H] = dlogits^T hv
             dhv = ops.gemm(dlogits, ops.transpose(lm_w.detach()))            # [n, H]
             dhn = ghn.contiguous().clone() if ghn is not None else torch.zeros_like(h)   # gradient arriving through hidden_states[-1]
@@ -400,7 +404,7 @@ class NormHeadCEFn(torch.autograd.Function):
         return dh, dW, None, None, None, None, None
 
 
-def lm_train_forward(model, x, pos3, cu, max_len, labels_np, am_cur, flat_keep, lens):
+def lm_train_forward(model, x, pos3, cu, max_len, labels_np, am_cur, flat_keep, lens, plan=None):
     """Decoder + LM head + CE with autograd nodes; x [T, H] packed embeddings (requires_grad if embed_tokens is trainable)."""
     tm = model.model
     cos, sin = tm.mrope_tables(pos3)
@@ -411,12 +415,15 @@ def lm_train_forward(model, x, pos3, cu, max_len, labels_np, am_cur, flat_keep, 
         seeds = (next_dropout_seed(li, 0), next_dropout_seed(li, 1, advance=False)) if (pq > 0.0 or pv > 0.0) else None
         x = DecoderLayerFn.apply(x, lq[0] if lq else None, lq[1] if lq else None, lv[0] if lv else None, lv[1] if lv else None, layer, cos, sin,
                                  cu, max_len, seeds)
-    B, S = labels_np.shape
-    nxt = np.full((B, S), -100, dtype=np.int64)
-    nxt[:, :-1] = labels_np[:, 1:]
-    tgt = nxt.reshape(-1)[flat_keep]
-    valid = np.flatnonzero(tgt != -100)
-    dev = x.device
-    loss, hn = NormHeadCEFn.apply(x, model.lm_head.weight, tm.norm.weight, tm.norm.variance_epsilon, torch.from_numpy(valid.astype(np.int64)).to(dev),
-                                  torch.from_numpy(tgt[valid]).to(dev), int(valid.size))
+    plan = plan if plan is not None else {}
+    if "train_targets" not in plan:     # labelled rows and their targets, uploaded once per distinct input
+        B, S = labels_np.shape
+        nxt = np.full((B, S), -100, dtype=np.int64)
+        nxt[:, :-1] = labels_np[:, 1:]
+        tgt = nxt.reshape(-1)[flat_keep]
+        valid = np.flatnonzero(tgt != -100)
+        dev = x.device
+        plan["train_targets"] = (torch.from_numpy(valid.astype(np.int64)).to(dev), torch.from_numpy(tgt[valid]).to(dev), int(valid.size))
+    valid_dev, tgt_dev, n_valid = plan["train_targets"]
+    loss, hn = NormHeadCEFn.apply(x, model.lm_head.weight, tm.norm.weight, tm.norm.variance_epsilon, valid_dev, tgt_dev, n_valid)
     return loss, hn

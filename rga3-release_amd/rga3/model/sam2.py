@@ -30,6 +30,9 @@ from ..hip import ops
 from .qwen2_5_vl import Linear
 
 
+_DEBUG = None   # set to a dict by tools/grad_locate.py (diagnostic)
+
+
 def _ag():
     """Record autograd nodes (training of the mask decoder / text_hidden_fcs) instead of the fused inference kernels."""
     return torch.is_grad_enabled()
@@ -466,6 +469,11 @@ class MaskDecoder(nn.Module):
             up = AG.GeluFn.apply(AG.PixelShuffleFn.apply(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w))
             hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)
             masks = torch.stack([AG.linear(hyper[b].contiguous(), up[b * npx:(b + 1) * npx], out_f32=True).view(4, 4 * h, 4 * w) for b in range(B)], dim=0)
+            if _DEBUG is not None:   # tools/grad_locate.py: keep the gradients of the head's intermediates
+                _DEBUG.update(hs=hs, src=src, up=up, hyper=hyper, masks=masks, tokens=tokens)
+                for t_ in (hs, src, up, hyper, masks, tokens):
+                    if t_.requires_grad:
+                        t_.retain_grad()
         else:
             g1 = ops.gemm(src, dc1.as_linear())
             up = ops.pixel_shuffle2x(g1, dc1.bias, feat_s1, B, h, w)

@@ -95,3 +95,68 @@ def test_frame_sampling_matches_reference_tables():
         nm, ns = row[:2]
         assert D.get_dense_indices(nm, ns) == row[2:2 + ns], (nm, ns)
     assert len(D.get_sparse_indices(3, 8)) == 8 and set(D.get_sparse_indices(3, 8)) == {0, 1, 2}
+
+
+def test_stom_mask_shape_branch():
+    """reference STOM.py:163-207 restated without cv2: the structuring elements equal OpenCV's documented 3x3 / 5x5 ellipses; closing bridges gaps
+    narrower than the element and leaves isolated far points apart; the filled circle is the midpoint raster (extent exactly r on both axes,
+    symmetric); warp_point draws it at the centroid of the closed point cloud in the prompt's colour with alpha clamped to [96, 148]."""
+    assert ST.ellipse_kernel(3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert ST.ellipse_kernel(5).tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+    rng0 = np.random.default_rng(3)
+    for k in (5, 6):                       # odd and even elements (even ones are not symmetric about the anchor: OpenCV applies them as they are)
+        m = np.zeros((24, 31), np.uint8)
+        m[rng0.integers(0, 24, 40), rng0.integers(0, 31, 40)] = 255
+        m[10:14, 12] = 255
+        ker = ST.ellipse_kernel(k)
+        a = k // 2
+        offs = [(i - a, j - a) for i in range(k) for j in range(k) if ker[i, j]]
+        inside = lambda y, x: 0 <= y < 24 and 0 <= x < 31
+        dil = np.zeros_like(m)
+        for y in range(24):
+            for x in range(31):
+                dil[y, x] = max([m[y + dy, x + dx] for dy, dx in offs if inside(y + dy, x + dx)] or [0])
+        clo = np.zeros_like(m)
+        for y in range(24):
+            for x in range(31):
+                clo[y, x] = min([dil[y + dy, x + dx] for dy, dx in offs if inside(y + dy, x + dx)] or [255])
+        assert np.array_equal(ST.morph_close(m, k), clo), k
+        if k % 2:
+            assert (ST.morph_close(m, k) >= m).all()       # closing is extensive for an element symmetric about its anchor
+    circ = ST.filled_circle((50, 50), 25, 20, 7)
+    assert circ[20, 18:33].min() == 255 and circ[20, 17] == 0 and circ[20, 33] == 0 and circ[13, 25] == 255 and circ[12, 25] == 0 and circ[27, 25] == 255 and circ[28, 25] == 0
+    assert np.array_equal(circ[:, 18:33], circ[:, 18:33][:, ::-1])
+    assert np.array_equal(circ[13:28], circ[13:28][::-1])
+    clipped = ST.filled_circle((30, 30), 2, 3, 6)            # partly outside: same raster, cut at the border
+    full = ST.filled_circle((60, 60), 32, 33, 6)
+    assert np.array_equal(clipped, full[30:60, 30:60])
+    # warp_point: 40 points around (row 30, col 45) in a 60 x 90 frame
+    rng = np.random.default_rng(0)
+    h, w = 60, 90
+    src = np.zeros((h, w, 4), np.uint8)
+    src[10:20, 10:20] = (200, 30, 40, 255)
+    tgt = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+    pts = np.stack([45 + rng.integers(-2, 3, 40), 30 + rng.integers(-2, 3, 40)], 1).astype(np.float32)   # (col, row) as the tracker returns them
+    vis = np.ones(40, bool)
+    out = ST.warp_point(src, tgt, pts, vis)
+    k, r = min(h, w) // 15, min(h, w) // 20
+    closed = ST.morph_close(np.where(np.isin(np.arange(h * w).reshape(h, w), (pts[:, 1].astype(int) * w + pts[:, 0].astype(int))), 255, 0).astype(np.uint8), k)
+    ys, xs = np.nonzero(closed)
+    cx, cy = int(xs.mean()), int(ys.mean())
+    disk = ST.filled_circle((h, w), cx, cy, r) > 0
+    assert np.array_equal(out[~disk], tgt[~disk])
+    a = 148 / 255.0
+    exp = np.array(Image_alpha(tgt, disk, (200, 30, 40, 148)))
+    assert np.array_equal(out, exp)
+    assert np.array_equal(ST.warp_point(src, tgt, pts, np.arange(40) < 10), tgt)      # fewer than half visible: frame untouched
+    frames = [tgt, tgt.copy(), tgt.copy()]
+    tracks = np.broadcast_to(pts[None, None], (1, 3, 40, 2)).copy()
+    res = ST.STOM().propagate_in_video(frames, src, 0, shape="mask", tracks=tracks, visibility=np.ones((1, 3, 40), bool))
+    assert len(res) == 3 and np.array_equal(res[1], out) and np.array_equal(res[2], out)
+
+
+def Image_alpha(tgt, disk, rgba):
+    from PIL import Image
+    ov = np.zeros(tgt.shape[:2] + (4,), np.uint8)
+    ov[disk] = rgba
+    return Image.alpha_composite(Image.fromarray(tgt, "RGB").convert("RGBA"), Image.fromarray(ov, "RGBA")).convert("RGB")
