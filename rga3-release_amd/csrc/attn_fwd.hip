@@ -403,6 +403,10 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     return launch_attn_p<DP, QT, NWAVE, USE_TR, false>(a, nseg, nqb, st);
 }
 
+int attn_fwd32_try(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
+                   int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st,
+                   int64_t o_sh, float scale, int causal, const float* rope_cos, const float* rope_sin, void* stream);   // attn_fwd32.hip
+
 static int g_attn_variant = 0;  // 0: auto, 1: force 4 waves x QT=2, 2: force 8 waves x QT=1 (benchmark switch, read-only after init)
 
 template <int DP, bool USE_TR>
@@ -454,7 +458,15 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
-    RGA3_CHECK_ARG(impl >= 0 && impl <= 3, "attn: impl %d", impl);
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 7, "attn: impl %d", impl);
+    // second-generation kernel (one wave per SIMD, 32 query rows per wave, 32x32x16 MFMA: attn_fwd32.hip) for long segments with head dims <= 128;
+    // impl bit 2 keeps the first-generation kernel (A/B), split-KV and block-diagonal calls always use it
+    if (!(impl & 4) && !(impl & 1) && !split_ws && block_q == 0 && D <= 128 && max_q >= 128 &&
+        (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && o_st % 4 == 0 && o_sh % 4 == 0 && k_st < (1 << 24) && v_st < (1 << 24)) {
+        const int rc = attn_fwd32_try(q, k, v, o, lse, cu_q, cu_k, nseg, max_q, total_q, Hq, Hkv, D, q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh, scale, causal,
+                                      nullptr, nullptr, stream);
+        if (rc <= 0) return rc;
+    }
     g_attn_variant = (impl & 2) ? 1 : 0;
     impl &= 1;
     AttnArgs a;
@@ -487,4 +499,22 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     hipStream_t st = (hipStream_t)stream;
     if (impl == 0) return launch_any<true>(a, nseg, max_q, st);
     return launch_any<false>(a, nseg, max_q, st);
+}
+
+extern "C" int rga3_attn_fwd_rope_q(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q, const int32_t* cu_k, int nseg,
+                                    int max_q, int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st,
+                                    int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal, const float* rope_cos, const float* rope_sin,
+                                    void* stream) {
+    RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k && rope_cos && rope_sin, "attn_fwd_rope_q: null pointer");
+    RGA3_CHECK_ARG(nseg > 0 && nseg <= 65535 && max_q >= 128 && total_q > 0, "attn_fwd_rope_q: nseg=%d max_q=%d (segments of >= 128 queries only)", nseg, max_q);
+    RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq <= 65535 && D >= 16 && D <= 128 && D % 16 == 0, "attn_fwd_rope_q: Hq=%d Hkv=%d D=%d", Hq, Hkv, D);
+    RGA3_CHECK_ARG(q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0 && o_st % 4 == 0 && o_sh % 4 == 0,
+                   "attn_fwd_rope_q: strides");
+    RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)rope_cos | (uintptr_t)rope_sin) & 15) == 0 && (((uintptr_t)o) & 7) == 0,
+                   "attn_fwd_rope_q: pointer alignment");
+    RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn_fwd_rope_q: k/v row stride too large");
+    const int rc = attn_fwd32_try(q, k, v, o, lse, cu_q, cu_k, nseg, max_q, total_q, Hq, Hkv, D, q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh, scale, causal,
+                                  rope_cos, rope_sin, stream);
+    if (rc > 0) return fail(RGA3_EINVAL, "attn_fwd_rope_q: shape not covered by the 32-row kernel");
+    return rc;
 }

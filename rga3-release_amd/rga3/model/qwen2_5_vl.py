@@ -250,8 +250,12 @@ class VisionAttention(nn.Module):
         N = h.shape[0]
         H, D = self.num_heads, self.head_dim
         qkv = self.qkv(h).view(N, 3 * H, D)
-        ops.rope_(qkv, cos, sin, 0, 2 * H)  # q heads then k heads are contiguous in the fused buffer
-        att = ops.attn_varlen(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, causal=False)
+        if ops.attn_rope_q_ok(max_len, D):    # long segments (the full-attention blocks): the attention kernel rotates Q as it loads it, only K takes the rope pass
+            ops.rope_(qkv, cos, sin, H, H)
+            att = ops.attn_varlen_rope_q(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False)
+        else:
+            ops.rope_(qkv, cos, sin, 0, 2 * H)  # q heads then k heads are contiguous in the fused buffer
+            att = ops.attn_varlen(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, causal=False)
         return self.proj(att.view(N, H * D), residual=residual)
 
 
@@ -373,13 +377,17 @@ class DecoderAttention(nn.Module):
             qkv = qkv_with_lora(self, h, seeds=getattr(self, "_lora_drop_seeds", None))[0].view(T, Hq + 2 * Hk, D)
         else:  # foreign wrappers (e.g. PEFT): honour them, then assemble the fused buffer
             qkv = torch.cat([self.q_proj(h), self.k_proj(h), self.v_proj(h)], dim=-1).view(T, Hq + 2 * Hk, D)
-        ops.rope_(qkv, cos, sin, 0, Hq + Hk)
+        fuse_q = ops.attn_rope_q_ok(max_len, D)     # prefill / forward: Q is rotated inside the attention kernel, the rope pass only touches the K heads
+        ops.rope_(qkv, cos, sin, Hq if fuse_q else 0, Hk if fuse_q else Hq + Hk)
         q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
         cu_k = cu
         if cache is not None:
             k, v, cu_k = cache.update(self.layer_idx, k, v, cu)
         # decode step (one query per sequence): every cached key is visible, and the non-causal form may split the key range over workgroups
-        att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
+        if fuse_q:
+            att = ops.attn_varlen_rope_q(q, k, v, cu, cu_k, max_len, D ** -0.5, cos, sin, causal=True)
+        else:
+            att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
         return self.o_proj(att.view(T, Hq * D), residual=residual)
 
 

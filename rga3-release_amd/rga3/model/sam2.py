@@ -743,6 +743,9 @@ class SAM2VideoPredictor(nn.Module):
         low = masks.reshape(B * 4, 4 * h, 4 * w)[sel.long()].unsqueeze(1)                               # chosen candidate, f32
         if _ag():
             high = AG.BilinearFn.apply(masks.reshape(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
+            if _DEBUG is not None:
+                high.retain_grad()
+                _DEBUG["high"] = high
         else:
             high = ops.bilinear(masks.view(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
         tok = toks[:, 1:][bi, best]

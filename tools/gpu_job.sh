@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 600 python tools/grad_locate.py > gpurun_out/r2f_locate.log 2>&1
-tail -14 gpurun_out/r2f_locate.log | cut -c1-200
-rm -rf /tmp/tr; ( cd /tmp && RGA3_BENCH_TIMED_ONLY=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o fwd -- python3 "$GRAFT_REPO_ROOT/bench.py" --mode forward --steps 6 --warmup 3 --no-cpu-baseline ) > gpurun_out/r2f_trace.log 2>&1
-python3 tools/trace_gaps.py /tmp/tr --last-ms 130 > gpurun_out/r2f_gaps.txt 2>&1; head -40 gpurun_out/r2f_gaps.txt | cut -c1-200
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x -k "attn" 2>&1 | tail -15 | cut -c1-300 > gpurun_out/r2i_attn_tests.log; cat gpurun_out/r2i_attn_tests.log
+timeout 300 python tools/attn_rates.py > gpurun_out/r2i_attn_rates.log 2>&1; cat gpurun_out/r2i_attn_rates.log
+timeout 1500 python -m pytest tests/test_unigr_gpu.py tests/test_qwen_gpu.py tests/test_fullsize_parity_gpu.py tests/test_sam2_gpu.py -q -m gpu -s 2>&1 | grep -v "^$" > gpurun_out/r2i_tests.log
+grep -n "EMU_ERRS\|^E  \|FAILED\|passed\|failed" gpurun_out/r2i_tests.log | cut -c1-600 | tail -30

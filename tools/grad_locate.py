@@ -40,28 +40,19 @@ def main():
     Bh = ri["masks"].shape[0]
     print("oracle frames", Bh, "product masks", tuple(d["masks"].shape))
     sl = slice(0, T)     # frames of sample 0 (the only one with [SEG])
-    def cmp(name, got, ref):
-        print(f"{name:10s} value rel {rl(got.detach(), ref.detach()):.4f}   grad rel {rl(got.grad, ref.grad):.4f}   |grad| {float(ref.grad.float().norm()):.3e}")
+    def cmp(name, got, got_grad, ref, ref_grad):
+        print(f"{name:10s} value rel {rl(got.detach(), ref.detach()):.4f}   grad rel {rl(got_grad, ref_grad):.4f}   |grad| {float(ref_grad.float().norm()):.3e}", flush=True)
+
     h = ri["upscaled"].shape[2] // 4
-    cmp("masks", d["masks"], ri["masks"][sl])
-    cmp("hyper", d["hyper"], ri["hyper"][sl])
-    up_ref = ri["upscaled"]
-    got_up = d["up"]
-    class V:   # product [T*16hw, C/8] token-major -> [T, C/8, 4h, 4w]
-        pass
-    g = V(); g.grad = got_up.grad.float().view(T, 4 * h, 4 * h, -1).permute(0, 3, 1, 2)
-    gv = got_up.detach().float().view(T, 4 * h, 4 * h, -1).permute(0, 3, 1, 2)
-    r = V(); r.grad = up_ref.grad[sl]
-    print(f"{'up':10s} value rel {rl(gv, up_ref[sl].detach()):.4f}   grad rel {rl(g.grad, r.grad):.4f}   |grad| {float(r.grad.norm()):.3e}")
-    cmp("hs", d["hs"], ri["hs"][sl])
-    src_ref = ri["src"]       # [B, hw, C] in the oracle before the view? (two_way_transformer returns [B, hw, C])
-    sg = d["src"].grad.float().view(T, -1, d["src"].shape[-1])
-    sr = src_ref.grad[sl] if src_ref.grad is not None else None
-    if sr is not None:
-        sr = sr.reshape(T, sr.shape[1], -1) if sr.dim() == 3 else sr.flatten(2).transpose(1, 2)
-        print(f"{'src':10s} grad rel {rl(sg, sr):.4f}   |grad| {float(sr.norm()):.3e}")
-    tg = d["tokens"].grad.float().view(T, -1, d["tokens"].shape[-1])
-    print(f"{'tokens':10s} grad rel {rl(tg, ri['tokens'].grad[sl]):.4f}   |grad| {float(ri['tokens'].grad[sl].norm()):.3e}")
+    cmp("high", d["high"], d["high"].grad, ri["high"].reshape(-1, 1, 1024, 1024)[sl], ri["high"].grad.reshape(-1, 1, 1024, 1024)[sl])
+    cmp("masks", d["masks"], d["masks"].grad, ri["masks"][sl], ri["masks"].grad[sl])
+    cmp("hyper", d["hyper"], d["hyper"].grad, ri["hyper"][sl], ri["hyper"].grad[sl])
+    tok2map = lambda t: t.float().view(T, 4 * h, 4 * h, -1).permute(0, 3, 1, 2)     # product [T*16hw, C/8] token-major -> [T, C/8, 4h, 4w]
+    cmp("up", tok2map(d["up"].detach()), tok2map(d["up"].grad), ri["upscaled"][sl], ri["upscaled"].grad[sl])
+    cmp("hs", d["hs"], d["hs"].grad, ri["hs"][sl], ri["hs"].grad[sl])
+    s2t = lambda t: t.float().view(T, -1, t.shape[-1])
+    cmp("src", s2t(d["src"].detach()), s2t(d["src"].grad), ri["src"][sl].flatten(2).transpose(1, 2), ri["src"].grad[sl].flatten(2).transpose(1, 2))
+    cmp("tokens", s2t(d["tokens"].detach()), s2t(d["tokens"].grad), ri["tokens"][sl], ri["tokens"].grad[sl])
     for k in ("loss", "mask_bce_loss", "mask_dice_loss"):
         print(k, float(out[k]), float(ro[k]))
 
