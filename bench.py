@@ -491,6 +491,9 @@ def measure_forward(model_fwd, inputs, args, rank, refine=True):
         ch = tuner.refine(step, reps=int(rr), within=float(rw))
         if rank == 0 and ch:
             print("tuner.refine changed %d shape(s): %s" % (len(ch), {str(k[:3]): v for k, v in ch.items()}), file=sys.stderr)
+    if os.environ.get("RGA3_TUNE_SAVE") and rank == 0:
+        step()
+        tuner.save(os.environ["RGA3_TUNE_SAVE"])
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

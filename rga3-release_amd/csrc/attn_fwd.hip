@@ -40,7 +40,32 @@ struct AttnArgs {
     // block-diagonal visibility inside a segment (several tiny windows packed into one segment: Hiera's 4- and 16-token windows would
     // otherwise be one workgroup each): query i sees key j iff (i >> bq_shift) == (j >> bk_shift); -1 = off
     int bq_shift, bk_shift;
+    // RoPE applied while loading (rotate-half pairing d <-> d +- D/2, tables [tokens, D] f32 indexed by the packed token): q always when rope_cos is set,
+    // k too when rope_kcos is set (windowed ViT attention loads every key exactly once per head, so the stand-alone rope pass disappears altogether)
+    const float* rope_cos;
+    const float* rope_sin;
+    const float* rope_kcos;
+    const float* rope_ksin;
 };
+
+// x[0..7] (bf16x8 as u32x4) of row `row_ptr` at column d, rotated: x cos + rotate_half(x) sin in f32, one bf16 rounding (rope_kernel's arithmetic)
+__device__ __forceinline__ u32x4 rope_chunk(u32x4 z, const unsigned short* row_ptr, int d, int D, const float* cs, const float* sn) {
+    const int half = D >> 1;
+    const bool first = d < half;
+    const u32x4 zp = *(const u32x4*)(row_ptr + (first ? d + half : d - half));
+    const f32x4 c0 = *(const f32x4*)(cs + d), c1 = *(const f32x4*)(cs + d + 4), s0 = *(const f32x4*)(sn + d), s1 = *(const f32x4*)(sn + d + 4);
+    const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]}, ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    u32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = __uint_as_float(z[e] << 16), x1 = __uint_as_float(z[e] & 0xffff0000u);
+        const float p0 = __uint_as_float(zp[e] << 16), p1 = __uint_as_float(zp[e] & 0xffff0000u);
+        const float a0 = first ? x0 * cc[2 * e] - p0 * ss[2 * e] : x0 * cc[2 * e] + p0 * ss[2 * e];
+        const float a1 = first ? x1 * cc[2 * e + 1] - p1 * ss[2 * e + 1] : x1 * cc[2 * e + 1] + p1 * ss[2 * e + 1];
+        out[e] = pack_bf2(a0, a1);
+    }
+    return out;
+}
 
 constexpr int KV_TILE = 64;
 
@@ -99,7 +124,11 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
         for (int ds = 0; ds < DS; ++ds) {
             const int d = ds * 32 + g * 8;
             u32x4 z = {0u, 0u, 0u, 0u};
-            if (qi < Lq && d < p.D) z = *(const u32x4*)(p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh + d);
+            if (qi < Lq && d < p.D) {
+                const unsigned short* qrow = p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh;
+                z = *(const u32x4*)(qrow + d);
+                if (p.rope_cos) z = rope_chunk(z, qrow, d, p.D, p.rope_cos + (long)(qs + qi) * p.D, p.rope_sin + (long)(qs + qi) * p.D);
+            }
             qf[t][ds] = __builtin_bit_cast(bf16x8, z);
         }
     }
@@ -152,6 +181,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
             if ((EVEN || idx < KV_TILE * CH) && key < Lk && ch * 8 < p.D) {
                 zk = *(const u32x4*)(kt_k + koff0[i]);
                 zv = *(const u32x4*)(kt_v + voff0[i]);
+                if (p.rope_kcos) zk = rope_chunk(zk, kt_k + koff0[i] - ch * 8, ch * 8, p.D, p.rope_kcos + (long)(ks + key) * p.D, p.rope_ksin + (long)(ks + key) * p.D);
             }
             kreg[slot][i] = zk;
             vreg[slot][i] = zv;
@@ -403,10 +433,6 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     return launch_attn_p<DP, QT, NWAVE, USE_TR, false>(a, nseg, nqb, st);
 }
 
-int attn_fwd32_try(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
-                   int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st,
-                   int64_t o_sh, float scale, int causal, const float* rope_cos, const float* rope_sin, void* stream);   // attn_fwd32.hip
-
 static int g_attn_variant = 0;  // 0: auto, 1: force 4 waves x QT=2, 2: force 8 waves x QT=1 (benchmark switch, read-only after init)
 
 template <int DP, bool USE_TR>
@@ -458,15 +484,7 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
-    RGA3_CHECK_ARG(impl >= 0 && impl <= 7, "attn: impl %d", impl);
-    // second-generation kernel (one wave per SIMD, 32 query rows per wave, 32x32x16 MFMA: attn_fwd32.hip) for long segments with head dims <= 128;
-    // impl bit 2 keeps the first-generation kernel (A/B), split-KV and block-diagonal calls always use it
-    if (!(impl & 4) && !(impl & 1) && !split_ws && block_q == 0 && D <= 128 && max_q >= 128 &&
-        (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && o_st % 4 == 0 && o_sh % 4 == 0 && k_st < (1 << 24) && v_st < (1 << 24)) {
-        const int rc = attn_fwd32_try(q, k, v, o, lse, cu_q, cu_k, nseg, max_q, total_q, Hq, Hkv, D, q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh, scale, causal,
-                                      nullptr, nullptr, stream);
-        if (rc <= 0) return rc;
-    }
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 7, "attn: impl %d", impl);   // (bit 2 is accepted and ignored: it selected a since-removed experimental kernel)
     g_attn_variant = (impl & 2) ? 1 : 0;
     impl &= 1;
     AttnArgs a;
@@ -477,6 +495,7 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     a.total_q = total_q;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.causal = causal;
+    a.rope_cos = a.rope_sin = a.rope_kcos = a.rope_ksin = nullptr;
     // split the key range when the grid would leave most CUs idle: <= 8 slices, >= 8 key tiles each, workspace permitting
     RGA3_CHECK_ARG((block_q == 0) == (block_k == 0) && block_q >= 0 && (block_q & (block_q - 1)) == 0 && (block_k & (block_k - 1)) == 0,
                    "attn: block_q / block_k must both be 0 or powers of two (got %d, %d)", block_q, block_k);
@@ -501,20 +520,28 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     return launch_any<false>(a, nseg, max_q, st);
 }
 
-extern "C" int rga3_attn_fwd_rope_q(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q, const int32_t* cu_k, int nseg,
-                                    int max_q, int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st,
-                                    int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal, const float* rope_cos, const float* rope_sin,
-                                    void* stream) {
-    RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k && rope_cos && rope_sin, "attn_fwd_rope_q: null pointer");
-    RGA3_CHECK_ARG(nseg > 0 && nseg <= 65535 && max_q >= 128 && total_q > 0, "attn_fwd_rope_q: nseg=%d max_q=%d (segments of >= 128 queries only)", nseg, max_q);
-    RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq <= 65535 && D >= 16 && D <= 128 && D % 16 == 0, "attn_fwd_rope_q: Hq=%d Hkv=%d D=%d", Hq, Hkv, D);
+extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q, const int32_t* cu_k, int nseg,
+                                        int max_q, int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st,
+                                        int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal, const float* cos_q, const float* sin_q,
+                                        const float* cos_k, const float* sin_k, void* stream) {
+    RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k && cos_q && sin_q && ((cos_k == nullptr) == (sin_k == nullptr)), "attn_varlen_fwd_rope: null pointer");
+    RGA3_CHECK_ARG(nseg > 0 && nseg <= 65535 && max_q > 0 && total_q > 0, "attn_varlen_fwd_rope: nseg=%d max_q=%d", nseg, max_q);
+    RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq <= 65535 && D >= 16 && D <= 256 && D % 16 == 0, "attn_varlen_fwd_rope: Hq=%d Hkv=%d D=%d", Hq, Hkv, D);
     RGA3_CHECK_ARG(q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0 && o_st % 4 == 0 && o_sh % 4 == 0,
-                   "attn_fwd_rope_q: strides");
-    RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)rope_cos | (uintptr_t)rope_sin) & 15) == 0 && (((uintptr_t)o) & 7) == 0,
-                   "attn_fwd_rope_q: pointer alignment");
-    RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn_fwd_rope_q: k/v row stride too large");
-    const int rc = attn_fwd32_try(q, k, v, o, lse, cu_q, cu_k, nseg, max_q, total_q, Hq, Hkv, D, q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh, scale, causal,
-                                  rope_cos, rope_sin, stream);
-    if (rc > 0) return fail(RGA3_EINVAL, "attn_fwd_rope_q: shape not covered by the 32-row kernel");
-    return rc;
+                   "attn_varlen_fwd_rope: strides");
+    RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)cos_q | (uintptr_t)sin_q | (uintptr_t)cos_k | (uintptr_t)sin_k) & 15) == 0 &&
+                       (((uintptr_t)o) & 7) == 0, "attn_varlen_fwd_rope: pointer alignment");
+    RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn_varlen_fwd_rope: k/v row stride too large");
+    AttnArgs a;
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.o = (unsigned short*)o; a.lse = lse; a.cu_q = cu_q; a.cu_k = cu_k;
+    a.q_st = q_st; a.q_sh = q_sh; a.k_st = k_st; a.k_sh = k_sh; a.v_st = v_st; a.v_sh = v_sh; a.o_st = o_st; a.o_sh = o_sh;
+    a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.total_q = total_q;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.causal = causal;
+    a.rope_cos = cos_q; a.rope_sin = sin_q; a.rope_kcos = cos_k; a.rope_ksin = sin_k;
+    a.bq_shift = a.bk_shift = -1;
+    a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1;
+    g_attn_variant = 0;
+    return launch_any<true>(a, nseg, max_q, (hipStream_t)stream);
 }

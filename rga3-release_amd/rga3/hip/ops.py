@@ -168,26 +168,33 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
 
 
 def attn_rope_q_ok(max_q: int, D: int) -> bool:
-    """Shapes rga3_attn_fwd_rope_q covers (second-generation attention kernel)."""
-    return int(max_q) >= 128 and D <= 128 and D % 16 == 0
+    """Long segments: Q is rotated inside the attention call (each query row is loaded once per workgroup), K by the stand-alone pass (each key is
+    loaded by every query block, so rotating it in the kernel would repeat the work)."""
+    return int(max_q) >= 128 and D % 16 == 0
 
 
-def attn_varlen_rope_q(q, k, v, cu_q, cu_k, max_q: int, scale: float, cos, sin, causal: bool = False, out=None, return_lse=False):
-    """attn_varlen with RoPE applied to q while it is loaded (q un-rotated, k already rotated); cos / sin [Tq, D] f32."""
+def attn_varlen_rope(q, k, v, cu_q, cu_k, max_q: int, scale: float, cos, sin, causal: bool = False, rope_k: bool = False, out=None, return_lse=False):
+    """attn_varlen with RoPE applied while q is loaded (q un-rotated); rope_k=False: k is already rotated; rope_k=True: k (un-rotated, same token
+    packing as q: self-attention) is rotated while it is staged.  cos / sin [T, D] f32."""
     _need_cuda(q, k, v, cu_q, cu_k, cos, sin)
     assert q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
     Tq, Hq, D = q.shape
     assert cos.dtype == sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and tuple(cos.shape) == (Tq, D) == tuple(sin.shape)
+    assert not rope_k or k.shape[0] == Tq, "rope_k needs keys packed like the queries (self-attention)"
     if out is None:
         out = torch.empty((Tq, Hq, D), dtype=torch.bfloat16, device=q.device)
     lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device) if return_lse else None
-    rc = _lib.load().rga3_attn_fwd_rope_q(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(lse), cu_q.data_ptr(), cu_k.data_ptr(),
-                                          cu_q.numel() - 1, int(max_q), Tq, Hq, k.shape[1], D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                          v.stride(0), v.stride(1), out.stride(0), out.stride(1), float(scale), int(bool(causal)), cos.data_ptr(), sin.data_ptr(),
-                                          _stream())
-    _lib.check(rc, "attn_fwd_rope_q")
+    rc = _lib.load().rga3_attn_varlen_fwd_rope(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(lse), cu_q.data_ptr(), cu_k.data_ptr(),
+                                               cu_q.numel() - 1, int(max_q), Tq, Hq, k.shape[1], D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                               v.stride(0), v.stride(1), out.stride(0), out.stride(1), float(scale), int(bool(causal)), cos.data_ptr(),
+                                               sin.data_ptr(), cos.data_ptr() if rope_k else None, sin.data_ptr() if rope_k else None, _stream())
+    _lib.check(rc, "attn_varlen_fwd_rope")
     return (out, lse) if return_lse else out
+
+
+def attn_varlen_rope_q(q, k, v, cu_q, cu_k, max_q: int, scale: float, cos, sin, causal: bool = False, out=None, return_lse=False):
+    return attn_varlen_rope(q, k, v, cu_q, cu_k, max_q, scale, cos, sin, causal, False, out, return_lse)
 
 
 def rmsnorm(x, weight, eps: float, add=None, return_residual=False):

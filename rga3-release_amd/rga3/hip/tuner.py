@@ -125,5 +125,24 @@ def table():
     return dict(_cache)
 
 
+def save(path: str):
+    """Write the decisions (key -> tile) as JSON; `load` restores them so a later process launches no trial GEMMs (rocprofv3 --pmc passes count bytes
+    per launch of the TIMED tilings only)."""
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k), v] for k, v in _cache.items()], f)
+
+
+def load(path: str):
+    import json
+    with open(path) as f:
+        for k, v in json.load(f):
+            _cache[tuple(k)] = int(v)
+
+
 def timings():
     return {k: dict(v) for k, v in _times.items()}
+
+
+if os.environ.get("RGA3_TUNE_LOAD") and os.path.exists(os.environ["RGA3_TUNE_LOAD"]):
+    load(os.environ["RGA3_TUNE_LOAD"])

@@ -253,6 +253,9 @@ class VisionAttention(nn.Module):
         if ops.attn_rope_q_ok(max_len, D):    # long segments (the full-attention blocks): the attention kernel rotates Q as it loads it, only K takes the rope pass
             ops.rope_(qkv, cos, sin, H, H)
             att = ops.attn_varlen_rope_q(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False)
+        elif D % 16 == 0 and not torch.is_grad_enabled():
+            # windows: every key is loaded once per head, so q AND k are rotated while the attention kernel loads them -- no rope pass at all
+            att = ops.attn_varlen_rope(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False, rope_k=True)
         else:
             ops.rope_(qkv, cos, sin, 0, 2 * H)  # q heads then k heads are contiguous in the fused buffer
             att = ops.attn_varlen(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, causal=False)

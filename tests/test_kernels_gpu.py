@@ -113,7 +113,7 @@ ATTN_CASES = [
     ([5], [133], 2, 2, 64, True),                 # causal with Lk > Lq (decode-style)
     ([1024], [7000], 1, 1, 256, False),           # memory attention over a grown bank: key range split over workgroups
     ([100, 700], [3000, 1200], 2, 2, 64, False),  # split-KV with ragged segments (second segment shorter than a slice set)
-    ([640, 129, 1000], None, 6, 2, 128, True),    # second-generation kernel: paired causal q-blocks, ragged tails, GQA
+    ([640, 129, 1000], None, 6, 2, 128, True),    # paired causal q-blocks, ragged tails, GQA
     ([200], [457], 3, 3, 64, True),               # ... causal with Lk > Lq, one unpaired block pair
     ([333, 128], None, 2, 2, 96, False),          # ... head dim 96, non-causal, ragged
     ([130], [64], 2, 1, 32, False),               # ... a single key tile, D = 32 (padded to 64)
@@ -141,11 +141,11 @@ def test_attn_varlen(dev, case, impl):
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("case", [([2112], 28, 4, 128, True), ([1024, 1024], 4, 4, 80, False), ([300, 150], 4, 2, 64, True), ([128], 2, 2, 16, False)])
+@pytest.mark.parametrize("case", [([2112], 28, 4, 128, True), ([1024, 1024], 4, 4, 80, False), ([300, 150], 4, 2, 64, True), ([128], 2, 2, 16, False),
+                                  ([64] * 12, 16, 16, 80, False)])
 def test_attn_rope_q_fused(dev, case):
-    """RoPE on Q inside the attention kernel (rga3_attn_fwd_rope_q) == rope pass over q and k, then attention: same values (the rotation is the
-    rope kernel's arithmetic with one bf16 rounding), against the oracle's rotate-half + exact softmax attention; the A/B switch (impl bit 2) of the
-    first-generation kernel agrees with the second-generation one."""
+    """RoPE applied while the attention kernel loads q (and optionally k) (rga3_attn_varlen_fwd_rope) == rope pass over q and k, then attention: same
+    values (the rotation is the rope kernel's arithmetic with one bf16 rounding), and against the oracle's rotate-half + exact softmax attention."""
     from rga3.hip import ops
 
     lens, Hq, Hkv, D, causal = case
@@ -160,13 +160,14 @@ def test_attn_rope_q_fused(dev, case):
     a = qkv.clone()
     ops.rope_(a, cos, sin, 0, Hq + Hkv)
     ref_o, ref_lse = ops.attn_varlen(a[:, :Hq], a[:, Hq:Hq + Hkv], a[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, causal, return_lse=True)
-    old_o = ops.attn_varlen(a[:, :Hq], a[:, Hq:Hq + Hkv], a[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, causal, impl=4)
     b = qkv.clone()
     ops.rope_(b, cos, sin, Hq, Hkv)
     assert torch.equal(b[:, :Hq], qkv[:, :Hq]) and torch.equal(b[:, Hq:Hq + Hkv], a[:, Hq:Hq + Hkv])
     o, lse = ops.attn_varlen_rope_q(b[:, :Hq], b[:, Hq:Hq + Hkv], b[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, cos, sin, causal, return_lse=True)
     assert _rel_l2(o, ref_o) < 2e-3 and (lse - ref_lse).abs().max().item() < 1e-3
-    assert _rel_l2(old_o, ref_o) < 5e-3
+    # q and k both rotated while they are loaded (no rope pass at all): the windowed-ViT form
+    o2 = ops.attn_varlen_rope(qkv[:, :Hq], qkv[:, Hq:Hq + Hkv], qkv[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, cos, sin, causal, rope_k=True)
+    assert _rel_l2(o2, ref_o) < 2e-3
     qf = qkv.float().cpu()
     rot = lambda x: torch.cat([-x[..., D // 2:], x[..., :D // 2]], -1)
     c, s_ = emb.cos()[:, None], emb.sin()[:, None]

@@ -253,6 +253,33 @@ def test_fp8_frozen_gemm_training_step_close_to_bf16(dev):
     assert any(k.startswith("fp8:") for layer in m.model.layers for k in layer.mlp.__dict__.get("_wt_cache", {})), "fp8 weight packs were not built"
     assert abs(l8 - l16) / l16 < 2e-2, (l8, l16)
     assert set(g8) == set(g16)
+    # ---- against an ORACLE fp8 step (oracle/fp8step.py: the fp32 restatement with the same e4m3 quantisation of the frozen contractions, forward and dX):
+    #      same quantiser, same scales, so what is left is bf16 rounding of the other ops -- far below the e4m3 noise that separates fp8 from bf16
+    from oracle.fp8step import fp8_frozen_linears
+    Po = {}
+    for n, p in m.named_parameters():
+        key = n.replace(".lora_A.default.weight", ".lora_A.default.weight")
+        Po[key] = p.detach().float().cpu().clone()
+    Po["lora_scaling"] = 2.0
+    tkeys = [k for k in Po if isinstance(Po[k], torch.Tensor) and ("lora_" in k or k in ("lm_head.weight", "model.embed_tokens.weight"))]
+    for k in tkeys:
+        Po[k].requires_grad_(True)
+    ocfg = Q.QwenCfg(vision=oracle_cfg().vision, text=Q.TextCfg(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, intermediate_size=512,
+                                                             vocab_size=640, rms_norm_eps=1e-6, rope_theta=1000000.0, mrope_section=(16, 24, 24)),
+                     image_token_id=301, video_token_id=302, vision_start_token_id=303)
+    with fp8_frozen_linears():
+        ro = Q.forward(Po, ocfg, ids, am, labels=labels)
+        ro["loss"].backward()
+    with torch.no_grad():
+        rb = Q.forward({k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in Po.items()}, ocfg, ids, am, labels=labels)
+    assert abs(l8 - float(ro["loss"])) / float(ro["loss"]) < 5e-3, (l8, float(ro["loss"]))
+    assert abs(l8 - float(ro["loss"])) < abs(l8 - float(rb["loss"])) + 1e-4      # closer to the oracle's fp8 step than to its bf16-free fp32 step
+    eo = {k: rel_l2(g8[k], Po[k].grad) for k in tkeys}
+    # (the oracle quantises the fp32 oracle's activations, the build its own bf16 ones: a different rounding of an activation moves an e4m3 code by a
+    #  whole step, so the two fp8 steps agree to ~e4m3 step noise / sqrt(K) per contraction, not to bf16 noise)
+    print("FP8_ERRS vs oracle fp8 step", {k.split("layers.")[-1]: round(v, 3) for k, v in eo.items()}, "vs own bf16 step", round(float(np.median([rel_l2(g8[k], g16[k]) for k in g16])), 3))
+    assert max(eo.values()) < 0.2 and float(np.median(list(eo.values()))) < 0.15, eo
+    assert float(np.median(list(eo.values()))) <= float(np.median([rel_l2(g8[k], g16[k]) for k in g16])) + 2e-2   # no further from the oracle's fp8 step than from its own bf16 step
     errs = {k: rel_l2(g8[k], g16[k]) for k in g16}
     # each e4m3 x e4m3 contraction carries ~5 % relative noise (3 mantissa bits, two operands, random-sign terms do not average it out);
     # eight of them sit on the path from the loss to a LoRA factor
