@@ -316,7 +316,7 @@ def cpu_baseline(train: bool, sam_frames: int = 16):
 def launch_ranks(args):
     """Parent of a multi-GPU run: never touches the GPU (torch.cuda.device_count() does not initialise it on this image), starts N ranks of this file
     through torch.distributed.run and exits with their code (reference launcher: run_torchrun.sh:6-12,23)."""
-    if args.mode != "ddp_selftest":
+    if args.mode != "ddp_selftest" and not os.environ.get("RGA3_BENCH_SHARE_GPU"):
         n_vis = torch.cuda.device_count()
         if n_vis < args.gpus:
             print(f"bench.py: {args.gpus} GPUs requested, {n_vis} visible", file=sys.stderr)
@@ -491,9 +491,6 @@ def measure_forward(model_fwd, inputs, args, rank, refine=True):
         ch = tuner.refine(step, reps=int(rr), within=float(rw))
         if rank == 0 and ch:
             print("tuner.refine changed %d shape(s): %s" % (len(ch), {str(k[:3]): v for k, v in ch.items()}), file=sys.stderr)
-    if os.environ.get("RGA3_TUNE_SAVE") and rank == 0:
-        step()
-        tuner.save(os.environ["RGA3_TUNE_SAVE"])
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -588,16 +585,25 @@ def main():
         sys.exit(2)
     if args.mode == "ddp_selftest":
         return ddp_selftest(args, rank, world)
+    # RGA3_BENCH_SHARE_GPU=1 (+ RGA3_BENCH_BACKEND=gloo): every rank on GPU 0 -- a functional check of the multi-rank code path (hooks, bucket order, sparse row
+    # exchange, side streams) on a 1-GPU box; RCCL itself refuses two ranks on one device, so this is never a measurement
+    share = bool(os.environ.get("RGA3_BENCH_SHARE_GPU"))
     n_vis = torch.cuda.device_count()
-    if n_vis < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+    if not share and n_vis < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
         print(f"bench.py: {args.gpus} GPUs requested, {n_vis} visible", file=sys.stderr)
         sys.exit(2)
+    if share:
+        local = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("RGA3_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -644,6 +650,9 @@ def main():
                                    "flops_per_sample": TOTAL_FLOPS},
                         "roofline": fwd_roof, "verify": fwd_verify, "cpu_baseline": cpu}
                 print(json.dumps(line), flush=True)
+                if os.environ.get("RGA3_TUNE_SAVE"):
+                    from rga3.hip import tuner
+                    tuner.save(os.environ["RGA3_TUNE_SAVE"])
             if dist is not None:
                 dist.destroy_process_group()
             return
@@ -782,6 +791,9 @@ def main():
                 "verify": dict(fwd_verify or {}, loss_first_last=[round(float(lv[0]), 5), round(float(lv[-1]), 5)]),
                 "comm": comm, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
+    if rank == 0 and os.environ.get("RGA3_TUNE_SAVE"):   # decisions of this run, for rocprofv3 --pmc passes without trial launches (RGA3_TUNE_LOAD)
+        from rga3.hip import tuner
+        tuner.save(os.environ["RGA3_TUNE_SAVE"])
     if dist is not None:
         dist.destroy_process_group()
 

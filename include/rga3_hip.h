@@ -89,11 +89,12 @@ int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, f
                          const int32_t* cu_k, int nseg, int max_q, int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh,
                          int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
                          float scale, int causal, int impl, float* split_ws, int64_t split_ws_elems, int max_k, int block_q, int block_k, void* stream);
-/* The same attention with RoPE applied WHILE q (and optionally k) ARE LOADED: cos / sin [tokens, D] f32 tables indexed by the packed token, rotate-half
- * pairing d <-> d +- D/2 (HF apply_rotary_pos_emb_vision modeling_qwen2_5_vl.py:160-171, apply_multimodal_rotary_pos_emb :557-599), D % 16 == 0.
- * cos_k / sin_k NULL: k is already rotated (rga3_rope_inplace on the K heads only: the decoder's 4 KV heads, the ViT's full-attention blocks).
- * cos_k / sin_k given: k is rotated while it is staged, so the stand-alone rope pass disappears altogether -- meant for windowed attention, where every
- * key is loaded once per head (the ViT's 64-token windows); on long segments every query block would rotate the keys again. */
+/* Windowed attention (segments of <= 64 queries: the ViT's 64-token windows) with RoPE applied WHILE q and k ARE LOADED: cos / sin [tokens, D] f32
+ * tables indexed by the packed token, rotate-half pairing d <-> d +- D/2 (HF apply_rotary_pos_emb_vision modeling_qwen2_5_vl.py:160-171), D % 16 == 0,
+ * D <= 128.  Every key of a window is loaded exactly once per head, so the stand-alone rga3_rope_inplace pass over q and k disappears (measured on
+ * MI355X, 128 windows x 16 heads x 80: rope 21 us + attention 25.6 us -> 42 us).  cos_k / sin_k NULL: k is already rotated.  Longer segments are
+ * rejected: there every query block would rotate the keys again, and rotating Q in the long-row kernel cost more than the pass it removed
+ * (decoder S = 2112: 72 -> 98 us), so those call sites keep rga3_rope_inplace + rga3_attn_varlen_fwd. */
 int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
                               int64_t total_q, int Hq, int Hkv, int D, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh,
                               int64_t o_st, int64_t o_sh, float scale, int causal, const float* cos_q, const float* sin_q, const float* cos_k,

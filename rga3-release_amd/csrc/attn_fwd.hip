@@ -69,7 +69,7 @@ __device__ __forceinline__ u32x4 rope_chunk(u32x4 z, const unsigned short* row_p
 
 constexpr int KV_TILE = 64;
 
-template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, bool SPLIT = false>
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, bool SPLIT = false, bool ROPE = false>
 __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     static_assert(!(PAIR && SPLIT), "pairing and KV splitting are alternatives");
     constexpr int NT = 64 * NWAVE;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
             if (qi < Lq && d < p.D) {
                 const unsigned short* qrow = p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh;
                 z = *(const u32x4*)(qrow + d);
-                if (p.rope_cos) z = rope_chunk(z, qrow, d, p.D, p.rope_cos + (long)(qs + qi) * p.D, p.rope_sin + (long)(qs + qi) * p.D);
+                if constexpr (ROPE) z = rope_chunk(z, qrow, d, p.D, p.rope_cos + (long)(qs + qi) * p.D, p.rope_sin + (long)(qs + qi) * p.D);
             }
             qf[t][ds] = __builtin_bit_cast(bf16x8, z);
         }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
             if ((EVEN || idx < KV_TILE * CH) && key < Lk && ch * 8 < p.D) {
                 zk = *(const u32x4*)(kt_k + koff0[i]);
                 zv = *(const u32x4*)(kt_v + voff0[i]);
-                if (p.rope_kcos) zk = rope_chunk(zk, kt_k + koff0[i] - ch * 8, ch * 8, p.D, p.rope_kcos + (long)(ks + key) * p.D, p.rope_ksin + (long)(ks + key) * p.D);
+                if constexpr (ROPE) if (p.rope_kcos) zk = rope_chunk(zk, kt_k + koff0[i] - ch * 8, ch * 8, p.D, p.rope_kcos + (long)(ks + key) * p.D, p.rope_ksin + (long)(ks + key) * p.D);
             }
             kreg[slot][i] = zk;
             vreg[slot][i] = zv;
@@ -433,6 +433,22 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     return launch_attn_p<DP, QT, NWAVE, USE_TR, false>(a, nseg, nqb, st);
 }
 
+// RoPE-while-loading variant: windows of <= 64 queries (one query block of 4 waves x 16 rows per segment and head)
+template <int DP>
+static int launch_rope_win(const AttnArgs& a, int nseg, hipStream_t st) {
+    constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
+    auto kern = attn_fwd_kernel<DP, 1, 4, true, false, false, true>;
+    static bool attr_done = false;
+    if (!attr_done && LDS > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(1, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS, st, a);
+    RGA3_CHECK_LAUNCH("attn_fwd_kernel<rope>");
+    return 0;
+}
+
 static int g_attn_variant = 0;  // 0: auto, 1: force 4 waves x QT=2, 2: force 8 waves x QT=1 (benchmark switch, read-only after init)
 
 template <int DP, bool USE_TR>
@@ -525,8 +541,8 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
                                         int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal, const float* cos_q, const float* sin_q,
                                         const float* cos_k, const float* sin_k, void* stream) {
     RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k && cos_q && sin_q && ((cos_k == nullptr) == (sin_k == nullptr)), "attn_varlen_fwd_rope: null pointer");
-    RGA3_CHECK_ARG(nseg > 0 && nseg <= 65535 && max_q > 0 && total_q > 0, "attn_varlen_fwd_rope: nseg=%d max_q=%d", nseg, max_q);
-    RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq <= 65535 && D >= 16 && D <= 256 && D % 16 == 0, "attn_varlen_fwd_rope: Hq=%d Hkv=%d D=%d", Hq, Hkv, D);
+    RGA3_CHECK_ARG(nseg > 0 && nseg <= 65535 && max_q > 0 && max_q <= 64 && total_q > 0, "attn_varlen_fwd_rope: nseg=%d max_q=%d (windows of <= 64 queries)", nseg, max_q);
+    RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq <= 65535 && D >= 16 && D <= 128 && D % 16 == 0, "attn_varlen_fwd_rope: Hq=%d Hkv=%d D=%d", Hq, Hkv, D);
     RGA3_CHECK_ARG(q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0 && o_st % 4 == 0 && o_sh % 4 == 0,
                    "attn_varlen_fwd_rope: strides");
     RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)cos_q | (uintptr_t)sin_q | (uintptr_t)cos_k | (uintptr_t)sin_k) & 15) == 0 &&
@@ -542,6 +558,9 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
     a.rope_cos = cos_q; a.rope_sin = sin_q; a.rope_kcos = cos_k; a.rope_ksin = sin_k;
     a.bq_shift = a.bk_shift = -1;
     a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1;
-    g_attn_variant = 0;
-    return launch_any<true>(a, nseg, max_q, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 32) return launch_rope_win<32>(a, nseg, st);
+    if (D <= 64) return launch_rope_win<64>(a, nseg, st);
+    if (D <= 96) return launch_rope_win<96>(a, nseg, st);
+    return launch_rope_win<128>(a, nseg, st);
 }

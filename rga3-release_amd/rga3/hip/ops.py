@@ -167,10 +167,9 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
     return (out, lse) if return_lse else out
 
 
-def attn_rope_q_ok(max_q: int, D: int) -> bool:
-    """Long segments: Q is rotated inside the attention call (each query row is loaded once per workgroup), K by the stand-alone pass (each key is
-    loaded by every query block, so rotating it in the kernel would repeat the work)."""
-    return int(max_q) >= 128 and D % 16 == 0
+def attn_rope_win_ok(max_q: int, D: int) -> bool:
+    """Windowed attention (<= 64 queries per segment): q and k can be rotated while the attention kernel loads them (rga3_attn_varlen_fwd_rope)."""
+    return int(max_q) <= 64 and D <= 128 and D % 16 == 0
 
 
 def attn_varlen_rope(q, k, v, cu_q, cu_k, max_q: int, scale: float, cos, sin, causal: bool = False, rope_k: bool = False, out=None, return_lse=False):
@@ -191,10 +190,6 @@ def attn_varlen_rope(q, k, v, cu_q, cu_k, max_q: int, scale: float, cos, sin, ca
                                                sin.data_ptr(), cos.data_ptr() if rope_k else None, sin.data_ptr() if rope_k else None, _stream())
     _lib.check(rc, "attn_varlen_fwd_rope")
     return (out, lse) if return_lse else out
-
-
-def attn_varlen_rope_q(q, k, v, cu_q, cu_k, max_q: int, scale: float, cos, sin, causal: bool = False, out=None, return_lse=False):
-    return attn_varlen_rope(q, k, v, cu_q, cu_k, max_q, scale, cos, sin, causal, False, out, return_lse)
 
 
 def rmsnorm(x, weight, eps: float, add=None, return_residual=False):

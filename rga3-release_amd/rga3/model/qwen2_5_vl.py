@@ -250,10 +250,7 @@ class VisionAttention(nn.Module):
         N = h.shape[0]
         H, D = self.num_heads, self.head_dim
         qkv = self.qkv(h).view(N, 3 * H, D)
-        if ops.attn_rope_q_ok(max_len, D):    # long segments (the full-attention blocks): the attention kernel rotates Q as it loads it, only K takes the rope pass
-            ops.rope_(qkv, cos, sin, H, H)
-            att = ops.attn_varlen_rope_q(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False)
-        elif D % 16 == 0 and not torch.is_grad_enabled():
+        if ops.attn_rope_win_ok(max_len, D) and not torch.is_grad_enabled():
             # windows: every key is loaded once per head, so q AND k are rotated while the attention kernel loads them -- no rope pass at all
             att = ops.attn_varlen_rope(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False, rope_k=True)
         else:
@@ -380,17 +377,13 @@ class DecoderAttention(nn.Module):
             qkv = qkv_with_lora(self, h, seeds=getattr(self, "_lora_drop_seeds", None))[0].view(T, Hq + 2 * Hk, D)
         else:  # foreign wrappers (e.g. PEFT): honour them, then assemble the fused buffer
             qkv = torch.cat([self.q_proj(h), self.k_proj(h), self.v_proj(h)], dim=-1).view(T, Hq + 2 * Hk, D)
-        fuse_q = ops.attn_rope_q_ok(max_len, D)     # prefill / forward: Q is rotated inside the attention kernel, the rope pass only touches the K heads
-        ops.rope_(qkv, cos, sin, Hq if fuse_q else 0, Hk if fuse_q else Hq + Hk)
+        ops.rope_(qkv, cos, sin, 0, Hq + Hk)
         q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
         cu_k = cu
         if cache is not None:
             k, v, cu_k = cache.update(self.layer_idx, k, v, cu)
         # decode step (one query per sequence): every cached key is visible, and the non-causal form may split the key range over workgroups
-        if fuse_q:
-            att = ops.attn_varlen_rope_q(q, k, v, cu, cu_k, max_len, D ** -0.5, cos, sin, causal=True)
-        else:
-            att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
+        att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
         return self.o_proj(att.view(T, Hq * D), residual=residual)
 
 

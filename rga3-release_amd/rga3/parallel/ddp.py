@@ -71,7 +71,8 @@ class GradBucketReducer:
             self.flat.append(torch.zeros(off, dtype=b[0].dtype, device=b[0].device))
             self.pending.append(len(b))
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self._avg = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self._nccl = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self._avg = self._nccl
         # ---- sparse parameters: a persistent dense gradient buffer (zero outside the rows touched this step) + the exchange state
         self._sp = {}
         for p in self.sparse_params:
@@ -183,7 +184,7 @@ class GradBucketReducer:
             return
         dev = p.device
         n = torch.tensor([st["union"].size], dtype=torch.int64)
-        if dev.type == "cuda":
+        if dev.type == "cuda" and self._nccl:
             side = st.setdefault("side", torch.cuda.Stream(device=dev))
             n = n.pin_memory()
             host = torch.empty(self.world, dtype=torch.int64).pin_memory()
@@ -227,8 +228,15 @@ class GradBucketReducer:
             send_rows[:ids.numel()] = _gather(d, ids)
         all_ids = torch.empty((self.world * cap,), dtype=torch.int64, device=dev)
         all_rows = torch.empty((self.world * cap, H), dtype=d.dtype, device=dev)
-        dist.all_gather_into_tensor(all_ids, send_ids, group=self.pg)
-        dist.all_gather_into_tensor(all_rows, send_rows, group=self.pg)
+        if self._nccl or dev.type != "cuda":
+            dist.all_gather_into_tensor(all_ids, send_ids, group=self.pg)
+            dist.all_gather_into_tensor(all_rows, send_rows, group=self.pg)
+        else:   # gloo has no all-gather on device tensors (functional multi-rank runs on a shared GPU, bench.py RGA3_BENCH_SHARE_GPU): stage through the host
+            hi, hr = torch.empty(all_ids.shape, dtype=all_ids.dtype), torch.empty(all_rows.shape, dtype=all_rows.dtype)
+            dist.all_gather_into_tensor(hi, send_ids.cpu(), group=self.pg)
+            dist.all_gather_into_tensor(hr, send_rows.cpu(), group=self.pg)
+            all_ids.copy_(hi)
+            all_rows.copy_(hr)
         self.sparse_bytes_last = self.world * cap * (8 + H * d.element_size())
         # local rows out, then the N contributions in rank order (every id list is unique within itself): identical bits on every rank
         if ids.numel():

@@ -141,12 +141,13 @@ def test_attn_varlen(dev, case, impl):
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("case", [([2112], 28, 4, 128, True), ([1024, 1024], 4, 4, 80, False), ([300, 150], 4, 2, 64, True), ([128], 2, 2, 16, False),
-                                  ([64] * 12, 16, 16, 80, False)])
-def test_attn_rope_q_fused(dev, case):
-    """RoPE applied while the attention kernel loads q (and optionally k) (rga3_attn_varlen_fwd_rope) == rope pass over q and k, then attention: same
-    values (the rotation is the rope kernel's arithmetic with one bf16 rounding), and against the oracle's rotate-half + exact softmax attention."""
-    from rga3.hip import ops
+@pytest.mark.parametrize("case", [([64] * 12, 16, 16, 80, False), ([64, 17, 40], 4, 2, 64, False), ([33] * 3, 2, 2, 128, True), ([16] * 5, 2, 1, 32, False)])
+@pytest.mark.parametrize("rope_k", [True, False])
+def test_attn_rope_windows_fused(dev, case, rope_k):
+    """Windowed attention with RoPE applied while q (and k) are loaded (rga3_attn_varlen_fwd_rope) == rope pass over q and k, then attention: same
+    values (the rotation is the rope kernel's arithmetic with one bf16 rounding), and against the oracle's rotate-half + exact softmax attention;
+    longer segments are rejected."""
+    from rga3.hip import lib, ops
 
     lens, Hq, Hkv, D, causal = case
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
@@ -161,13 +162,11 @@ def test_attn_rope_q_fused(dev, case):
     ops.rope_(a, cos, sin, 0, Hq + Hkv)
     ref_o, ref_lse = ops.attn_varlen(a[:, :Hq], a[:, Hq:Hq + Hkv], a[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, causal, return_lse=True)
     b = qkv.clone()
-    ops.rope_(b, cos, sin, Hq, Hkv)
-    assert torch.equal(b[:, :Hq], qkv[:, :Hq]) and torch.equal(b[:, Hq:Hq + Hkv], a[:, Hq:Hq + Hkv])
-    o, lse = ops.attn_varlen_rope_q(b[:, :Hq], b[:, Hq:Hq + Hkv], b[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, cos, sin, causal, return_lse=True)
+    if not rope_k:
+        ops.rope_(b, cos, sin, Hq, Hkv)
+    o, lse = ops.attn_varlen_rope(b[:, :Hq], b[:, Hq:Hq + Hkv], b[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, cos, sin, causal, rope_k=rope_k,
+                                  return_lse=True)
     assert _rel_l2(o, ref_o) < 2e-3 and (lse - ref_lse).abs().max().item() < 1e-3
-    # q and k both rotated while they are loaded (no rope pass at all): the windowed-ViT form
-    o2 = ops.attn_varlen_rope(qkv[:, :Hq], qkv[:, Hq:Hq + Hkv], qkv[:, Hq + Hkv:], cu.to(dev), cu.to(dev), max(lens), D ** -0.5, cos, sin, causal, rope_k=True)
-    assert _rel_l2(o2, ref_o) < 2e-3
     qf = qkv.float().cpu()
     rot = lambda x: torch.cat([-x[..., D // 2:], x[..., :D // 2]], -1)
     c, s_ = emb.cos()[:, None], emb.sin()[:, None]
@@ -175,6 +174,8 @@ def test_attn_rope_q_fused(dev, case):
     kr = (qf[:, Hq:Hq + Hkv] * c + rot(qf[:, Hq:Hq + Hkv]) * s_).to(torch.bfloat16).float()
     ro, _ = R.attn_varlen_ref(qr, kr, qf[:, Hq + Hkv:], cu, cu, D ** -0.5, causal)
     assert _rel_l2(o, ro) < 1e-2
+    with pytest.raises(lib.Rga3Error):
+        ops.attn_varlen_rope(b[:, :Hq], b[:, Hq:Hq + Hkv], b[:, Hq + Hkv:], cu.to(dev), cu.to(dev), 65, D ** -0.5, cos, sin, causal, rope_k=rope_k)
 
 
 def test_attn_forced_rescale(dev):

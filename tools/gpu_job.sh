@@ -1,7 +1,9 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT" || exit 1
-export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x -k "attn" 2>&1 | tail -15 | cut -c1-300 > gpurun_out/r2j_attn_tests.log; cat gpurun_out/r2j_attn_tests.log
-timeout 300 python tools/attn_rates.py > gpurun_out/r2j_attn_rates.log 2>&1; cat gpurun_out/r2j_attn_rates.log
-timeout 900 python -m pytest tests/test_train_gpu.py -q -m gpu -x -k "fp8" 2>&1 | tail -25 | cut -c1-400
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py"
+RGA3_TUNE_SAVE=$O/r2l_tuner_forward.json $B --mode forward --steps 10 --warmup 3 --no-cpu-baseline > $O/r2l_fwd.json 2> $O/r2l_fwd.err
+export RGA3_TUNE_LOAD=$O/r2l_tuner_forward.json RGA3_BENCH_TIMED_ONLY=1
+rm -rf /tmp/p2; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -o fwd -- $B --mode forward --steps 20 --warmup 3 --no-refine --no-cpu-baseline > $O/r2l_prof_forward.log 2>&1
+cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $O/r2l_forward_kernel_stats.csv
+head -30 $O/r2l_forward_kernel_stats.csv | cut -c1-230
