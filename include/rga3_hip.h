@@ -278,6 +278,11 @@ int rga3_quant_fp8_rows(const void* x, void* q, float* scales, int64_t rows, int
  * rate); K % 128 == 0; lda / ldw in bytes.  Replaces the frozen nn.Linear contractions (HF modeling_qwen2_5_vl.py:602-757) when fp8 is enabled. */
 int rga3_gemm_fp8(const void* Aq, const void* Wq, const float* sa, const float* sw, const void* bias, const void* residual, void* C, int64_t M,
                   int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, void* stream);
+/* The row quantiser fused into the producers of the two widest activations of a decoder layer (BASELINE configs[4]): q / scales as rga3_quant_fp8_rows would
+ * give them for rga3_swiglu_fwd(gu) [T, I] and for rga3_swiglu_bwd(gu, da) [T, 2I] (interleaved like gu), bit for bit, without the bf16 tensors ever
+ * reaching memory.  The MLP of HF Qwen2MLP (modeling_qwen2_5_vl.py:541-553) under the fp8 switch. */
+int rga3_swiglu_fwd_quant_fp8(const void* gu, void* q, float* scales, int64_t T, int64_t I, void* stream);
+int rga3_swiglu_bwd_quant_fp8(const void* gu, const void* da, void* q, float* scales, int64_t T, int64_t I, void* stream);
 
 #ifdef __cplusplus
 }

@@ -297,6 +297,108 @@ __global__ __launch_bounds__(512) void gemm_fp8_pp_kernel(Fp8GemmArgs p) {
     }
 }
 
+// ---- the row quantiser fused into the producers of the two widest activations of a decoder layer (config 5): the SwiGLU output a = silu(g) * u
+//      [T, I] (consumed only by the down projection) and its backward dgu [T, 2I] (consumed only by the dX contraction through gate/up).  Unfused, each
+//      is written as bf16 and read back by quant_fp8_rows_kernel (3 x 2 bytes per element of traffic); fused, only the e4m3 bytes + one scale per row
+//      leave the kernel.  One workgroup per row, two passes over the (L2-resident) inputs: amax of the bf16-ROUNDED values, then the same values quantised
+//      -- bit-identical to swiglu_{fwd,bwd}_kernel followed by quant_fp8_rows_kernel.
+__device__ __forceinline__ void unpack8f(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ float bfround(float x) { return __uint_as_float(((unsigned)f2bf(x)) << 16); }
+__device__ __forceinline__ u32x2 quant8(const float* f, float scale) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] / scale, f[1] / scale, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] / scale, f[3] / scale, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] / scale, f[5] / scale, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] / scale, f[7] / scale, hi, true);
+    u32x2 o;
+    o[0] = (unsigned)lo;
+    o[1] = (unsigned)hi;
+    return o;
+}
+__device__ __forceinline__ float block_amax(float amax, float* part) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    return fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+
+__global__ __launch_bounds__(256) void swiglu_fwd_quant_kernel(const unsigned short* __restrict__ gu, unsigned char* __restrict__ q, float* __restrict__ scales,
+                                                               long I) {
+    __shared__ float part[4];
+    const long t = blockIdx.x;
+    const int nch = (int)(I / 8);
+    const unsigned short* gr = gu + t * 2 * I;
+    auto values = [&](int ch, float* o) {   // swiglu_fwd_kernel's arithmetic, result rounded to bf16 as its store does
+        float g[8], u[8];
+        const long goff = (long)(ch / 2) * 32 + (ch % 2) * 8;
+        unpack8f(*(const u32x4*)(gr + goff), g);
+        unpack8f(*(const u32x4*)(gr + goff + 16), u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bfround(bfround(g[e] / (1.f + __expf(-g[e]))) * u[e]);
+    };
+    float amax = 0.f;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        float o[8];
+        values(ch, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(o[e]));
+    }
+    amax = block_amax(amax, part);
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (threadIdx.x == 0) scales[t] = scale;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        float o[8];
+        values(ch, o);
+        *(u32x2*)(q + t * I + ch * 8) = quant8(o, scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_quant_kernel(const unsigned short* __restrict__ gu, const unsigned short* __restrict__ da,
+                                                               unsigned char* __restrict__ q, float* __restrict__ scales, long I) {
+    __shared__ float part[4];
+    const long t = blockIdx.x;
+    const int nch = (int)(I / 8);
+    const unsigned short* gr = gu + t * 2 * I;
+    const unsigned short* dr = da + t * I;
+    auto values = [&](int ch, float* dg, float* du) {   // swiglu_bwd_kernel's arithmetic, rounded to bf16 as its stores do
+        float g[8], u[8], d[8];
+        const long goff = (long)(ch / 2) * 32 + (ch % 2) * 8;
+        unpack8f(*(const u32x4*)(gr + goff), g);
+        unpack8f(*(const u32x4*)(gr + goff + 16), u);
+        unpack8f(*(const u32x4*)(dr + ch * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.f / (1.f + __expf(-g[e]));
+            du[e] = bfround(d[e] * (g[e] * sg));
+            dg[e] = bfround(d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg)));
+        }
+    };
+    float amax = 0.f;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        float dg[8], du[8];
+        values(ch, dg, du);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fmaxf(fabsf(dg[e]), fabsf(du[e])));
+    }
+    amax = block_amax(amax, part);
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (threadIdx.x == 0) scales[t] = scale;
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        float dg[8], du[8];
+        values(ch, dg, du);
+        const long goff = (long)(ch / 2) * 32 + (ch % 2) * 8;
+        *(u32x2*)(q + t * 2 * I + goff) = quant8(dg, scale);
+        *(u32x2*)(q + t * 2 * I + goff + 16) = quant8(du, scale);
+    }
+}
+
 }  // namespace rga3
 
 using namespace rga3;
@@ -334,5 +436,20 @@ extern "C" int rga3_gemm_fp8(const void* Aq, const void* Wq, const float* sa, co
     }
     hipLaunchKernelGGL(gemm_fp8_pp_kernel, dim3((unsigned)(a.ntm * a.ntn)), dim3(512), LDS, (hipStream_t)stream, a);
     RGA3_CHECK_LAUNCH("gemm_fp8_pp_kernel");
+    return 0;
+}
+
+extern "C" int rga3_swiglu_fwd_quant_fp8(const void* gu, void* q, float* scales, int64_t T, int64_t I, void* stream) {
+    RGA3_CHECK_ARG(gu && q && scales && T > 0 && T <= 0x7fffffff && I > 0 && I % 16 == 0, "swiglu_fwd_quant_fp8: T=%ld I=%ld", (long)T, (long)I);
+    hipLaunchKernelGGL(swiglu_fwd_quant_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)gu, (unsigned char*)q, scales, (long)I);
+    RGA3_CHECK_LAUNCH("swiglu_fwd_quant_kernel");
+    return 0;
+}
+
+extern "C" int rga3_swiglu_bwd_quant_fp8(const void* gu, const void* da, void* q, float* scales, int64_t T, int64_t I, void* stream) {
+    RGA3_CHECK_ARG(gu && da && q && scales && T > 0 && T <= 0x7fffffff && I > 0 && I % 16 == 0, "swiglu_bwd_quant_fp8: T=%ld I=%ld", (long)T, (long)I);
+    hipLaunchKernelGGL(swiglu_bwd_quant_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)gu, (const unsigned short*)da,
+                       (unsigned char*)q, scales, (long)I);
+    RGA3_CHECK_LAUNCH("swiglu_bwd_quant_kernel");
     return 0;
 }

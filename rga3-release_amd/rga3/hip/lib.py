@@ -47,6 +47,8 @@ SIGNATURES = {
     "rga3_gemm_stream_k_timeouts": [_p],
     "rga3_quant_fp8_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "rga3_gemm_fp8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "rga3_swiglu_fwd_quant_fp8": [_p, _p, _p, _i64, _i64, _p],
+    "rga3_swiglu_bwd_quant_fp8": [_p, _p, _p, _p, _i64, _i64, _p],
     "rga3_im2col3x3s2": [_p, _p, _i64, _i, _i, _i, _p],
     "rga3_pil_bicubic_coeffs": [_i, _i, _p, _p, _i64, _p],
     "rga3_sam_preprocess_u8": [_p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],

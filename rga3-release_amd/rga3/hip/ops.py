@@ -478,6 +478,28 @@ def gemm_fp8(aq, sa, wq, sw, bias=None, residual=None, out=None):
     return out
 
 
+def swiglu_fwd_quant(gu):
+    """(e4m3 [T, I], scales [T]) of silu(gate) * up, as quant_fp8_rows(swiglu_fwd(gu)) gives them, without the bf16 tensor in between."""
+    _need_cuda(gu)
+    assert gu.dtype == torch.bfloat16 and gu.is_contiguous() and gu.shape[1] % 32 == 0
+    T, I = gu.shape[0], gu.shape[1] // 2
+    q = torch.empty((T, I), dtype=torch.uint8, device=gu.device)
+    sc = torch.empty((T,), dtype=torch.float32, device=gu.device)
+    _lib.check(_lib.load().rga3_swiglu_fwd_quant_fp8(gu.data_ptr(), q.data_ptr(), sc.data_ptr(), T, I, _stream()), "swiglu_fwd_quant_fp8")
+    return q, sc
+
+
+def swiglu_bwd_quant(gu, da):
+    """(e4m3 [T, 2I], scales [T]) of the SwiGLU backward, as quant_fp8_rows(swiglu_bwd(gu, da)) gives them."""
+    _need_cuda(gu, da)
+    assert gu.dtype == da.dtype == torch.bfloat16 and gu.is_contiguous() and da.is_contiguous() and gu.shape[1] == 2 * da.shape[1]
+    T, I = da.shape
+    q = torch.empty((T, 2 * I), dtype=torch.uint8, device=gu.device)
+    sc = torch.empty((T,), dtype=torch.float32, device=gu.device)
+    _lib.check(_lib.load().rga3_swiglu_bwd_quant_fp8(gu.data_ptr(), da.data_ptr(), q.data_ptr(), sc.data_ptr(), T, I, _stream()), "swiglu_bwd_quant_fp8")
+    return q, sc
+
+
 def dropout(x, p: float, seed: int, out=None, accumulate: bool = False):
     """out = (accumulate ? out : 0) + dropout(x) with the counter-hash mask of (seed, element index); x bf16 contiguous, numel % 8 == 0."""
     _need_cuda(x, out)

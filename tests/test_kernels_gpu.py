@@ -303,6 +303,24 @@ def test_fp8_quant_and_gemm(dev, M, N, K):
     assert _rel_l2(plain, full) < 6e-2           # two e4m3 operands: ~2^-4 relative per element, averaged over K
 
 
+@pytest.mark.parametrize("T,I", [(37, 512), (200, 18944), (3, 32)])
+def test_swiglu_quant_fused_equals_unfused(dev, T, I):
+    """rga3_swiglu_{fwd,bwd}_quant_fp8 == swiglu_{fwd,bwd} followed by quant_fp8_rows, bit for bit (codes and scales), incl. a zero row and an outlier row."""
+    from rga3.hip import ops
+
+    gu = _rand((T, 2 * I), dev, 1.5, seed=41)
+    da = _rand((T, I), dev, 0.7, seed=42)
+    gu[1] = 0
+    da[1] = 0
+    gu[2, 5] = 30.0
+    q0, s0 = ops.quant_fp8_rows(ops.swiglu_fwd(gu))
+    q1, s1 = ops.swiglu_fwd_quant(gu)
+    assert torch.equal(s0, s1) and torch.equal(q0, q1)
+    q2, s2 = ops.quant_fp8_rows(ops.swiglu_bwd(gu, da))
+    q3, s3 = ops.swiglu_bwd_quant(gu, da)
+    assert torch.equal(s2, s3) and torch.equal(q2, q3)
+
+
 @pytest.mark.parametrize("M,N,K,f32", [(256, 256, 65536, False), (32, 256, 131072, True), (300, 520, 16384, False), (64, 64, 4096, False), (700, 256, 2048, False)])
 def test_gemm_split_k_small_outputs(dev, M, N, K, f32):
     """Tile 25 (few tiles, huge K: the weight-gradient products): slices summed in f32 slabs by the reduce kernel; with bias and f32 output."""

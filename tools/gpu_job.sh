@@ -1,9 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py"
-RGA3_TUNE_SAVE=$O/r2l_tuner_forward.json $B --mode forward --steps 10 --warmup 3 --no-cpu-baseline > $O/r2l_fwd.json 2> $O/r2l_fwd.err
-export RGA3_TUNE_LOAD=$O/r2l_tuner_forward.json RGA3_BENCH_TIMED_ONLY=1
-rm -rf /tmp/p2; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -o fwd -- $B --mode forward --steps 20 --warmup 3 --no-refine --no-cpu-baseline > $O/r2l_prof_forward.log 2>&1
-cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $O/r2l_forward_kernel_stats.csv
-head -30 $O/r2l_forward_kernel_stats.csv | cut -c1-230
+cd $R && export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_qwen_gpu.py -q -m gpu -x 2>&1 | tail -5 | cut -c1-300
+timeout 300 python tools/attn_rates.py 2>&1 | grep -v amdgpu.ids
+timeout 600 python bench.py --mode forward --steps 20 --warmup 5 --no-cpu-baseline > $O/r2m_fwd.json 2> $O/r2m_fwd.err; python3 -c "
+import json;d=json.loads(open('$O/r2m_fwd.json').read().strip().splitlines()[-1]);print('FWD',d['ms_per_step'],d['roofline']['whole_forward_frac'],d['roofline']['frac'],d['roofline']['gemm_ms_per_step'])"
+RGA3_BENCH_SHARE_GPU=1 RGA3_BENCH_BACKEND=gloo timeout 1200 python bench.py --gpus 2 --mode train_full --steps 2 --warmup 1 --no-cpu-baseline > $O/r2m_two_ranks.json 2> $O/r2m_two_ranks.err; tail -c 1500 $O/r2m_two_ranks.json; tail -12 $O/r2m_two_ranks.err | cut -c1-300
