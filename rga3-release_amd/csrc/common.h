@@ -59,6 +59,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// SwiGLU element arithmetic shared by the plain kernels (trainops.hip) and the ones with the e4m3 quantiser fused in (gemm_fp8.hip): one definition,
+// contraction off, so both produce the same bits.
+__device__ __forceinline__ float swiglu_fwd_elem(float g, float u) {
+#pragma clang fp contract(off)
+    const float silu = g / (1.f + __expf(-g));
+    return __uint_as_float(((unsigned)f2bf(silu)) << 16) * u;
+}
+__device__ __forceinline__ void swiglu_bwd_elem(float g, float u, float d, float& dg, float& du) {
+#pragma clang fp contract(off)
+    const float sg = 1.f / (1.f + __expf(-g));
+    const float silu = g * sg;
+    du = d * silu;
+    dg = d * u * sg * (1.f + g * (1.f - sg));
+}
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // number of XCDs on MI355X (MI355X_MICROARCH.md chip table); used only for speed (L2 affinity), never correctness

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_quant_kernel(const unsigned sh
         unpack8f(*(const u32x4*)(gr + goff), g);
         unpack8f(*(const u32x4*)(gr + goff + 16), u);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = bfround(bfround(g[e] / (1.f + __expf(-g[e]))) * u[e]);
+        for (int e = 0; e < 8; ++e) o[e] = bfround(swiglu_fwd_elem(g[e], u[e]));
     };
     float amax = 0.f;
     for (int ch = threadIdx.x; ch < nch; ch += 256) {
@@ -375,9 +375,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_quant_kernel(const unsigned sh
         unpack8f(*(const u32x4*)(dr + ch * 8), d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float sg = 1.f / (1.f + __expf(-g[e]));
-            du[e] = bfround(d[e] * (g[e] * sg));
-            dg[e] = bfround(d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg)));
+            swiglu_bwd_elem(g[e], u[e], d[e], dg[e], du[e]);
+            dg[e] = bfround(dg[e]);
+            du[e] = bfround(du[e]);
         }
     };
     float amax = 0.f;

@@ -81,12 +81,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const unsigned short* _
         un8(*(const u32x4*)(gu + goff + 16), u);
         un8(*(const u32x4*)(da + t * I + ch * 8), d);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float sg = 1.f / (1.f + __expf(-g[e]));
-            const float silu = g[e] * sg;
-            du[e] = d[e] * silu;
-            dg[e] = d[e] * u[e] * sg * (1.f + g[e] * (1.f - sg));
-        }
+        for (int e = 0; e < 8; ++e) swiglu_bwd_elem(g[e], u[e], d[e], dg[e], du[e]);
         *(u32x4*)(dgu + goff) = pk8_(dg);
         *(u32x4*)(dgu + goff + 16) = pk8_(du);
     }
@@ -105,10 +100,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const unsigned short* _
         un8(*(const u32x4*)(gu + goff), g);
         un8(*(const u32x4*)(gu + goff + 16), u);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float silu = g[e] / (1.f + __expf(-g[e]));
-            o[e] = __uint_as_float(((unsigned)f2bf(silu)) << 16) * u[e];
-        }
+        for (int e = 0; e < 8; ++e) o[e] = swiglu_fwd_elem(g[e], u[e]);
         *(u32x4*)(a + t * I + ch * 8) = pk8_(o);
     }
 }
