@@ -412,7 +412,7 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     const unsigned nqb = (unsigned)cdiv(max_q, BLOCK_M);
     // the paired-q-block form only for the long causal rows of the decoder (D = 64 / 128, 8 waves): elsewhere it would only
     // cost registers
-    if constexpr (NWAVE == 8 || (NWAVE == 4 && QT == 1 && (DP == 128 || DP == 64))) {
+    if constexpr (NWAVE == 8) {
         if (a.causal && nqb >= 4) return launch_attn_p<DP, QT, NWAVE, USE_TR, true>(a, nseg, (nqb + 1) / 2, st);
     }
     if (a.nsplit > 1) {
@@ -456,8 +456,7 @@ static int launch_dp(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     if constexpr (DP == 128 || DP == 64) {
         // long sequences: 8 waves x 16 query rows keeps the register footprint near 110 VGPRs (4 waves/SIMD) instead of
         // one 300-register wave per SIMD
-        // impl bit 2 (experiment): 64-row query blocks, 4 waves -- twice the workgroups (two per CU at S = 2112, drifting against each other)
-        if (max_q > 64 && g_attn_variant == 2) return launch_attn<DP, 1, 4, USE_TR>(a, nseg, max_q, st);
+        // (measured, round 2: 64-row paired query blocks on 4 waves -- twice the workgroups, two per CU at S = 2112 -- are slower: 73.8 vs 65.9 us)
         if (max_q > 64 && g_attn_variant != 1) return launch_attn<DP, 1, 8, USE_TR>(a, nseg, max_q, st);
     }
     if constexpr (DP == 96) {
@@ -502,8 +501,8 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
-    RGA3_CHECK_ARG(impl >= 0 && impl <= 7, "attn: impl %d", impl);
-    g_attn_variant = (impl & 4) ? 2 : ((impl & 2) ? 1 : 0);
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 3, "attn: impl %d", impl);
+    g_attn_variant = (impl & 2) ? 1 : 0;
     impl &= 1;
     AttnArgs a;
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
