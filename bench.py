@@ -123,7 +123,7 @@ def make_trainable(model, full, reducer_kw=None):
     trainables = [p for p in model.parameters() if p.requires_grad]
     sparse = [model.model.embed_tokens.weight] if model.model.embed_tokens.weight.requires_grad else []
     reducer = GradBucketReducer(trainables, bucket_mb=256.0, sparse_params=sparse, **(reducer_kw or {}))
-    opt = FusedAdamW(trainables, lr=4e-5, betas=(0.9, 0.95), weight_decay=0.0, max_grad_norm=1.0)
+    opt = FusedAdamW.for_reducer(reducer, lr=4e-5, betas=(0.9, 0.95), weight_decay=0.0, max_grad_norm=1.0)   # state laid out like the buckets: one launch per bucket
     return trainables, reducer, opt
 
 

@@ -95,6 +95,16 @@ class GradBucketReducer:
         (the clipping norm) can run once per bucket instead of once per tensor."""
         return list(self.flat) + [st["dense"].view(-1) for st in self._sp.values()]
 
+    def layout(self):
+        """[(flat gradient tensor, [(param, offset, numel), ...]), ...]: the buckets and the dense buffers of the sparse parameters.  FusedAdamW.for_reducer
+        lays its fp32 state (and the bf16 parameters themselves) out the same way, so the optimizer is one launch per bucket instead of one per tensor."""
+        out = []
+        for bi, b in enumerate(self.buckets):
+            out.append((self.flat[bi], [(p, self.slices[p][1], p.numel()) for p in b]))
+        for st in self._sp.values():
+            out.append((st["dense"].view(-1), [(st["p"], 0, st["p"].numel())]))
+        return out
+
     # ---------------------------------------------------------------------------------------------- dense buckets
     def _on_grad(self, p):
         bi, off, n = self.slices[p]
@@ -317,17 +327,51 @@ class FusedAdamW:
     clipping folded into the kernel's gradient scale (train_joint.py:300-324: lr 4e-5, betas (0.9, 0.95), wd 0, clip 1.0).  The clipping norm
     never visits the host: a deterministic two-stage sum of squares leaves it in device memory and the update kernel derives its scale from it."""
 
-    def __init__(self, params, lr=4e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, schedule: WarmupCosineLR = None):
+    def __init__(self, params, lr=4e-5, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, schedule: WarmupCosineLR = None, layout=None):
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.schedule = schedule
-        self.master = [p.detach().float().clone() for p in self.params]
-        self.m = [torch.zeros_like(x) for x in self.master]
-        self.v = [torch.zeros_like(x) for x in self.master]
+        self._flat = None
+        if layout is not None:
+            self._init_flat(layout)
+        else:
+            self.master = [p.detach().float().clone() for p in self.params]
+            self.m = [torch.zeros_like(x) for x in self.master]
+            self.v = [torch.zeros_like(x) for x in self.master]
         self.t = 0
         dev = self.params[0].device
         self._acc = torch.zeros(1, dtype=torch.float32, device=dev)
         self._partials = torch.zeros(2048, dtype=torch.float32, device=dev)
+
+    @classmethod
+    def for_reducer(cls, reducer: "GradBucketReducer", **kw):
+        """Optimizer state laid out like the reducer's gradient buckets: ONE AdamW launch per bucket.  (Per-tensor launches left the GPU idle between the
+        ~130 small kernels of a step: the host needs ~20 us per launch, a LoRA factor's update takes 3 us -- 2.9 ms of a 170 ms step.)  The bf16 parameters of a
+        multi-tensor bucket are re-pointed at slices of one flat buffer (values unchanged), as DDP / FSDP flat parameters are."""
+        return cls(reducer.all_params, layout=reducer.layout(), **kw)
+
+    def _init_flat(self, layout):
+        order = {id(p): i for i, p in enumerate(self.params)}
+        self.master, self.m, self.v = [None] * len(self.params), [None] * len(self.params), [None] * len(self.params)
+        self._flat = []
+        with torch.no_grad():
+            for flat_g, items in layout:
+                n = flat_g.numel()
+                dev = flat_g.device
+                if len(items) == 1 and items[0][1] == 0 and items[0][2] == n and items[0][0].is_contiguous():
+                    flat_p = items[0][0].data.view(-1)                      # a bucket that IS one tensor (embed_tokens, lm_head): no copy
+                else:
+                    flat_p = torch.zeros(n, dtype=flat_g.dtype, device=dev)
+                    for p, off, k in items:
+                        flat_p[off:off + k].copy_(p.data.reshape(-1))
+                        p.data = flat_p[off:off + k].view(p.shape)
+                fm = flat_p.float()
+                fmm, fv = torch.zeros_like(fm), torch.zeros_like(fm)
+                self._flat.append((flat_p, fm, flat_g, fmm, fv))
+                for p, off, k in items:
+                    i = order[id(p)]
+                    self.master[i], self.m[i], self.v[i] = fm[off:off + k].view(p.shape), fmm[off:off + k].view(p.shape), fv[off:off + k].view(p.shape)
+        assert all(x is not None for x in self.master), "layout does not cover every trainable parameter"
 
     def current_lr(self) -> float:
         return self.lr * self.schedule.scale_at(self.t) if self.schedule is not None else self.lr
@@ -370,8 +414,17 @@ class FusedAdamW:
 
         lr = self.current_lr()
         self.t += 1
-        grads = [grad_of(p).contiguous() for p in self.params]
         clip = self.max_norm is not None
+        if self._flat is not None:   # one launch per bucket (gradients are the reducer's flat buckets themselves)
+            if clip:
+                for i, (_, _, g, _, _) in enumerate(self._flat):
+                    ops.sumsq_det_(g, self._partials, self._acc, accumulate=i > 0)
+            for fp, fm, g, mm, vv in self._flat:
+                ops.adamw_step_clip_(fp, fm, g, mm, vv, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self._acc if clip else None,
+                                     self.max_norm if clip else 0.0)
+            self._bump_versions()
+            return
+        grads = [grad_of(p).contiguous() for p in self.params]
         if clip:
             first = True
             for g in (flat_grads if flat_grads is not None else grads):
@@ -380,3 +433,10 @@ class FusedAdamW:
         for p, w, g, m, v in zip(self.params, self.master, grads, self.m, self.v):
             ops.adamw_step_clip_(p.data, w, g, m, v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                  self._acc if clip else None, self.max_norm if clip else 0.0)
+        self._bump_versions()
+
+    def _bump_versions(self):
+        """The update kernels write the parameters through raw pointers; derived tensors cached by (data_ptr, version) elsewhere (the ConvTranspose weight
+        packs of the mask decoder's inference path, captured decode graphs) must see that the values changed."""
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)

@@ -419,3 +419,37 @@ def test_embedding_gradient_through_sparse_sink_equals_dense(dev):
         assert torch.allclose(a, b, atol=2e-2, rtol=2e-2)     # accumulation across micro-steps rounds at different points (bf16 add vs bf16 add of sums)
         assert torch.equal(a != 0, b != 0)
     assert float(sparse[1].abs().sum()) < float(sparse[0].abs().sum())
+
+
+def test_bucket_layout_optimizer_equals_per_tensor(dev):
+    """FusedAdamW.for_reducer (state laid out like the gradient buckets, one launch per bucket, parameters re-pointed at slices of a flat buffer) gives the
+    same parameters, masters and moments as the per-tensor optimizer, over two steps with clipping; parameter versions are bumped so caches keyed on them refresh."""
+    from rga3.parallel.ddp import FusedAdamW, GradBucketReducer
+
+    shapes = [(64, 40), (130,), (17, 9), (256, 128), (8,)]
+
+    def make():
+        torch.manual_seed(4)
+        return [torch.nn.Parameter((torch.randn(*s, device=dev) * 0.3).to(torch.bfloat16)) for s in shapes]
+
+    res = []
+    for flat in (False, True):
+        ps = make()
+        red = GradBucketReducer(ps, bucket_mb=0.01)
+        opt = FusedAdamW.for_reducer(red, lr=1e-2, betas=(0.9, 0.95), max_grad_norm=1.0) if flat else FusedAdamW(ps, lr=1e-2, betas=(0.9, 0.95), max_grad_norm=1.0)
+        v0 = [p._version for p in ps]
+        for step in range(2):
+            torch.manual_seed(10 + step)
+            red.begin_step()
+            red.begin_micro_step()
+            for p in ps:
+                p.grad = (torch.randn(p.shape, device=dev) * 2.0).to(torch.bfloat16)
+                red._on_grad(p)
+            red.finish()
+            opt.step(red.grad_view, red.flat_grads())
+        assert all(p._version > v for p, v in zip(ps, v0))
+        res.append(([p.detach().float().clone() for p in ps], [w.clone() for w in opt.master], [m.clone() for m in opt.m], float(opt.grad_norm())))
+        red.remove()
+    for a, b in zip(res[0][0] + res[0][1] + res[0][2], res[1][0] + res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
+    assert abs(res[0][3] - res[1][3]) <= 1e-5 * res[0][3]
