@@ -112,7 +112,13 @@ class GradBucketReducer:
             if p in self._written:   # a later micro-step of the same optimizer step accumulates
                 self.flat[bi][off:off + n].add_(p.grad.reshape(-1))
             else:
-                self.flat[bi][off:off + n].copy_(p.grad.reshape(-1))
+                g = p.grad.reshape(-1)
+                if g.is_cuda and g.dtype == self.flat[bi].dtype:
+                    # an elementwise kernel, not copy_(): a device-to-device copy_ goes through hipMemcpyAsync, whose blit dispatch left the GPU idle
+                    # ~37 us after each of the ~105 gradient copies of a step (rocprofv3 timeline, tools/trace_gaps.py)
+                    torch.mul(g, 1, out=self.flat[bi][off:off + n])
+                else:
+                    self.flat[bi][off:off + n].copy_(g)
                 self._written.add(p)
             p.grad = None  # the bucket slice is the gradient from here on (no second copy kept)
         self.pending[bi] -= 1
@@ -165,7 +171,8 @@ class GradBucketReducer:
                 self._exchange_sparse(st)
         else:   # a local-only step (finish() under no_sync): nothing is exchanged; the rows touched are still remembered for the clean-up
             for st in self._sp.values():
-                st["last_ids"] = torch.from_numpy(st["union"]).to(st["dense"].device)
+                mine = st.get("dev_ids") or []
+                st["last_ids"] = mine[0] if len(mine) == 1 and mine[0].numel() == st["union"].size else torch.from_numpy(st["union"]).to(st["dense"].device)
         for bi, h in self.handles:
             h.wait()
             if not self._avg and self.world > 1:
@@ -184,6 +191,7 @@ class GradBucketReducer:
                 d[st["last_ids"]] = 0
         st["last_ids"] = None
         st["union"] = np.zeros(0, dtype=np.int64)
+        st["dev_ids"] = []
 
     def announce_sparse(self, p, uniq_ids_np):
         """Forward of a micro-step: the rows this rank will contribute are known on the host.  The size of the running union is exchanged now, on a
@@ -215,12 +223,16 @@ class GradBucketReducer:
         """Backward of a micro-step: accumulate (unique row ids, summed rows) of this rank into the dense buffer."""
         st = self._sp[id(p)]
         _scatter_add(st["dense"], ids_dev, rows, 1.0)
+        st.setdefault("dev_ids", []).append(ids_dev)
 
     def _exchange_sparse(self, st):
         d = st["dense"]
         dev = d.device
         ids_np = st["union"]
-        ids = torch.from_numpy(ids_np).to(dev)
+        mine = st.get("dev_ids") or []
+        # the union of this step's row ids on the device: with one micro-step it is the tensor backward handed over (an upload of the host copy would be a
+        # stream sync at the end of backward, with the optimizer's launches still to be issued)
+        ids = mine[0] if len(mine) == 1 and mine[0].numel() == ids_np.size else torch.from_numpy(ids_np).to(dev)
         if self.world == 1:
             st["last_ids"] = ids
             self.sparse_bytes_last = 0
