@@ -70,6 +70,7 @@ class GradBucketReducer:
                 off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
             self.flat.append(torch.zeros(off, dtype=b[0].dtype, device=b[0].device))
             self.pending.append(len(b))
+        self._view = {p: self.flat[self.slices[p][0]][self.slices[p][1]:self.slices[p][1] + self.slices[p][2]] for p in self.params}   # built once: the hook runs ~300 times per step
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._nccl = self.world > 1 and dist.get_backend(process_group) == "nccl"
         self._avg = self._nccl
@@ -107,22 +108,25 @@ class GradBucketReducer:
 
     # ---------------------------------------------------------------------------------------------- dense buckets
     def _on_grad(self, p):
-        bi, off, n = self.slices[p]
-        if p.grad is not None:   # (a graphed backward hands an undefined gradient to parameters its forward never used: nothing to add)
+        g = p.grad
+        if g is not None:   # (a graphed backward hands an undefined gradient to parameters its forward never used: nothing to add)
+            view = self._view[p]
+            g = g.reshape(-1)
             if p in self._written:   # a later micro-step of the same optimizer step accumulates
-                self.flat[bi][off:off + n].add_(p.grad.reshape(-1))
+                view.add_(g)
             else:
-                g = p.grad.reshape(-1)
-                if g.is_cuda and g.dtype == self.flat[bi].dtype:
+                if g.is_cuda and g.dtype == view.dtype:
                     # an elementwise kernel, not copy_(): a device-to-device copy_ goes through hipMemcpyAsync, whose blit dispatch left the GPU idle
                     # ~37 us after each of the ~105 gradient copies of a step (rocprofv3 timeline, tools/trace_gaps.py)
-                    torch.mul(g, 1, out=self.flat[bi][off:off + n])
+                    torch.mul(g, 1, out=view)
                 else:
-                    self.flat[bi][off:off + n].copy_(g)
+                    view.copy_(g)
                 self._written.add(p)
             p.grad = None  # the bucket slice is the gradient from here on (no second copy kept)
+        bi = self.slices[p][0]
         self.pending[bi] -= 1
-        self._launch_ready()
+        if self.pending[bi] == 0:
+            self._launch_ready()
 
     def _launch_ready(self):
         """Launch, in index order, every bucket whose gradients are all in: bucket i never goes out before bucket i-1 (rank-independent order)."""
@@ -159,10 +163,10 @@ class GradBucketReducer:
     def finish(self):
         """Launch what backward left (buckets holding a parameter without a gradient on this rank: their untouched slices are zeroed first), exchange
         the sparse rows, wait for everything; afterwards grad_view(p) holds the averaged gradient."""
-        for p in self.params:    # a parameter without a gradient in this step must not hand last step's slice to the optimizer
-            if p not in self._written:
-                bi, off, n = self.slices[p]
-                self.flat[bi][off:off + n].zero_()
+        if len(self._written) != len(self.params):
+            for p in self.params:    # a parameter without a gradient in this step must not hand last step's slice to the optimizer
+                if p not in self._written:
+                    self._view[p].zero_()
         if self.sync:
             while self._next < len(self.buckets):
                 self._launch(self._next)
