@@ -228,15 +228,28 @@ int rga3_scatter_add_rows(void* dst, const int64_t* idx, const void* src, int64_
 
 /* ---- mask-path backward (trainable sam_mask_decoder + text_hidden_fcs, train_joint.py:237-251) ---------------- */
 
-/* LayerNorm backward: dx (bf16) and, if non-NULL, f32 accumulators dweight/dbias += (atomics); model/sam2.py:1364-1376,2334-2346 */
+/* LayerNorm backward: dx (bf16) and, if non-NULL, the f32 parameter gradients; model/sam2.py:1364-1376,2334-2346.
+   dim in {16,32,64,128,256,512}: dweight / dbias are WRITTEN, summed deterministically through `ws` (rga3_layernorm_bwd_ws_floats() f32 elements);
+   other widths (multiples of 8 up to 2048): dweight / dbias += by f32 atomics into buffers the caller zeroes, ws unused. */
+int64_t rga3_layernorm_bwd_ws_floats(int64_t rows, int64_t dim);
 int rga3_layernorm_bwd(const void* x, const void* weight, const void* dy, void* dx, float* dweight, float* dbias, int64_t rows, int64_t dim,
-                       float eps, void* stream);
-/* out[c] += sum_r x[r,c] (bias gradients) */
+                       float eps, float* ws, int64_t ws_floats, void* stream);
+/* out[c] += sum_r x[r,c] (bias gradients; any width, f32 atomics) */
 int rga3_colsum_accum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* stream);
+/* out[c] = sum_r x[r,c], written, deterministic two-stage sum; cols and ld multiples of 8, 16-byte aligned x; ws: rga3_colsum_ws_floats() f32 elements */
+int64_t rga3_colsum_ws_floats(int64_t rows, int64_t cols);
+int rga3_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, float* ws, int64_t ws_floats, void* stream);
 /* kind 0: out = gelu(a); kind 1: out = dy * gelu'(a) (a = pre-activation); kind 2: out = dy * (a > 0) (a = relu output) */
 int rga3_act(const void* a, const void* dy, void* out, int64_t n, int kind, void* stream);
-/* backward of rga3_bilinear into a pre-zeroed f32 input gradient (atomic adds) */
+/* backward of rga3_bilinear (gather form): plane_idx == NULL -> every element of din is written; with plane_idx -> one f32 atomic add per input pixel into
+   the pre-zeroed plane plane_idx[n] (deterministic for distinct indices) */
 int rga3_bilinear_bwd(const float* dout, float* din, const int32_t* plane_idx, int64_t N, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* mask logits of all frames at once, model/sam2.py:2142-2149: masks[b,m,p] = sum_c hyper[b,m,c] up[b*P+p,c]; hyper [B,4,C] bf16, up [B*P,C] bf16 (C = 8/16/32),
+   masks [B,4,P] f32.  Backward: dup [B*P,C] bf16, dhyper [B,4,C] bf16 from f32 dmasks; ws: rga3_mask_product_bwd_ws_floats() f32 elements */
+int rga3_mask_product(const void* hyper, const void* up, float* masks, int64_t B, int64_t NM, int64_t P, int64_t C, void* stream);
+int64_t rga3_mask_product_bwd_ws_floats(int64_t B, int64_t NM, int64_t P, int64_t C);
+int rga3_mask_product_bwd(const float* dmasks, const void* hyper, const void* up, void* dup, void* dhyper, int64_t B, int64_t NM, int64_t P, int64_t C,
+                          float* ws, int64_t ws_floats, void* stream);
 /* backward of rga3_pixel_shuffle2x w.r.t. the GEMM output */
 int rga3_pixel_shuffle2x_bwd(const void* dout, void* dg, int64_t F, int H, int W, int Co, void* stream);
 /* dlogits = coef_bce * d(sum_n mean BCE) + coef_dice * d(sum_n dice_n) (model/qwen_2_5_vl_sam2.py:17-60) from the forward sums */

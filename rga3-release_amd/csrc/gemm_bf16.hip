@@ -1449,13 +1449,13 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     TnArgs t;
     t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
     const int nk = (int)cdiv(K, 32);
-    // few output tiles over many tokens (LoRA dW: 1 x 28 tiles, K = 2112 / 4160): cut K into Z slices, one workgroup each, f32 partial slabs in
+    // few output tiles over many tokens (LoRA dW: 1 x 28 tiles, K = 2112 / 4160; mask-path dW: 1-4 tiles, K = 65 536 ..): cut K into Z slices, one workgroup each, f32 partial slabs in
     // the caller's workspace, summed in fixed order by a second launch (deterministic; no atomics)
     int Z = 1;
     const long tiles = (long)a.ntm * a.ntn;
     if (workspace && !bias && tiles < 128 && nk >= 32) {
         Z = (int)(256 / tiles);
-        if (Z > 16) Z = 16;
+        if (Z > 64) Z = 64;   // (16 until round 2: per-pixel weight gradients of the mask path, 1-4 tiles over 65 536 - 262 144 rows, filled 64 CUs)
         if (Z > nk / 8) Z = nk / 8;
         const long fit = workspace_bytes / (M * N * 4);
         if (Z > fit) Z = (int)fit;

@@ -32,10 +32,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             da = ops.gemm(dy, ops.transpose(w.detach()))            # [M, K] = dy @ w   (ops.gemm pads ragged reduction dims)
         if ctx.needs_input_grad[1]:
-            if dy.shape[0] <= 16384:
-                dw = ops.gemm_tn(dy, a.detach()).to(w.dtype)                              # [N, K] = dy^T @ a, contraction over rows as they lie
-            else:   # per-pixel products (10^6 rows): transposed operands + the split-K tiling
-                dw = ops.gemm(ops.transpose(dy), ops.transpose(a.detach())).to(w.dtype)
+            dw = ops.gemm_tn(dy, a.detach()).to(w.dtype)    # [N, K] = dy^T @ a, contraction over rows as they lie (per-pixel products: up to 64 K-slices)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy).to(torch.bfloat16)
         return da, dw, db, dres, None, None
@@ -149,6 +146,23 @@ class BilinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return ops.bilinear_bwd(dy.contiguous().float(), ctx.in_shape, ctx.plane_idx), None, None
+
+
+class MaskProductFn(torch.autograd.Function):
+    """masks [B, 4, P] f32 = hyper [B, 4, C] x up [B * P, C]^T per frame (reference model/sam2.py:2142-2149), all frames in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, hyper, up, P):
+        hyper, up = hyper.contiguous(), up.contiguous()
+        ctx.P = P
+        ctx.save_for_backward(hyper, up)
+        return ops.mask_product(hyper, up, P)
+
+    @staticmethod
+    def backward(ctx, dm):
+        hyper, up = ctx.saved_tensors
+        dhyper, dup = ops.mask_product_bwd(dm.float().contiguous(), hyper, up, ctx.P)
+        return dhyper, dup, None
 
 
 class MaskLossFn(torch.autograd.Function):

@@ -65,14 +65,22 @@ SIGNATURES = {
     "rga3_sumsq_det": [_p, _i64, _p, _i64, _p, _i, _p],
     "rga3_adamw_step_clip": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p, _f, _p],
     "rga3_scatter_add_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
-    "rga3_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _p],
+    "rga3_layernorm_bwd_ws_floats": [_i64, _i64],
+    "rga3_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _p, _i64, _p],
     "rga3_colsum_accum": [_p, _p, _i64, _i64, _i64, _p],
+    "rga3_colsum_ws_floats": [_i64, _i64],
+    "rga3_colsum": [_p, _p, _i64, _i64, _i64, _p, _i64, _p],
     "rga3_act": [_p, _p, _p, _i64, _i, _p],
     "rga3_bilinear_bwd": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
+    "rga3_mask_product": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "rga3_mask_product_bwd_ws_floats": [_i64, _i64, _i64, _i64],
+    "rga3_mask_product_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p],
     "rga3_pixel_shuffle2x_bwd": [_p, _p, _i64, _i, _i, _i, _p],
     "rga3_bce_dice_grad": [_p, _p, _p, _p, _i64, _i64, _f, _f, _p],
     "rga3_bce_dice_grad_dev": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p],
 }
+
+_INT64_RESULTS = ("rga3_gemm_workspace_bytes", "rga3_layernorm_bwd_ws_floats", "rga3_colsum_ws_floats", "rga3_mask_product_bwd_ws_floats")
 
 _lib = None
 
@@ -102,7 +110,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name == "rga3_gemm_workspace_bytes" else C.c_int
+        fn.restype = C.c_int64 if name in _INT64_RESULTS else C.c_int
     _lib = lib
     return lib
 

@@ -125,8 +125,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == out_dtype
     ws = None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles < 128 and K >= 1024:      # few output tiles over many tokens: give the kernel room to split K (<= 16 f32 slabs)
-        ws = torch.empty((min(16, 256 // tiles) * M * N,), dtype=torch.float32, device=a.device)
+    if tiles < 128 and K >= 1024:      # few output tiles over many tokens: give the kernel room to split K (<= 64 f32 slabs)
+        ws = torch.empty((min(64, 256 // tiles, max(2, K // 256)) * M * N,), dtype=torch.float32, device=a.device)
     _lib.check(_lib.load().rga3_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                                              BF16 if out_dtype == torch.bfloat16 else F32, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
                "gemm_tn_bf16")
@@ -607,13 +607,21 @@ def check_gemm_health(device=None):
 def layernorm_bwd(x, weight, dy, eps: float, want_param_grads=True):
     _need_cuda(x, weight, dy)
     assert x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype == torch.bfloat16
+    L = _lib.load()
     dx = torch.empty_like(x)
-    dw = db = None
+    dw = db = ws = None
+    nws = 0
     if want_param_grads:
-        dw = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
-        db = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rga3_layernorm_bwd(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), x.shape[0], x.shape[1],
-                                              float(eps), _stream()), "layernorm_bwd")
+        nws = int(L.rga3_layernorm_bwd_ws_floats(x.shape[0], x.shape[1]))
+        if nws:      # deterministic path: gradients are written
+            dw = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+            db = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        else:        # generic widths accumulate with atomics
+            dw = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+            db = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(L.rga3_layernorm_bwd(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), x.shape[0], x.shape[1],
+                                    float(eps), _ptr(ws), nws, _stream()), "layernorm_bwd")
     return dx, dw, db
 
 
@@ -621,9 +629,43 @@ def colsum(x):
     """f32 column sums of a bf16 [rows, cols] tensor (row stride free)."""
     _need_cuda(x)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
-    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rga3_colsum_accum(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0), _stream()), "colsum_accum")
+    L = _lib.load()
+    rows, cols = x.shape
+    if cols % 8 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:   # two-stage deterministic sum
+        nws = int(L.rga3_colsum_ws_floats(rows, cols))
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+        _lib.check(L.rga3_colsum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), ws.data_ptr(), nws, _stream()), "colsum")
+        return out
+    out = torch.zeros(cols, dtype=torch.float32, device=x.device)
+    _lib.check(L.rga3_colsum_accum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), _stream()), "colsum_accum")
     return out
+
+
+def mask_product(hyper, up, P: int):
+    """masks[b, m, p] = sum_c hyper[b, m, c] * up[b * P + p, c]; hyper [B, 4, C] bf16, up [B * P, C] bf16 -> [B, 4, P] f32 (all frames in one launch)."""
+    _need_cuda(hyper, up)
+    assert hyper.dtype == up.dtype == torch.bfloat16 and hyper.is_contiguous() and up.is_contiguous() and hyper.dim() == 3 and up.dim() == 2
+    B, NM, C = hyper.shape
+    assert up.shape == (B * P, C)
+    masks = torch.empty((B, NM, P), dtype=torch.float32, device=up.device)
+    _lib.check(_lib.load().rga3_mask_product(hyper.data_ptr(), up.data_ptr(), masks.data_ptr(), B, NM, P, C, _stream()), "mask_product")
+    return masks
+
+
+def mask_product_bwd(dmasks, hyper, up, P: int):
+    """-> (dhyper [B, 4, C] bf16, dup [B * P, C] bf16) from f32 dmasks [B, 4, P]."""
+    _need_cuda(dmasks, hyper, up)
+    assert dmasks.dtype == torch.float32 and dmasks.is_contiguous() and hyper.is_contiguous() and up.is_contiguous()
+    B, NM, C = hyper.shape
+    L = _lib.load()
+    nws = int(L.rga3_mask_product_bwd_ws_floats(B, NM, P, C))
+    ws = torch.empty(nws, dtype=torch.float32, device=up.device)
+    dup = torch.empty_like(up)
+    dhyper = torch.empty_like(hyper)
+    _lib.check(L.rga3_mask_product_bwd(dmasks.data_ptr(), hyper.data_ptr(), up.data_ptr(), dup.data_ptr(), dhyper.data_ptr(), B, NM, P, C, ws.data_ptr(), nws,
+                                       _stream()), "mask_product_bwd")
+    return dhyper, dup
 
 
 def gelu(x):
@@ -646,7 +688,8 @@ def act_bwd(a, dy, kind: str):
 def bilinear_bwd(dout, in_shape, plane_idx=None):
     _need_cuda(dout, plane_idx)
     assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.dim() == 3
-    din = torch.zeros(in_shape, dtype=torch.float32, device=dout.device)
+    # without plane_idx the gather kernel writes every element; with it the atomic form adds into zeros
+    din = (torch.empty if plane_idx is None else torch.zeros)(in_shape, dtype=torch.float32, device=dout.device)
     _lib.check(_lib.load().rga3_bilinear_bwd(dout.data_ptr(), din.data_ptr(), _ptr(plane_idx), dout.shape[0], in_shape[1], in_shape[2], dout.shape[1],
                                              dout.shape[2], _stream()), "bilinear_bwd")
     return din

@@ -468,7 +468,7 @@ class MaskDecoder(nn.Module):
             g2 = AG.linear(up, dc2.as_linear_grad())
             up = AG.GeluFn.apply(AG.PixelShuffleFn.apply(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w))
             hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)
-            masks = torch.stack([AG.linear(hyper[b].contiguous(), up[b * npx:(b + 1) * npx], out_f32=True).view(4, 4 * h, 4 * w) for b in range(B)], dim=0)
+            masks = AG.MaskProductFn.apply(hyper, up, npx).view(B, 4, 4 * h, 4 * w)
             if _DEBUG is not None:   # tools/grad_locate.py: keep the gradients of the head's intermediates
                 _DEBUG.update(hs=hs, src=src, up=up, hyper=hyper, masks=masks, tokens=tokens)
                 for t_ in (hs, src, up, hyper, masks, tokens):
@@ -481,9 +481,7 @@ class MaskDecoder(nn.Module):
             g2 = ops.gemm(up, dc2.as_linear())
             up = ops.pixel_shuffle2x(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w, act="gelu")          # [B*16hw, C/8]
             hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)  # [B, 4, C/8]
-            masks = torch.empty((B, 4, 4 * h, 4 * w), dtype=torch.float32, device=src.device)
-            for b in range(B):  # masks[b] = hyper[b] @ up[b]^T : planes come out row-major, f32
-                ops.gemm(hyper[b].contiguous(), up[b * npx:(b + 1) * npx], out_dtype=torch.float32, out=masks[b].view(4, npx))
+            masks = ops.mask_product(hyper.contiguous(), up, npx).view(B, 4, 4 * h, 4 * w)   # masks[b] = hyper[b] @ up[b]^T, planes row-major, f32
         iou = self.iou_prediction_head(iou_tok.contiguous())
         obj = self.pred_obj_score_head(hs[:, 0].contiguous())
         return masks, iou, mask_toks, obj

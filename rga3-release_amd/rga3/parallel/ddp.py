@@ -63,6 +63,7 @@ class GradBucketReducer:
         if cur:
             self.buckets.append(cur)
         self.flat, self.slices, self.pending, self.handles = [], {}, [], []
+        self._stash = [[] for _ in self.buckets]
         for bi, b in enumerate(self.buckets):
             off = 0
             for p in b:
@@ -109,24 +110,41 @@ class GradBucketReducer:
     # ---------------------------------------------------------------------------------------------- dense buckets
     def _on_grad(self, p):
         g = p.grad
-        if g is not None:   # (a graphed backward hands an undefined gradient to parameters its forward never used: nothing to add)
-            view = self._view[p]
-            g = g.reshape(-1)
-            if p in self._written:   # a later micro-step of the same optimizer step accumulates
-                view.add_(g)
-            else:
-                if g.is_cuda and g.dtype == view.dtype:
-                    # an elementwise kernel, not copy_(): a device-to-device copy_ goes through hipMemcpyAsync, whose blit dispatch left the GPU idle
-                    # ~37 us after each of the ~105 gradient copies of a step (rocprofv3 timeline, tools/trace_gaps.py)
-                    torch.mul(g, 1, out=view)
-                else:
-                    view.copy_(g)
-                self._written.add(p)
-            p.grad = None  # the bucket slice is the gradient from here on (no second copy kept)
         bi = self.slices[p][0]
+        if g is not None:   # (a graphed backward hands an undefined gradient to parameters its forward never used: nothing to add)
+            # parked until the bucket's last gradient arrives, then copied with ONE multi-tensor launch per bucket (_flush): the ~250 per-parameter
+            # copies of a step were ~250 launches of a few microseconds each in the launch-bound mask-path backward (rocprofv3, tools/step_timeline.py)
+            self._stash[bi].append((p, g.reshape(-1)))
+            p.grad = None  # the bucket slice is the gradient from here on (no second copy kept)
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
+            self._flush(bi)
             self._launch_ready()
+
+    def _flush(self, bi):
+        """Move the parked gradients of bucket bi into its flat buffer: first arrival of an optimizer step copies, later micro-steps add."""
+        st = self._stash[bi]
+        if not st:
+            return
+        cp_v, cp_g, ad_v, ad_g = [], [], [], []
+        for p, g in st:
+            view = self._view[p]
+            if p in self._written:
+                ad_v.append(view)
+                ad_g.append(g if g.dtype == view.dtype else g.to(view.dtype))
+            else:
+                self._written.add(p)
+                if g.is_cuda and g.dtype == view.dtype:
+                    cp_v.append(view)
+                    cp_g.append(g)
+                else:
+                    view.copy_(g)
+        # multi-tensor kernels, not copy_() per tensor: a device-to-device copy_ goes through hipMemcpyAsync, whose blit dispatch left the GPU idle ~37 us each
+        if cp_v:
+            torch._foreach_copy_(cp_v, cp_g)
+        if ad_v:
+            torch._foreach_add_(ad_v, ad_g)
+        st.clear()
 
     def _launch_ready(self):
         """Launch, in index order, every bucket whose gradients are all in: bucket i never goes out before bucket i-1 (rank-independent order)."""
@@ -141,6 +159,8 @@ class GradBucketReducer:
 
     def begin_step(self):
         """Call before the first micro-step of an optimizer step."""
+        for st in self._stash:   # gradients of a step that was never finished are dropped with it
+            st.clear()
         self._written = set()
         self.handles = []
         self.begin_micro_step()
@@ -148,6 +168,8 @@ class GradBucketReducer:
             self._clear_rows(st)
 
     def begin_micro_step(self):
+        for bi in range(len(self.buckets)):   # a bucket the previous micro-step left incomplete: its gradients go in before the next ones are parked
+            self._flush(bi)
         self.pending = [len(b) for b in self.buckets]
         self._next = 0
 
@@ -163,6 +185,8 @@ class GradBucketReducer:
     def finish(self):
         """Launch what backward left (buckets holding a parameter without a gradient on this rank: their untouched slices are zeroed first), exchange
         the sparse rows, wait for everything; afterwards grad_view(p) holds the averaged gradient."""
+        for bi in range(len(self.buckets)):
+            self._flush(bi)
         if len(self._written) != len(self.params):
             for p in self.params:    # a parameter without a gradient in this step must not hand last step's slice to the optimizer
                 if p not in self._written:

@@ -146,9 +146,9 @@ def test_layernorm_narrow_rows(dev):
         assert rel(ops.layernorm(x, w, b, 1e-6, act="gelu"), refg) < 8e-3, dim
 
 
-@pytest.mark.parametrize("rows,dim", [(5000, 32), (4097, 64), (1000, 16), (3000, 128), (700, 256)])
+@pytest.mark.parametrize("rows,dim", [(5000, 32), (4097, 64), (1000, 16), (3000, 128), (700, 256), (70000, 256), (3, 256), (900, 512), (500, 384), (300, 1024)])
 def test_layernorm_backward(dev, rows, dim):
-    """dx, dw, db of LayerNorm vs fp32 autograd (narrow-row kernel for 16..128 channels, wave-per-row above)."""
+    """dx, dw, db of LayerNorm vs fp32 autograd (lane-group kernel with per-workgroup partial rows for 16..512 channels, wave-per-row + atomics for other widths)."""
     from rga3.hip import ops
 
     x, dy = rnd((rows, dim), dev, seed=1), rnd((rows, dim), dev, seed=2)
@@ -159,3 +159,57 @@ def test_layernorm_backward(dev, rows, dim):
     br = torch.zeros(dim, requires_grad=True)
     F.layer_norm(xr, (dim,), wr, br, 1e-6).backward(dy.float().cpu())
     assert rel(dx, xr.grad) < 8e-3 and rel(dw, wr.grad) < 5e-3 and rel(db, br.grad) < 5e-3, (rows, dim)
+    if dim in (16, 32, 64, 128, 256, 512):   # the partial-row path is bit-reproducible
+        dx2, dw2, db2 = ops.layernorm_bwd(x, w, dy, 1e-6)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(65536, 256, 256), (100000, 32, 32), (262144, 64, 64), (7, 256, 256), (1000, 2048, 2048), (513, 24, 40), (3000, 4096, 4096),
+                                          (900, 4, 4), (700, 36, 36)])
+def test_colsum(dev, rows, cols, ld):
+    """bias gradients: two-stage deterministic column sums (cols % 8 == 0) and the atomic fall-back for other widths, vs an fp64 sum of the same bf16 values."""
+    from rga3.hip import ops
+
+    buf = rnd((rows, ld), dev, seed=rows + cols)
+    x = buf[:, :cols]
+    out = ops.colsum(x)
+    ref = x.double().sum(0).cpu()
+    assert ((out.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item() < 2e-5, (rows, cols)
+    if cols % 8 == 0:
+        assert torch.equal(out, ops.colsum(x))
+
+
+@pytest.mark.parametrize("n,hi,wi,ho,wo", [(3, 64, 64, 256, 256), (2, 37, 53, 120, 168), (2, 120, 168, 37, 53), (1, 16, 16, 16, 16), (2, 5, 7, 50, 9), (1, 256, 256, 1024, 1024)])
+def test_bilinear_backward_gather(dev, n, hi, wi, ho, wo):
+    """gradient of the bilinear resize (align_corners=False) by gathering, up- and down-sampling, vs torch's autograd of F.interpolate; run-to-run identical."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(hi * wo)
+    dout = torch.randn(n, ho, wo, generator=g)
+    xin = torch.zeros(n, 1, hi, wi, requires_grad=True)
+    F.interpolate(xin, size=(ho, wo), mode="bilinear", align_corners=False).backward(dout[:, None])
+    got = ops.bilinear_bwd(dout.to(dev), (n, hi, wi))
+    assert rel(got, xin.grad[:, 0]) < 1e-5
+    assert torch.equal(got, ops.bilinear_bwd(dout.to(dev), (n, hi, wi)))
+    # with a plane selection the atomic form is used: same numbers within f32 summation order
+    idx = torch.arange(n, dtype=torch.int32, device=dev)
+    assert rel(ops.bilinear_bwd(dout.to(dev), (n, hi, wi), idx), xin.grad[:, 0]) < 1e-5
+
+
+@pytest.mark.parametrize("B,P,C", [(16, 65536, 32), (3, 1000, 32), (2, 4096, 16), (1, 77, 8)])
+def test_mask_product_forward_backward(dev, B, P, C):
+    """masks[b] = hyper[b] @ up[b]^T for all frames in one launch (reference model/sam2.py:2142-2149) and its two gradients vs fp32 einsum autograd."""
+    from rga3.hip import ops
+
+    hyper, up = rnd((B, 4, C), dev, seed=1), rnd((B * P, C), dev, 0.5, seed=2)
+    dm = torch.randn(B, 4, P, generator=torch.Generator().manual_seed(3))
+    hr = hyper.float().cpu().requires_grad_(True)
+    ur = up.float().cpu().view(B, P, C).requires_grad_(True)
+    ref = torch.einsum("bmc,bpc->bmp", hr, ur)
+    ref.backward(dm)
+    masks = ops.mask_product(hyper, up, P)
+    assert masks.dtype == torch.float32 and rel(masks, ref.detach()) < 1e-5
+    dh, du = ops.mask_product_bwd(dm.to(dev), hyper, up, P)
+    assert rel(du, ur.grad.view(B * P, C)) < 4e-3 and rel(dh, hr.grad) < 4e-3
+    dh2, du2 = ops.mask_product_bwd(dm.to(dev), hyper, up, P)
+    assert torch.equal(dh, dh2) and torch.equal(du, du2)

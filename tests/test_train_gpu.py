@@ -49,6 +49,13 @@ def test_rmsnorm_swiglu_backward_and_transpose(dev):
     xf = x.float().cpu().requires_grad_(True)
     R.rmsnorm_ref(xf, w.cpu(), 1e-6).backward(dy.float().cpu())
     assert rel_l2(ops.rmsnorm_bwd(x, w, dy, 1e-6, add=add), xf.grad + add.float().cpu()) < 1e-2
+    for rows, dim in ((50, 1280), (33, 3584), (9, 5120), (5, 8192)):   # wide rows: one workgroup per row (1 / 2 / 4 chunks per thread)
+        x, w, dy = rnd((rows, dim), dev, 2.0, dim), (1 + 0.1 * torch.randn(dim)).to(torch.bfloat16).to(dev), rnd((rows, dim), dev, seed=dim + 1)
+        xf = x.float().cpu().requires_grad_(True)
+        R.rmsnorm_ref(xf, w.cpu(), 1e-6).backward(dy.float().cpu())
+        assert rel_l2(ops.rmsnorm_bwd(x, w, dy, 1e-6), xf.grad) < 6e-3, dim
+        add = rnd((rows, dim), dev, seed=dim + 2)
+        assert rel_l2(ops.rmsnorm_bwd(x, w, dy, 1e-6, add=add), xf.grad + add.float().cpu()) < 6e-3, dim
     T, I = 19, 64
     gu, da = rnd((T, 2 * I), dev, seed=4), rnd((T, I), dev, seed=5)
     gf = gu.float().cpu().requires_grad_(True)
