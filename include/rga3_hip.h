@@ -48,12 +48,14 @@ int rga3_last_error(char* buf, size_t n);
  * (Hiera qkv/proj/mlp), :857-889 (FPN 1x1), :1417-1481 (decoder attention projections).
  * colscale [N_out] is the ConvNeXt layer scale of reference model/sam2.py:690-703.
  * K, lda, ldw must be multiples of 8 (16-byte rows); tile = -1 lets the library choose (M <= 4 rows: the weight-stream kernel, 40).
- * Explicit tilings (all give the same bits except 22 / 32 / 25 / 40, whose K splits / lane-strided sums change the f32 summation order,
+ * Explicit tilings (all give the same bits except 22 / 32 / 25 / 14 / 40, whose K splits / lane-strided sums change the f32 summation order,
  * reproducibly):
  *   20 = 256x256 ping-pong, one tile per workgroup;  21 = the same, persistent (one workgroup per CU);
  *   22 = persistent + stream-K tail (needs the caller workspace below);  31 / 32 = 21 / 22 with 192x256 tiles (M = 2112 = 11 x 192);
  *   25 = split-K for few output tiles over a very long K (same workspace; falls back to 21 when it does not apply);
  *   11, 12 / 3 / 4 / 5 / 13 = single-phase 128x128 / 128x256 / 128x320 / 128x192 / 64x64;  10 = single-phase 256x256 (first generation, A/B);
+ *   14 = 64x64 with K cut into up to 32 slices (skinny plain products such as LoRA's x A^T: N = 128 over K = 3584; same workspace; runs as 13
+ *        when there is a bias / activation / residual);
  *   40 = skinny weight-stream kernel for M <= 4 (the decode step of generate(), reference app.py:308-317): no column scale. */
 int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, int out_dtype, int tile,

@@ -41,6 +41,7 @@ struct GemmArgs {
     int group_m;  // tile rows per group of the tile order (see launchers)
     void* ws;     // caller workspace for the stream-K / split-K tilings (may be null)
     long ws_bytes;
+    int ksl;      // gemm_nt_kernel only: K-tiles per grid.y slice (0: no split); slice y accumulates K-tiles [y ksl, (y+1) ksl) into f32 slab y of C
 };
 
 // 16 bytes of zeros in device memory: source for staging chunks that lie beyond K in the last K-tile
@@ -339,16 +340,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
     static_assert(PIPE == 0, "the register-pipelined variant was removed (it spilled at 256x256 and lost to the ping-pong kernel)");
+    // K split (tile 14, skinny products: M x 128 over K = 3584 is 66 tiles of 64 x 64): slice blockIdx.y takes ksl K-tiles and writes an f32 slab
+    const int kt0 = p.ksl ? (int)blockIdx.y * p.ksl : 0;
+    const int nk = p.ksl ? min(nk_all, kt0 + p.ksl) : nk_all;
+    if (p.ksl) p.C = (void*)((float*)p.C + (long)blockIdx.y * p.M * p.ldc);
     {
-    stage_tile(0, 0, nk == 1);
-    for (int kt = 0; kt < nk; ++kt) {
+    stage_tile(kt0 & 1, kt0, kt0 + 1 == nk_all);
+    for (int kt = kt0; kt < nk; ++kt) {
         // tile kt has landed (own loads: vmcnt(0); everyone's: barrier) and everyone is done reading
         // the other stage, so it can be refilled while this one is consumed.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage_tile((kt + 1) & 1, kt + 1, kt + 2 == nk);
+        if (kt + 1 < nk) stage_tile((kt + 1) & 1, kt + 1, kt + 2 == nk_all);
         const char* As = smem + (kt & 1) * STAGE + (wm * WTM) * ROWB;
         const char* Bs = smem + (kt & 1) * STAGE + BM * ROWB + (wn * WTN) * ROWB;
 #pragma unroll
@@ -1082,6 +1087,47 @@ static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
+__global__ __launch_bounds__(256) void tn_slab_sum_kernel(const float* __restrict__ slabs, void* __restrict__ out, long n, long ldc, int ncols, int Z, int out_f32);
+
+// tile 14: 64 x 64 tiles with K cut into S grid.y slices (f32 slabs [S][M][N] in the caller's workspace, summed in slice order by tn_slab_sum_kernel:
+// deterministic).  For skinny products -- LoRA's x A^T and dY B (M = 2112 tokens, N = r = 128, K = 3584: 66 tiles, one 56-K-tile loop each, 40 us on
+// 66 of 256 CUs) -- the split fills the chip.  Plain products only (no bias / activation / residual); anything else runs as tile 13.
+template <bool OUT_F32>
+static int launch_split64(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
+    a.ntm = (int)cdiv(a.M, 64);
+    a.ntn = (int)cdiv(a.N, 64);
+    a.group_m = pick_group_m(a.ntm, 64);
+    const long tiles = (long)a.ntm * a.ntn;
+    const int nk = (int)cdiv(a.K, 64);
+    SkWorkspace ws;
+    long S = 1024 / tiles;                 // ~4 workgroups of 256 threads per CU
+    if (S > nk / 2) S = nk / 2;            // at least 2 K-tiles per slice
+    if (S > 32) S = 32;
+    if (a.bias || a.res || a.colscale || a.N % 8 != 0 || S < 2 || sk_workspace(a0.ws, a0.ws_bytes, ws)) return launch_cfg<64, 64, 2, 2, ACT_NONE, OUT_F32, 0>(a0, st);
+    const long fit = (long)((size_t)ws.P * 512 * 32 * 16 / ((size_t)a.M * a.N * 4));
+    if (S > fit) S = fit;
+    if (S < 2) return launch_cfg<64, 64, 2, 2, ACT_NONE, OUT_F32, 0>(a0, st);
+    a.ksl = (int)cdiv(nk, S);
+    S = cdiv(nk, a.ksl);
+    a.C = ws.slabs;
+    a.ldc = a.N;
+    constexpr int LDS = 2 * (64 + 64) * 128;
+    auto kern = gemm_nt_kernel<64, 64, 2, 2, ACT_NONE, true, 0>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)S), dim3(256), LDS, st, a);
+    RGA3_CHECK_LAUNCH("gemm_nt_kernel<split 64>");
+    const long n = (long)a0.M * a0.N;
+    hipLaunchKernelGGL(tn_slab_sum_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)ws.slabs, a0.C, n, (long)a0.ldc, (int)a0.N, (int)S, OUT_F32 ? 1 : 0);
+    RGA3_CHECK_LAUNCH("tn_slab_sum_kernel");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // TN product for weight gradients: C[M, N] = A^T . B with A [K, M] and B [K, N] row-major, K = tokens (dW = dY^T X of nn.Linear /
 // LoRA, reference autograd of train_joint.py:534).  The NT kernels above would need both operands transposed first (one extra
@@ -1363,6 +1409,9 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
             else return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 10: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 13: return launch_cfg<64, 64, 2, 2, ACT, OUT_F32, 0>(a, st);   // small products (SAM2 per-frame 4096 x 256 x 256: 256 tiles instead of 64)
+        case 14:   // 64 x 64 with a K split (skinny plain products)
+            if constexpr (ACT == ACT_NONE) return launch_split64<OUT_F32>(a, st);
+            else return launch_cfg<64, 64, 2, 2, ACT, OUT_F32, 0>(a, st);
         case 20: return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
         case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
@@ -1405,7 +1454,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || tile == 5 || (tile >= 10 && tile <= 13) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || tile == 5 || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;
@@ -1416,7 +1465,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.colscale = (const unsigned short*)colscale;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
-    a.ws = workspace; a.ws_bytes = workspace_bytes;
+    a.ws = workspace; a.ws_bytes = workspace_bytes; a.ksl = 0;
     hipStream_t st = (hipStream_t)stream;
     RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
     int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
@@ -1445,7 +1494,7 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = 0; a.ldw = 0; a.ldc = ldc; a.ldr = 0;
     a.ntm = (int)cdiv(M, 128); a.ntn = (int)cdiv(N, 128); a.group_m = 1;
-    a.ws = nullptr; a.ws_bytes = 0;
+    a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0;
     TnArgs t;
     t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
     const int nk = (int)cdiv(K, 32);

@@ -105,7 +105,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
         tile = 40   # decode step: a weight stream, not a tiled product (gemv_kernel)
     if tile == -1 and M * N * K >= (1 << 24) and not (residual is not None and residual.data_ptr() == out.data_ptr()):
         # few output tiles over a very long K (weight gradients dW = dY^T X): also try the split-K form
-        extra = (25,) if (M * N <= (1 << 20) and K >= 4096 and act == "none" and residual is None and colscale is None) else ()
+        plain = act == "none" and residual is None and colscale is None
+        extra = (25,) if (M * N <= (1 << 20) and K >= 4096 and plain) else ()
+        if plain and bias is None and N % 8 == 0 and M * N <= (1 << 19) and K >= 512:   # skinny products (LoRA x A^T, dY B): 64 x 64 tiles with a K split
+            extra = extra + (14,)
         tile = _tuner.pick(_tuner.key_of(M, N, K, act, odt, bias is not None, residual is not None), run, extra)
     run(tile)
     return out

@@ -497,7 +497,8 @@ class PositionEmbeddingRandom(nn.Module):
         G = self.positional_encoding_gaussian_matrix.float()
         grid = torch.ones((h, w), dtype=torch.float32, device=G.device)
         y, x = (grid.cumsum(0) - 0.5) / h, (grid.cumsum(1) - 0.5) / w
-        c = 2 * math.pi * ((2 * torch.stack([x, y], dim=-1) - 1) @ G)
+        # a 2-term contraction written out (x' G[0] + y' G[1]): a torch `@` here would be a vendor-BLAS launch on the product path
+        c = 2 * math.pi * ((2 * x - 1)[..., None] * G[0] + (2 * y - 1)[..., None] * G[1])
         return torch.cat([torch.sin(c), torch.cos(c)], dim=-1).reshape(h * w, -1)
 
 

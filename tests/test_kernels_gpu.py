@@ -25,7 +25,7 @@ def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed / mis-mapped C fragment layout."""
     from rga3.hip import ops
 
-    for tile in (3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 31, 32):
+    for tile in (3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 31, 32):
         n, k = 256, 256
         a = torch.eye(k, dtype=torch.bfloat16, device=dev)
         w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(torch.bfloat16).to(dev)
@@ -35,7 +35,7 @@ def test_gemm_identity_asymmetric(dev):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (2112, 512, 3584), (8192, 1280, 1280), (64, 3456, 1280),
                                    (17, 24, 64), (1000, 152064 // 16, 192)])
-@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 31, 32])
 def test_gemm_plain(dev, M, N, K, tile):
     from rga3.hip import ops
 
@@ -43,6 +43,27 @@ def test_gemm_plain(dev, M, N, K, tile):
     out = ops.gemm(a, w, tile=tile)
     ref = R.linear_ref(a.cpu(), w.cpu())
     assert _rel_l2(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K,f32", [(2112, 128, 3584, False), (2112, 128, 512, False), (4160, 128, 3584, False), (100, 8, 1000, True), (333, 264, 2056, False),
+                                       (64, 64, 128, False)])
+def test_gemm_split64_skinny(dev, M, N, K, f32):
+    """Tile 14 (64 x 64 tiles, K cut into grid.y slices, f32 slabs summed in slice order): LoRA's x A^T / dY B shapes, ragged K, f32 and strided outputs;
+    equal to the unsplit 64 x 64 tiling up to the f32 re-association, and reproducible."""
+    from rga3.hip import ops
+
+    a, w = _rand((M, K), dev, seed=41), _rand((N, K), dev, 0.05, seed=42)
+    odt = torch.float32 if f32 else torch.bfloat16
+    buf = torch.zeros((M, N + 8), dtype=odt, device=dev)
+    out = ops.gemm(a, w, out_dtype=odt, out=buf[:, :N], tile=14)
+    again = ops.gemm(a, w, out_dtype=odt, tile=14)
+    assert torch.equal(out, again) and float(buf[:, N:].abs().max()) == 0.0
+    ref = ops.gemm(a, w, out_dtype=odt, tile=13)
+    assert _rel_l2(out, ref.float().cpu()) < (1e-5 if f32 else 3e-3), (M, N, K)
+    assert _rel_l2(out, R.linear_ref(a.cpu(), w.cpu())) < 6e-3
+    # with a bias the split does not apply: the call runs as the plain 64 x 64 tiling
+    bias = _rand((N,), dev, 0.5, seed=43)
+    assert torch.equal(ops.gemm(a, w, bias=bias, out_dtype=odt, tile=14), ops.gemm(a, w, bias=bias, out_dtype=odt, tile=13))
 
 
 def test_gemm_stream_k_split_shapes(dev):
