@@ -30,6 +30,7 @@ struct AttnBwdArgs {
     int causal;
     float* dkv_ws;   // GQA split: f32 partial dK | dV, each [group][total_k][Hkv][D]; null = loop the group inside one workgroup
     long total_k;
+    int gx, gy;      // logical grid (blocks, heads) of the dq / dkv launches: the hardware grid is 1-D, decoded XCD-aware (xcd_decode3)
 };
 
 constexpr int BT = 64;  // tile of the streamed (LDS-staged) dimension
@@ -74,17 +75,18 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int seg = blockIdx.z, hq = blockIdx.y;
+    const Wg3 wg = xcd_decode3(p.gx, p.gy);   // heads of one (query block, segment) share an XCD: K / V of a GQA group are fetched once per XCD
+    const int seg = wg.z, hq = wg.y;
     const int hk = hq / (p.Hq / p.Hkv);
     const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
     const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
     const int shift = Lk - Lq;
     // causal launches pair query block i with n-1-i (as the forward does): every workgroup walks the same number of key tiles
     const int nqb = (Lq + BLOCK_M - 1) / BLOCK_M;
-    int qb_first = blockIdx.x, qb_second = -1;
+    int qb_first = wg.x, qb_second = -1;
     if constexpr (PAIR) {
-        qb_first = nqb - 1 - (int)blockIdx.x;
-        qb_second = (int)blockIdx.x;
+        qb_first = nqb - 1 - wg.x;
+        qb_second = wg.x;
         if (qb_second > qb_first) return;
         if (qb_second == qb_first) qb_second = -1;
     } else if (qb_first >= nqb) {
@@ -258,18 +260,19 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int seg = blockIdx.z;
+    const Wg3 wg = xcd_decode3(p.gx, p.gy);
+    const int seg = wg.z;
     const int group = p.Hq / p.Hkv;
-    const int hk = SPLIT ? (int)blockIdx.y / group : (int)blockIdx.y;
-    const int hh0 = SPLIT ? (int)blockIdx.y % group : 0, hh1 = SPLIT ? hh0 + 1 : group;
+    const int hk = SPLIT ? wg.y / group : wg.y;
+    const int hh0 = SPLIT ? wg.y % group : 0, hh1 = SPLIT ? hh0 + 1 : group;
     const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
     const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
     const int shift = Lk - Lq;
     const int nkb = (Lk + BLOCK_N - 1) / BLOCK_N;
-    int kb_first = blockIdx.x, kb_second = -1;
+    int kb_first = wg.x, kb_second = -1;
     if constexpr (PAIR) {   // causal: key block j sees query tiles j..n-1; pair j with n-1-j
-        kb_first = (int)blockIdx.x;                 // the long one (early keys) first
-        kb_second = nkb - 1 - (int)blockIdx.x;
+        kb_first = wg.x;                 // the long one (early keys) first
+        kb_second = nkb - 1 - wg.x;
         if (kb_first > kb_second) return;
         if (kb_second == kb_first) kb_second = -1;
     } else if (kb_first >= nkb) {
@@ -440,7 +443,9 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
 }
 
 template <int DP>
-static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipStream_t st) {
+static int launch_bwd(const AttnBwdArgs& a0, int nseg, int max_q, int max_k, hipStream_t st) {
+    AttnBwdArgs a = a0;
+    a.gx = 1; a.gy = 1;
     constexpr int QT = (DP >= 128) ? 1 : 2;
     // 8 waves per workgroup at D = 128 (the decoder): a K/V (resp. Q/dO) tile staged once serves twice the rows
     constexpr int NW = (DP == 128) ? 8 : 4;
@@ -465,11 +470,13 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
     if (pair) {
         auto kq = attn_bwd_dq_kernel<DP, QT, NW, true>;
         if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
-        hipLaunchKernelGGL(kq, dim3((nqb + 1) / 2, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
+        a.gx = (int)((nqb + 1) / 2); a.gy = a.Hq;
+        hipLaunchKernelGGL(kq, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
     } else {
         auto kq = attn_bwd_dq_kernel<DP, QT, NW, false>;
         if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
-        hipLaunchKernelGGL(kq, dim3(nqb, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
+        a.gx = (int)nqb; a.gy = a.Hq;
+        hipLaunchKernelGGL(kq, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
     }
     RGA3_CHECK_LAUNCH("attn_bwd_dq_kernel");
     const unsigned gx = pair ? (nkb + 1) / 2 : nkb;
@@ -477,11 +484,13 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
         if (pair) {
             auto ks_ = attn_bwd_dkv_kernel<DP, NW, true, true>;
             if (int rc = prep((const void*)ks_, LDS_DKV)) return rc;
-            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
+            a.gx = (int)gx; a.gy = a.Hq;
+            hipLaunchKernelGGL(ks_, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
         } else {
             auto ks_ = attn_bwd_dkv_kernel<DP, NW, true, false>;
             if (int rc = prep((const void*)ks_, LDS_DKV)) return rc;
-            hipLaunchKernelGGL(ks_, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
+            a.gx = (int)gx; a.gy = a.Hq;
+            hipLaunchKernelGGL(ks_, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
         }
         RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel<split>");
         const long rows = a.total_k * a.Hkv;
@@ -492,11 +501,13 @@ static int launch_bwd(const AttnBwdArgs& a, int nseg, int max_q, int max_k, hipS
     if (pair) {
         auto kk = attn_bwd_dkv_kernel<DP, NW, false, true>;
         if (int rc = prep((const void*)kk, LDS_DKV)) return rc;
-        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
+        a.gx = (int)gx; a.gy = a.Hkv;
+        hipLaunchKernelGGL(kk, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
     } else {
         auto kk = attn_bwd_dkv_kernel<DP, NW, false, false>;
         if (int rc = prep((const void*)kk, LDS_DKV)) return rc;
-        hipLaunchKernelGGL(kk, dim3(gx, (unsigned)a.Hkv, (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
+        a.gx = (int)gx; a.gy = a.Hkv;
+        hipLaunchKernelGGL(kk, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DKV, st, a);
     }
     RGA3_CHECK_LAUNCH("attn_bwd_dkv_kernel");
     return 0;

@@ -46,6 +46,7 @@ struct AttnArgs {
     const float* rope_sin;
     const float* rope_kcos;
     const float* rope_ksin;
+    int gx;            // workgroups per (segment, head): the grid is 1-D, gx * Hq * nseg, decoded XCD-aware in the kernel
 };
 
 // x[0..7] (bf16x8 as u32x4) of row `row_ptr` at column d, rotated: x cos + rotate_half(x) sin in f32, one bf16 rounding (rope_kernel's arithmetic)
@@ -90,7 +91,14 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
 
-    const int seg = blockIdx.z, hq = blockIdx.y;
+    // 1-D grid, remapped so that CONSECUTIVE logical ids share an XCD (workgroups go round-robin over the 8 XCDs), decoded head-fastest: all heads of a
+    // (query block, segment) run on one XCD.  A head's slice of a packed qkv row is 144-256 B, so with the plain (x, head, segment) order -- head h of
+    // every window on XCD h % 8 -- every XCD's L2 fetched every cache line of q, k and v for its one head (up to 8x the fabric reads), and the 7 query
+    // heads of a GQA group each pulled their own copy of the group's K / V.
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int hq = (int)(lid % (unsigned)p.Hq);
+    const int bx = (int)((lid / (unsigned)p.Hq) % (unsigned)p.gx);
+    const int seg = (int)(lid / ((unsigned)p.Hq * (unsigned)p.gx));
     const int hk = hq / (p.Hq / p.Hkv);
     const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
     const int ks = p.cu_k[seg], Lk = p.cu_k[seg + 1] - ks;
@@ -98,11 +106,11 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     // Causal launches pair q-block i with q-block n-1-i in one workgroup: every workgroup then walks the same number of
     // key tiles (a plain grid leaves the chip to the few longest rows at the end: 34 tiles vs 2 at S = 2112).
     const int nqb = (Lq + BLOCK_M - 1) / BLOCK_M;
-    const int sp = SPLIT ? (int)blockIdx.x % p.nsplit : 0;   // this workgroup's slice of the key range
-    int qb_first = SPLIT ? (int)blockIdx.x / p.nsplit : (int)blockIdx.x, qb_second = -1;
+    const int sp = SPLIT ? bx % p.nsplit : 0;   // this workgroup's slice of the key range
+    int qb_first = SPLIT ? bx / p.nsplit : bx, qb_second = -1;
     if constexpr (PAIR) {
-        qb_first = nqb - 1 - (int)blockIdx.x;           // the long one first
-        qb_second = (int)blockIdx.x;
+        qb_first = nqb - 1 - bx;           // the long one first
+        qb_second = bx;
         if (qb_second > qb_first) return;
         if (qb_second == qb_first) qb_second = -1;
     } else if (qb_first >= nqb) {
@@ -401,7 +409,9 @@ static int launch_attn_p(const AttnArgs& a, int nseg, unsigned gx, hipStream_t s
         if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NWAVE), LDS, st, a);
+    AttnArgs b = a;
+    b.gx = (int)gx;
+    hipLaunchKernelGGL(kern, dim3(gx * (unsigned)a.Hq * (unsigned)nseg), dim3(64 * NWAVE), LDS, st, b);
     RGA3_CHECK_LAUNCH("attn_fwd_kernel");
     return 0;
 }
@@ -424,7 +434,9 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
             if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_done = true;
         }
-        hipLaunchKernelGGL(kern, dim3(nqb * (unsigned)a.nsplit, (unsigned)a.Hq, (unsigned)nseg), dim3(64 * NWAVE), LDS, st, a);
+        AttnArgs b = a;
+        b.gx = (int)(nqb * (unsigned)a.nsplit);
+        hipLaunchKernelGGL(kern, dim3(nqb * (unsigned)a.nsplit * (unsigned)a.Hq * (unsigned)nseg), dim3(64 * NWAVE), LDS, st, b);
         RGA3_CHECK_LAUNCH("attn_fwd_kernel<split>");
         hipLaunchKernelGGL(attn_split_combine_kernel, dim3((unsigned)cdiv(a.total_q * a.Hq, 4)), dim3(256), 0, st, a);
         RGA3_CHECK_LAUNCH("attn_split_combine_kernel");
@@ -444,7 +456,9 @@ static int launch_rope_win(const AttnArgs& a, int nseg, hipStream_t st) {
         if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(1, (unsigned)a.Hq, (unsigned)nseg), dim3(256), LDS, st, a);
+    AttnArgs b = a;
+    b.gx = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.Hq * (unsigned)nseg), dim3(256), LDS, st, b);
     RGA3_CHECK_LAUNCH("attn_fwd_kernel<rope>");
     return 0;
 }
@@ -519,7 +533,7 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     RGA3_CHECK_ARG(block_q == 0 || !causal, "attn: block-diagonal packing is for non-causal windows");
     a.bq_shift = a.bk_shift = -1;
     if (block_q > 0) { a.bq_shift = __builtin_ctz((unsigned)block_q); a.bk_shift = __builtin_ctz((unsigned)block_k); }
-    a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1;
+    a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1; a.gx = 1;
     if (split_ws && !causal && block_q == 0 && D % 4 == 0 && max_k >= 1024) {
         const long wgs = (long)cdiv(max_q, 64) * Hq * nseg;
         int ns = (int)(256 / (wgs > 0 ? wgs : 1));
@@ -558,7 +572,7 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
     a.causal = causal;
     a.rope_cos = cos_q; a.rope_sin = sin_q; a.rope_kcos = cos_k; a.rope_ksin = sin_k;
     a.bq_shift = a.bk_shift = -1;
-    a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1;
+    a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1; a.gx = 1;
     hipStream_t st = (hipStream_t)stream;
     if (D <= 32) return launch_rope_win<32>(a, nseg, st);
     if (D <= 64) return launch_rope_win<64>(a, nseg, st);

@@ -87,4 +87,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + bid / kNumXCD;
 }
 
+// Logical (x, y, z) of this workgroup for a launch flattened to a 1-D grid of gx * gy * gz workgroups: the id is XCD-remapped first, then decoded
+// y-fastest, so consecutive logical ids -- which share an XCD -- differ in y (attention: the heads of one query / key block and segment).
+struct Wg3 { int x, y, z; };
+__device__ __forceinline__ Wg3 xcd_decode3(int gx, int gy) {
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    Wg3 w;
+    w.y = (int)(lid % (unsigned)gy);
+    w.x = (int)((lid / (unsigned)gy) % (unsigned)gx);
+    w.z = (int)(lid / ((unsigned)gy * (unsigned)gx));
+    return w;
+}
+
 }  // namespace rga3

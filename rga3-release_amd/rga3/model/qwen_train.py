@@ -133,6 +133,51 @@ def _lora_parts(lin):
     return None
 
 
+# ---- derived LoRA operands, rebuilt once per optimizer step for ALL modules with a handful of batched launches.
+# y = W x + s B A drop(x) is evaluated as  t_s = drop(x) (sA)^T,  y += t_s B^T;  backward  dB = dy^T t_s,  dt_s = dy (sB),  dA = dt_s^T drop(x),
+# dx += dt_s A  -- the scaling s sits in the SMALL operand of exactly one product per gradient, so no activation-sized tensor is ever rescaled, and the
+# two NN-form products read A^T and (sB)^T.  Round 2 built those per layer and per step with ~14 tiny launches per layer (mul, transpose, float / mul /
+# cast of dB): ~400 launches of a few microseconds in a step.  Here: stack -> one mul / one transposed copy per module family.
+_lora_cache = {}   # id(LoRALinear) -> (key of its parameters, sA [r, in], A^T [in, r], (sB)^T [r, out])
+
+
+def _lora_versions(lin):
+    A, B = lin.lora_A["default"].weight, lin.lora_B["default"].weight
+    return A._version, A.data_ptr(), B._version, B.data_ptr()
+
+
+def _lora_build(mods):
+    groups = {}
+    for m in mods:
+        A, B = m.lora_A["default"].weight, m.lora_B["default"].weight
+        groups.setdefault((tuple(A.shape), tuple(B.shape), float(m.scaling), A.dtype, A.device), []).append(m)
+    with torch.no_grad():
+        for (_, _, sc, _, _), grp in groups.items():
+            A = torch.stack([m.lora_A["default"].weight.detach() for m in grp])    # [n, r, in]
+            B = torch.stack([m.lora_B["default"].weight.detach() for m in grp])    # [n, out, r]
+            As = A * sc
+            At = A.transpose(1, 2).contiguous()
+            Bts = (B * sc).transpose(1, 2).contiguous()
+            for i, m in enumerate(grp):
+                _lora_cache[id(m)] = (_lora_versions(m), As[i], At[i], Bts[i])
+
+
+def lora_refresh(layers):
+    """Call once per forward: rebuilds the derived operands of every LoRA projection of `layers` if the optimizer has stepped since they were made."""
+    mods = [p for layer in layers for p in (layer.self_attn.q_proj, layer.self_attn.v_proj) if isinstance(p, LoRALinear)]
+    if mods and any((e := _lora_cache.get(id(m))) is None or e[0] != _lora_versions(m) for m in (mods[0], mods[-1])):
+        _lora_build(mods)
+
+
+def _lora_ops(lin):
+    """(sA, A^T, (sB)^T) of one projection, current with its parameters (a stale or missing entry is rebuilt for this module alone)."""
+    e = _lora_cache.get(id(lin))
+    if e is None or e[0] != _lora_versions(lin):
+        _lora_build([lin])
+        e = _lora_cache[id(lin)]
+    return e[1], e[2], e[3]
+
+
 _drop_state = {"step": 0}
 
 
@@ -181,15 +226,15 @@ def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
     if lq is not None:
         if pq > 0.0:
             hq = ops.dropout(h1, pq, seeds[0])
-        tq = ops.gemm(hq, lq[0])
+        tq = ops.gemm(hq, _lora_ops(at.q_proj)[0])            # t_s = drop(h) (sA)^T
         oq = qkv2[:, : Hq * D]
-        ops.gemm(tq, (lq[1].detach() * lq[2]).to(tq.dtype), residual=oq, out=oq)
+        ops.gemm(tq, lq[1].detach(), residual=oq, out=oq)       # += t_s B^T
     if lv is not None:
         if pv > 0.0:
             hv = ops.dropout(h1, pv, seeds[1])
-        tv = ops.gemm(hv, lv[0])
+        tv = ops.gemm(hv, _lora_ops(at.v_proj)[0])
         ov = qkv2[:, (Hq + Hk) * D:]
-        ops.gemm(tv, (lv[1].detach() * lv[2]).to(tv.dtype), residual=ov, out=ov)
+        ops.gemm(tv, lv[1].detach(), residual=ov, out=ov)
     return (qkv2, tq, tv, hq, hv) if want_inputs else (qkv2, tq, tv)
 
 
@@ -249,6 +294,18 @@ def _layer_forward_store(layer, x, cos, sin, cu, max_len, seeds):
     gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)
     y = _down_from_gu(mlp, gu, wd, x1)
     return y, (h1, qkv, att, lse, x1, h2, gu, tq, tv, hq_in, hv_in)
+
+
+_neg = {}
+
+
+def _neg_table(sin):
+    """-sin, made once per table (every layer's backward un-rotates with the same one)."""
+    key = (sin.data_ptr(), sin._version, tuple(sin.shape))
+    if _neg.get("key") != key:
+        _neg["key"], _neg["t"] = key, (-sin).contiguous()
+        _neg["src"] = sin          # keeps the source alive: its address cannot be reused while the entry exists
+    return _neg["t"]
 
 
 class DecoderLayerFn(torch.autograd.Function):
@@ -326,24 +383,24 @@ class DecoderLayerFn(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             ops.attn_varlen_bwd(q, k, v, att, datt, lse, cu, cu, max_len, max_len, D ** -0.5, True, dq=dqkv[:, :Hq], dk=dqkv[:, Hq:Hq + Hk],
                                 dv=dqkv[:, Hq + Hk:])
-            ops.rope_(dqkv, cos, (-sin).contiguous(), 0, Hq + Hk)   # inverse rotation (cos/sin tables are symmetric in the two halves)
+            ops.rope_(dqkv, cos, _neg_table(sin), 0, Hq + Hk)   # inverse rotation (cos/sin tables are symmetric in the two halves)
             dqkv2 = dqkv.view(T, (Hq + 2 * Hk) * D)
             dh1 = _fgemm(dqkv2, at, "wqkv_t", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: ops.transpose(wqkv))   # [T, H]
             grads = [None, None, None, None]
             if lq is not None or lv is not None:
-                for slot, lp, t_, cols, pdrop, hin, sd in ((0, lq, tq, (0, Hq * D), pq, hq_in, 0), (2, lv, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D), pv, hv_in, 1)):
+                for slot, lp, lin, t_, cols, pdrop, hin, sd in ((0, lq, at.q_proj, tq, (0, Hq * D), pq, hq_in, 0),
+                                                                (2, lv, at.v_proj, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D), pv, hv_in, 1)):
                     if lp is None:
                         continue
-                    A, B, s = lp
+                    _, At, Bts = _lora_ops(lin)                                         # A^T [H, r], (sB)^T [r, out]: once per step for all layers
                     dsl = dqkv2[:, cols[0]:cols[1]]                                    # [T, out]
-                    dB = ops.gemm_tn(dsl, t_)                                           # [out, r] = dsl^T t  (contraction over tokens, no transposes)
-                    dB = (dB.float() * s).to(B.dtype)
-                    dt = ops.gemm(dsl, (ops.transpose(B.detach()) * s).to(B.dtype))     # [T, r] = s * dsl B
+                    dB = ops.gemm_tn(dsl, t_)                                           # [out, r] = dsl^T t_s  (t_s carries s; contraction over tokens)
+                    dt = ops.gemm(dsl, Bts)                                             # [T, r] = dsl (sB)
                     dA = ops.gemm_tn(dt, h1 if pdrop == 0.0 else hin)                   # [r, H] = dt^T dropout(h1): lora_A saw the dropped input
                     if pdrop == 0.0:
-                        ops.gemm(dt, ops.transpose(A.detach()), residual=dh1, out=dh1)  # dh1 += dt A
+                        ops.gemm(dt, At, residual=dh1, out=dh1)                         # dh1 += dt A
                     else:                                                               # dh1 += mask / keep * (dt A): same seed, same mask
-                        ops.dropout(ops.gemm(dt, ops.transpose(A.detach())), pdrop, ctx.seeds[sd], out=dh1, accumulate=True)
+                        ops.dropout(ops.gemm(dt, At), pdrop, ctx.seeds[sd], out=dh1, accumulate=True)
                     grads[slot], grads[slot + 1] = dA, dB
             dx = ops.rmsnorm_bwd(x, w1.weight, dh1, w1.variance_epsilon, add=dx1)
         return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None, None)
@@ -431,6 +488,7 @@ def lm_train_forward(model, x, pos3, cu, max_len, labels_np, am_cur, flat_keep, 
     """Decoder + LM head + CE with autograd nodes; x [T, H] packed embeddings (requires_grad if embed_tokens is trainable)."""
     tm = model.model
     cos, sin = tm.mrope_tables(pos3)
+    lora_refresh(tm.layers)
     for li, layer in enumerate(tm.layers):
         at = layer.self_attn
         lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)

@@ -3,7 +3,7 @@
 (--anchor, default adamw8_kernel); it is cut into --bin-ms bins and each bin prints busy %, launches and the kernel that holds most of its time, so a
 host-bound stretch (many launches, low busy %) can be told from a kernel-bound one.
 --from-ms / --to-ms additionally list the kernels of that stretch of the step by total time.
-  python3 tools/step_timeline.py <dir-or-csv> [--anchor adamw8_kernel] [--bin-ms 2.5] [--from-ms 108 --to-ms 134]"""
+  python3 tools/step_timeline.py <dir-or-csv> [--anchor adamw8_kernel] [--bin-ms 2.5] [--from-ms 108 --to-ms 134] [--exclude gemm_]"""
 import csv
 import glob
 import os
@@ -65,7 +65,8 @@ def main():
 
 
 def stretch(step, t0, a_ms, b_ms):
-    sel = [r for r in step if r[0] >= t0 + a_ms * 1e6 and r[0] < t0 + b_ms * 1e6]
+    excl = arg("--exclude", None)   # e.g. --exclude gemm_ : everything but the GEMM family
+    sel = [r for r in step if r[0] >= t0 + a_ms * 1e6 and r[0] < t0 + b_ms * 1e6 and not (excl and excl in r[2])]
     agg = defaultdict(lambda: [0, 0])
     for s, e, n in sel:
         k = n.split("(")[0].replace("void ", "").replace("rga3::", "")[:90]
