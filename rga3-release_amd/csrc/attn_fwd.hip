@@ -372,6 +372,210 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     }  // pass
 }
 
+// ---- Window attention with the WHOLE key / value range of a segment resident in LDS (non-causal, <= 256 keys, D <= DP <= 96): Hiera's 64- / 256-token
+// windows (reference model/sam2.py:986-1033 inside window_partition), 16-token windows packed block-diagonally, the ViT's 64-token windows.  The
+// pipelined kernel above walks 64-key tiles with two barriers each and a register ring -- for four tiles that is all prologue: 18 us per 256 x 256
+// window and head, one 8-wave workgroup per CU (256 VGPRs).  Here K and V of the segment are staged ONCE (every load of the workgroup in flight at the
+// same time, one barrier), then each wave walks the key tiles on its own 16 query rows with no further synchronisation, so the MFMA, softmax and
+// LDS phases of the 16 waves of the co-resident workgroups interleave freely.  16 query rows per wave, 8 waves per workgroup (4 for windows of <= 64
+// queries), <= 128 VGPRs.
+// LDS rows are D padded to an ODD number of 16-byte chunks (72 -> 144 B, 80 -> 176 B): the 16 rows a quarter-wave reads then start in 16 different
+// 4-bank groups, and a 256-key window of 72-d heads takes 2 x 36 KiB, so two workgroups share a CU.  Fragment reads of the padded d range (D..DP) run
+// into the next row: finite numbers that meet Q's zero padding (scores) or land in output columns >= D that are never stored.
+template <int DP, int NW, int QT, bool ROPE = false>
+__global__ __launch_bounds__(64 * NW, (QT == 1 ? 16 : 8) / NW) void attn_win_kernel(AttnArgs p) {
+    constexpr int NT = 64 * NW, BLOCK_M = 16 * QT * NW, DS = DP / 32, DT = DP / 16;
+    constexpr int LDMAX = (256 * (DP / 8 + 1) + 511) / 512;   // 16-byte chunks per thread, operand and staging pass (8 waves: the largest segment in one pass)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int hq = (int)(lid % (unsigned)p.Hq);
+    const int bx = (int)((lid / (unsigned)p.Hq) % (unsigned)p.gx);
+    const int seg = (int)(lid / ((unsigned)p.Hq * (unsigned)p.gx));
+    const int hk = hq / (p.Hq / p.Hkv);
+    const int qs = p.cu_q[seg], Lq = p.cu_q[seg + 1] - qs;
+    const int ks = p.cu_k[seg], Lk = min(p.cu_k[seg + 1] - ks, 256);
+    const int qb0 = bx * BLOCK_M;
+    if (qb0 >= Lq) return;
+
+    const int chd = (p.D + 7) >> 3;                 // chunks of a row that hold data
+    const int chr = (((p.D * 2 + 15) >> 4) | 1);    // chunks per LDS row (odd)
+    const int RS = chr * 16;
+    const int nrows = (Lk + 63) & ~63;
+    char* Ks = smem;
+    char* Vs = smem + nrows * RS;
+
+    // ---- Q fragments first (B operand): lane (c, g) holds Q[q = c][d = 32 ds + 8 g .. + 7] of each of the wave's QT 16-row tiles
+    const int qw0 = qb0 + wid * (16 * QT);
+    bf16x8 qf[QT][DS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = qw0 + t * 16 + c;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+            const int d = ds * 32 + g * 8;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (qi < Lq && d < p.D) {
+                const unsigned short* qrow = p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh;
+                z = *(const u32x4*)(qrow + d);
+                if constexpr (ROPE) z = rope_chunk(z, qrow, d, p.D, p.rope_cos + (long)(qs + qi) * p.D, p.rope_sin + (long)(qs + qi) * p.D);
+            }
+            qf[t][ds] = __builtin_bit_cast(bf16x8, z);
+        }
+    }
+    // ---- stage all of K and V: every load of a pass is in flight before its first store
+    {
+        const unsigned short* kbase = p.k + (long)ks * p.k_st + (long)hk * p.k_sh;
+        const unsigned short* vbase = p.v + (long)ks * p.v_st + (long)hk * p.v_sh;
+        const int total = nrows * chr;
+        for (int b0 = 0; b0 < total; b0 += NT * LDMAX) {   // one pass for 8 waves x 256 keys; 4-wave workgroups with a 256-key range take two
+            u32x4 kreg[LDMAX], vreg[LDMAX];
+#pragma unroll
+            for (int i = 0; i < LDMAX; ++i) {
+                const int idx = b0 + tid + i * NT;
+                const int r = idx / chr, ch = idx - r * chr;
+                u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
+                if (idx < total && r < Lk && ch < chd) {
+                    zk = *(const u32x4*)(kbase + (long)r * p.k_st + ch * 8);
+                    zv = *(const u32x4*)(vbase + (long)r * p.v_st + ch * 8);
+                    if constexpr (ROPE)   // every key is staged exactly once per head: rotating it here replaces the stand-alone rope pass
+                        if (p.rope_kcos) zk = rope_chunk(zk, kbase + (long)r * p.k_st, ch * 8, p.D, p.rope_kcos + (long)(ks + r) * p.D, p.rope_ksin + (long)(ks + r) * p.D);
+                }
+                kreg[i] = zk;
+                vreg[i] = zv;
+            }
+#pragma unroll
+            for (int i = 0; i < LDMAX; ++i) {
+                const int idx = b0 + tid + i * NT;
+                if (idx < total) {
+                    *(u32x4*)(Ks + idx * 16) = kreg[i];     // rows are chr chunks wide: chunk idx lies at byte idx * 16
+                    *(u32x4*)(Vs + idx * 16) = vreg[i];
+                }
+            }
+        }
+        if (tid < 16) *(u32x4*)(Vs + nrows * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};   // slack the last rows' padded-d reads run into
+    }
+    __syncthreads();
+    if (qw0 >= Lq) return;   // no barrier below
+
+    f32x4 oacc[QT][DT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) oacc[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+    }
+    const int ntiles = nrows >> 6;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const char* Kt = Ks + kt * 64 * RS;
+        const char* Vt = Vs + kt * 64 * RS;
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                const bf16x8 kf = *(const bf16x8*)(Kt + (j * 16 + c) * RS + ds * 64 + g * 16);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ds], s[t][j], 0, 0, 0);
+            }
+        const int k0 = kt * 64;
+        const bool need_mask = (k0 + 64 > Lk) || (p.bq_shift >= 0);
+        bf16x8 pf[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int qi = qw0 + t * 16 + c;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = s[t][j][r] * p.scale_log2;
+                    if (need_mask) {
+                        const int key = k0 + j * 16 + 4 * g + r;
+                        bool ok = key < Lk;
+                        if (p.bq_shift >= 0) ok = ok && ((qi >> p.bq_shift) == (key >> p.bk_shift));
+                        x = ok ? x : -INFINITY;
+                    }
+                    s[t][j][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);
+            m_run[t] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[t][j][r] - m_use);
+                    s[t][j][r] = e;
+                    ps += e;
+                }
+            l_run[t] = l_run[t] * alpha + ps;
+            if (__any(alpha != 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[t][d] *= alpha;
+            }
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                u32x4 pk;
+                pk[0] = pack_bf2(s[t][2 * ss][0], s[t][2 * ss][1]);
+                pk[1] = pack_bf2(s[t][2 * ss][2], s[t][2 * ss][3]);
+                pk[2] = pack_bf2(s[t][2 * ss + 1][0], s[t][2 * ss + 1][1]);
+                pk[3] = pack_bf2(s[t][2 * ss + 1][2], s[t][2 * ss + 1][3]);
+                pf[t][ss] = __builtin_bit_cast(bf16x8, pk);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const char* a0 = Vt + (ss * 32 + 4 * g + (c >> 2)) * RS + (d * 16 + 4 * (c & 3)) * 2;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 16 * RS));
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) oacc[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][ss], oacc[t][d], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = l_run[t];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = (l > 0.f) ? 1.f / l : 0.f;
+        const int qi = qw0 + t * 16 + c;
+        if (qi < Lq) {
+            unsigned short* orow = p.o + (long)(qs + qi) * p.o_st + (long)hq * p.o_sh;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int dd = d * 16 + 4 * g;
+                if (dd < p.D) {
+                    u32x2 pk;
+                    pk[0] = pack_bf2(oacc[t][d][0] * inv, oacc[t][d][1] * inv);
+                    pk[1] = pack_bf2(oacc[t][d][2] * inv, oacc[t][d][3] * inv);
+                    *(u32x2*)(orow + dd) = pk;
+                }
+            }
+            if (p.lse && g == 0) p.lse[(long)hq * p.total_q + qs + qi] = (l > 0.f) ? (m_run[t] * 0.6931471805599453f + logf(l)) : -INFINITY;
+        }
+    }
+}
+
 // out = sum_i w_i o_i / sum_i w_i with w_i = 2^(lse2_i - max): one wave per (query row, head), 4 floats of D per lane per pass
 __global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnArgs p) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (token, head)
@@ -463,6 +667,25 @@ static int launch_rope_win(const AttnArgs& a, int nseg, hipStream_t st) {
     return 0;
 }
 
+template <int DP, int NW, int QT, bool ROPE = false>
+static int launch_win(const AttnArgs& a, int nseg, int max_q, int max_k, hipStream_t st) {
+    const int chr = (((a.D * 2 + 15) >> 4) | 1);
+    const int nrows = (max_k + 63) & ~63;
+    const int lds = 2 * nrows * chr * 16 + 256;
+    auto kern = attn_win_kernel<DP, NW, QT, ROPE>;
+    static int lds_set = 0;   // grows monotonically; a racing second setter only repeats the call
+    if (lds > 48 * 1024 && lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        lds_set = lds;
+    }
+    AttnArgs b = a;
+    b.gx = (int)cdiv(max_q, 16 * QT * NW);
+    hipLaunchKernelGGL(kern, dim3((unsigned)b.gx * (unsigned)a.Hq * (unsigned)nseg), dim3(64 * NW), lds, st, b);
+    RGA3_CHECK_LAUNCH("attn_win_kernel");
+    return 0;
+}
+
 static int g_attn_variant = 0;  // 0: auto, 1: force 4 waves x QT=2, 2: force 8 waves x QT=1 (benchmark switch, read-only after init)
 
 template <int DP, bool USE_TR>
@@ -547,6 +770,13 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
         }
     }
     hipStream_t st = (hipStream_t)stream;
+    // whole-segment-in-LDS window kernel: non-causal, key range known and <= 256, D <= 96, 16-byte rows (impl bit 1 keeps the pipelined kernel: A/B)
+    if (impl == 0 && g_attn_variant == 0 && !causal && a.nsplit == 1 && max_k > 0 && max_k <= 256 && D <= 96 && D % 8 == 0 &&
+        (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0) {
+        // (4 waves x 32 rows per 256-token window -- half the fragment reads per row, one wave fewer per SIMD -- measured slower: 129 vs 112 us)
+        if (max_q <= 64) return (D <= 64) ? launch_win<64, 4, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 4, 1>(a, nseg, max_q, max_k, st);
+        return (D <= 64) ? launch_win<64, 8, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 8, 1>(a, nseg, max_q, max_k, st);
+    }
     if (impl == 0) return launch_any<true>(a, nseg, max_q, st);
     return launch_any<false>(a, nseg, max_q, st);
 }
@@ -574,6 +804,9 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
     a.bq_shift = a.bk_shift = -1;
     a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1; a.gx = 1;
     hipStream_t st = (hipStream_t)stream;
+    static const bool old_rope = [] { const char* e = getenv("RGA3_ATTN_ROPE_OLD"); return e && atoi(e) != 0; }();   // A/B switch: the pipelined rope kernel
+    if (!old_rope && !causal && cu_q == cu_k && D <= 96 && D % 8 == 0)   // self-attention windows: key range = query range <= 64
+        return (D <= 64) ? launch_win<64, 4, 1, true>(a, nseg, max_q, max_q, st) : launch_win<96, 4, 1, true>(a, nseg, max_q, max_q, st);
     if (D <= 32) return launch_rope_win<32>(a, nseg, st);
     if (D <= 64) return launch_rope_win<64>(a, nseg, st);
     if (D <= 96) return launch_rope_win<96>(a, nseg, st);

@@ -255,7 +255,7 @@ class VisionAttention(nn.Module):
             att = ops.attn_varlen_rope(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False, rope_k=True)
         else:
             ops.rope_(qkv, cos, sin, 0, 2 * H)  # q heads then k heads are contiguous in the fused buffer
-            att = ops.attn_varlen(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, causal=False)
+            att = ops.attn_varlen(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, causal=False, max_k=max_len)
         return self.proj(att.view(N, H * D), residual=residual)
 
 

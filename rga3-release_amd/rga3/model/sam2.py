@@ -208,10 +208,10 @@ class MultiScaleBlock(nn.Module):
                 g *= 2
         if g > 1:
             att = ops.attn_varlen(qv, kv[:, heads:2 * heads], kv[:, 2 * heads:], _cu(nwin // g, seg_q * g, x.device), _cu(nwin // g, seg * g, x.device),
-                                  seg_q * g, hd ** -0.5, causal=False, block=(seg_q, seg))
-        else:
+                                  seg_q * g, hd ** -0.5, causal=False, block=(seg_q, seg), max_k=seg * g)
+        else:   # max_k: windows of <= 256 keys take the whole-segment-in-LDS kernel
             att = ops.attn_varlen(qv, kv[:, heads:2 * heads], kv[:, 2 * heads:], _cu(nwin, seg_q, x.device), _cu(nwin, seg, x.device), seg_q,
-                                  hd ** -0.5, causal=False)
+                                  hd ** -0.5, causal=False, max_k=seg)
         x = self.attn.proj(att.view(att.shape[0], do), residual=shortcut)
         if self.pool_q:
             H, W, layout_w = H // 2, W // 2, ws // 2

@@ -3,6 +3,7 @@
 Tolerances: inputs are bf16-exact values, accumulation is fp32; outputs are bf16 => rel-L2 <= 1e-2 and
 max-abs scaled by the output magnitude (bf16 kernels vs fp32 oracle rel-L2 <= 2e-2).
 """
+import numpy as np
 import pytest
 import torch
 
@@ -197,6 +198,46 @@ def test_attn_rope_windows_fused(dev, case, rope_k):
     assert _rel_l2(o, ro) < 1e-2
     with pytest.raises(lib.Rga3Error):
         ops.attn_varlen_rope(b[:, :Hq], b[:, Hq:Hq + Hkv], b[:, Hq + Hkv:], cu.to(dev), cu.to(dev), 65, D ** -0.5, cos, sin, causal, rope_k=rope_k)
+
+
+@pytest.mark.parametrize("lq,lk,Hq,Hkv,D,block", [
+    ([256] * 6, [256] * 6, 8, 8, 72, None),            # Hiera stage 3: 16 x 16 windows, 8 heads x 72
+    ([64] * 20, [64] * 20, 2, 2, 72, None),            # Hiera stage 1 / 4: 8 x 8 windows
+    ([64] * 9, [64] * 9, 16, 16, 80, None),            # ViT windows (grad-enabled path: rope applied beforehand)
+    ([64] * 5, [256] * 5, 4, 4, 72, None),             # pooled queries against the un-pooled window
+    ([256, 100, 7, 200, 129], [256, 100, 7, 200, 129], 3, 3, 64, None),   # ragged segments, partial last key tile, idle waves
+    ([130, 64], [190, 33], 4, 2, 32, None),            # GQA, Lq != Lk, D = 32 (padded to 64)
+    ([64] * 6, [64] * 6, 4, 4, 72, (16, 16)),          # 16-token windows packed four to a segment, block-diagonal visibility
+    ([16] * 6, [64] * 6, 4, 4, 72, (4, 16)),           # 4 pooled queries x 16 keys per packed window
+])
+def test_attn_window_kernel(dev, lq, lk, Hq, Hkv, D, block):
+    """Whole-segment-in-LDS window kernel (taken when max_k <= 256 is passed, non-causal): vs the softmax oracle, vs the pipelined kernel (impl=2 keeps it),
+    with q / k / v as slices of one packed qkv buffer (the layout the models hand over) and with the log-sum-exp output."""
+    from rga3.hip import ops
+
+    Tq, Tk = sum(lq), sum(lk)
+    same = lq == lk
+    if same:
+        buf = _rand((Tq, Hq + 2 * Hkv, D), dev, 0.8, seed=5)
+        q, k, v = buf[:, :Hq], buf[:, Hq:Hq + Hkv], buf[:, Hq + Hkv:]
+    else:
+        q, k, v = _rand((Tq, Hq, D), dev, 0.8, seed=5), _rand((Tk, Hkv, D), dev, 0.8, seed=6), _rand((Tk, Hkv, D), dev, 0.8, seed=7)
+    cu_q = torch.tensor([0] + list(np.cumsum(lq)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(lk)), dtype=torch.int32)
+    scale = D ** -0.5
+    out, lse = ops.attn_varlen(q, k, v, cu_q.to(dev), cu_k.to(dev), max(lq), scale, causal=False, return_lse=True, block=block, max_k=max(lk))
+    old = ops.attn_varlen(q, k, v, cu_q.to(dev), cu_k.to(dev), max(lq), scale, causal=False, block=block, max_k=max(lk), impl=2)
+    assert _rel_l2(out, old.float().cpu()) < 4e-3
+    if block is None:
+        ref, rlse = R.attn_varlen_ref(q.cpu(), k.cpu(), v.cpu(), cu_q, cu_k, scale, False)
+    else:   # block-diagonal visibility = independent windows of (block_q queries, block_k keys)
+        bq, bk = block
+        nb = Tq // bq
+        cq = torch.arange(0, (nb + 1) * bq, bq, dtype=torch.int32)
+        ck = torch.arange(0, (nb + 1) * bk, bk, dtype=torch.int32)
+        ref, rlse = R.attn_varlen_ref(q.cpu(), k.cpu(), v.cpu(), cq, ck, scale, False)
+    assert _rel_l2(out, ref) < 8e-3
+    assert float((lse.float().cpu() - rlse).abs().max()) < 2e-2
 
 
 def test_attn_forced_rescale(dev):
