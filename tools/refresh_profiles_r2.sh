@@ -39,3 +39,10 @@ python3 $R/tools/evaluate_probe.py > $O/r02_evaluate_probe.log 2>&1; tail -1 $O/
 python3 $R/tools/generate_probe.py 64 > $O/r02_generate_probe.log 2>&1; tail -1 $O/r02_generate_probe.log
 # 5. functional two-rank run of the training step on the one GPU (gloo, both ranks on device 0): bucket order, sparse row exchange, side streams
 RGA3_BENCH_SHARE_GPU=1 RGA3_BENCH_BACKEND=gloo timeout 900 $B --gpus 2 --mode train_full --steps 2 --warmup 1 --no-cpu-baseline > $O/r02_two_ranks_shared_gpu.json 2> $O/r02_two_ranks_shared_gpu.err; tail -c 600 $O/r02_two_ranks_shared_gpu.json; tail -3 $O/r02_two_ranks_shared_gpu.err
+# 6. where the step goes: per-shape GEMM table, timeline + non-GEMM kernel table of one training step, gaps
+python3 $R/tools/gemm_shape_table.py $O/r02_train_gemm_shapes.json > $O/r02_train_gemm_shapes.txt 2>&1; head -12 $O/r02_train_gemm_shapes.txt | grep -v amdgpu
+rm -rf /tmp/pt; rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -o tr -- $B --mode train_full --steps 4 --warmup 3 --no-cpu-baseline > $O/r02_prof_train_trace.log 2>&1
+python3 $R/tools/step_timeline.py /tmp/pt --bin-ms 5 --from-ms 0 --to-ms 1000 --exclude gemm_ > $O/r02_train_step_timeline.txt 2>&1; tail -n +2 $O/r02_train_step_timeline.txt | head -3
+python3 $R/tools/trace_gaps.py /tmp/pt --last-ms 600 > $O/r02_train_gaps.txt 2>&1; head -1 $O/r02_train_gaps.txt
+# 7. the GPU test suite
+cd $R && python3 -m pytest tests -m gpu -q > $O/r02_gpu_tests.log 2>&1; tail -2 $O/r02_gpu_tests.log
