@@ -786,9 +786,11 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": ("BASELINE.json configs[2] per GPU: " if full else "") +
                                        "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd (layer activations kept in HBM, no recompute), LoRA r128 (alpha 256, dropout 0.05) q/v + lm_head + embed_tokens "
-                                       "trainable, AdamW step, bucketed RCCL all-reduce (embed_tokens rows exchanged sparsely); 16 frames 448x448, S=2112, 1 sample/GPU" +
+                                       "trainable, AdamW step (weight decay 0 as in the reference; embed_tokens rows that never received a gradient -- g = m = v = 0, exactly unchanged by "
+                                       "AdamW -- are not streamed), bucketed RCCL all-reduce (embed_tokens rows exchanged sparsely); 16 frames 448x448, S=2112, 1 sample/GPU" +
                                        (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)" if full else ""),
-                           "per_gpu_batch": 1, "seq_len": 2112, "parallelism": f"dp{world}", "trainable_params": n_train, "flops_per_sample": fl},
+                           "per_gpu_batch": 1, "seq_len": 2112, "parallelism": f"dp{world}", "trainable_params": n_train, "flops_per_sample": fl,
+                           "adamw_embed_rows_updated": int(sum(int(m.sum()) for m in getattr(opt, "_row_mask", {}).values())) or None},
                 "roofline": fwd_roof if fwd_roof is not None else rfb, "roofline_fwd_bwd": rfb,
                 "verify": dict(fwd_verify or {}, loss_first_last=[round(float(lv[0]), 5), round(float(lv[-1]), 5)]),
                 "comm": comm, "cpu_baseline": cpu}

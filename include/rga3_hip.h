@@ -223,6 +223,10 @@ int rga3_sumsq_det(const void* g, int64_t n, float* partials, int64_t partials_c
  * All pointers 16-byte aligned. */
 int rga3_adamw_step_clip(void* param, float* master, const void* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int step, const float* sumsq, float max_norm, void* stream);
+/* the same update (weight decay 0) for a [rows, row_len] table, restricted to the rows with row_active[r] != 0: a row that never received a gradient has
+   g = m = v = 0 and stays bit-for-bit unchanged under AdamW without weight decay, so skipping it is exact (embed_tokens: <= S of 152 064 rows per sample) */
+int rga3_adamw_step_clip_rows(void* param, float* master, const void* grad, float* m, float* v, int64_t rows, int64_t row_len, const uint8_t* row_active,
+                              float lr, float beta1, float beta2, float eps, int step, const float* sumsq, float max_norm, void* stream);
 /* dst[idx[i], :] += scale * src[i, :] on bf16 rows, idx UNIQUE within the call: applies one rank's (row ids, rows) contribution to the
  * embed_tokens gradient (the sparse replacement of the 1.09 GB dense bucket of the reference's ZeRO-2 exchange, train_joint.py:325-334). */
 int rga3_scatter_add_rows(void* dst, const int64_t* idx, const void* src, int64_t n, int64_t dim, int64_t ld_dst, int64_t ld_src, float scale,

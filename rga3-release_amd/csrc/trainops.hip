@@ -259,12 +259,15 @@ __global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restri
 //      on the device from the norm sumsq_* left there (torch.nn.utils.clip_grad_norm_ / DeepSpeed gradient_clipping semantics, train_joint.py:324)
 __global__ __launch_bounds__(256) void adamw8_kernel(unsigned short* __restrict__ p, float* __restrict__ master, const unsigned short* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                     float wd, float bc1, float bc2, const float* __restrict__ sumsq, float max_norm) {
+                                                     float wd, float bc1, float bc2, const float* __restrict__ sumsq, float max_norm,
+                                                     const unsigned char* __restrict__ row_active, long row_len8) {
     float gscale = 1.f;
     if (sumsq) gscale = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
     const long n8 = n / 8;
     const float decay = 1.f - lr * wd, ibc1 = 1.f / bc1, ibc2 = 1.f / bc2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        // rows whose gradient AND both moments are exactly zero (never touched) are left alone: with weight decay 0 their update is exactly zero
+        if (row_active && !row_active[i / row_len8]) continue;
         float gr[8], w[8], mi[8], vi[8];
         un8(*(const u32x4*)(g + i * 8), gr);
         *(f32x4*)(w) = *(const f32x4*)(master + i * 8);     *(f32x4*)(w + 4) = *(const f32x4*)(master + i * 8 + 4);
@@ -453,8 +456,23 @@ extern "C" int rga3_adamw_step_clip(void* param, float* master, const void* grad
     RGA3_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_step_clip: pointers must be 16-byte aligned");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw8_kernel, dim3(g1(cdiv(n, 8), 256L * 16)), dim3(256), 0, (hipStream_t)stream, (us)param, master, (cus)grad, m, v, (long)n, lr, beta1, beta2,
-                       eps, weight_decay, bc1, bc2, sumsq, max_norm);
+                       eps, weight_decay, bc1, bc2, sumsq, max_norm, (const unsigned char*)nullptr, 1L);
     RGA3_CHECK_LAUNCH("adamw_step_clip");
+    return 0;
+}
+
+// The same update for a [rows, row_len] table (embed_tokens) of which only the rows with row_active[r] != 0 are touched.  A row that never received a
+// gradient has g = m = v = 0, and with weight_decay == 0 AdamW leaves it bit-for-bit unchanged (m, v stay 0, the step is lr * 0 / (0 + eps)) -- skipping it
+// is exact, and one training sample touches <= S of the 152 064 rows (the dense update streams 30 B per element: 16 GB for the table).
+extern "C" int rga3_adamw_step_clip_rows(void* param, float* master, const void* grad, float* m, float* v, int64_t rows, int64_t row_len, const uint8_t* row_active,
+                                         float lr, float beta1, float beta2, float eps, int step, const float* sumsq, float max_norm, void* stream) {
+    RGA3_CHECK_ARG(param && master && grad && m && v && row_active && rows > 0 && row_len > 0 && row_len % 8 == 0 && step >= 1, "adamw_step_clip_rows: bad args (row_len % 8)");
+    RGA3_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)master | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_step_clip_rows: pointers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    const int64_t n = rows * row_len;
+    hipLaunchKernelGGL(adamw8_kernel, dim3(g1(cdiv(n, 8), 256L * 16)), dim3(256), 0, (hipStream_t)stream, (us)param, master, (cus)grad, m, v, (long)n, lr, beta1, beta2,
+                       eps, 0.f, bc1, bc2, sumsq, max_norm, row_active, (long)(row_len / 8));
+    RGA3_CHECK_LAUNCH("adamw_step_clip_rows");
     return 0;
 }
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "rga3_sumsq_accum": [_p, _p, _i64, _p],
     "rga3_sumsq_det": [_p, _i64, _p, _i64, _p, _i, _p],
     "rga3_adamw_step_clip": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p, _f, _p],
+    "rga3_adamw_step_clip_rows": [_p, _p, _p, _p, _p, _i64, _i64, _p, _f, _f, _f, _f, _i, _p, _f, _p],
     "rga3_scatter_add_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
     "rga3_layernorm_bwd_ws_floats": [_i64, _i64],
     "rga3_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _p, _i64, _p],

@@ -585,6 +585,16 @@ def adamw_step_clip_(param, master, grad, m, v, lr, beta1, beta2, eps, weight_de
                "adamw_step_clip")
 
 
+def adamw_step_clip_rows_(param, master, grad, m, v, row_active, lr, beta1, beta2, eps, step: int, sumsq=None, max_norm: float = 0.0):
+    """adamw_step_clip_ (weight decay 0) on the rows r of a [rows, row_len] table with row_active[r] != 0; the other rows (g = m = v = 0) are exactly unchanged."""
+    _need_cuda(param, master, grad, m, v, row_active, sumsq)
+    assert param.dtype == grad.dtype == torch.bfloat16 and master.dtype == m.dtype == v.dtype == torch.float32 and row_active.dtype == torch.uint8
+    assert param.dim() == 2 and param.is_contiguous() and grad.is_contiguous() and master.is_contiguous() and row_active.numel() == param.shape[0]
+    _lib.check(_lib.load().rga3_adamw_step_clip_rows(param.data_ptr(), master.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.shape[0], param.shape[1],
+                                                     row_active.data_ptr(), float(lr), float(beta1), float(beta2), float(eps), int(step), _ptr(sumsq), float(max_norm),
+                                                     _stream()), "adamw_step_clip_rows")
+
+
 def scatter_add_rows_(dst, idx, src, scale: float = 1.0):
     """dst[idx[i]] += scale * src[i] (bf16 rows, idx unique within the call)."""
     _need_cuda(dst, idx, src)

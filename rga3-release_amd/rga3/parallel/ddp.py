@@ -372,6 +372,7 @@ class FusedAdamW:
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.schedule = schedule
         self._flat = None
+        self._sparse_src, self._row_mask = {}, {}
         if layout is not None:
             self._init_flat(layout)
         else:
@@ -388,12 +389,16 @@ class FusedAdamW:
         """Optimizer state laid out like the reducer's gradient buckets: ONE AdamW launch per bucket.  (Per-tensor launches left the GPU idle between the
         ~130 small kernels of a step: the host needs ~20 us per launch, a LoRA factor's update takes 3 us -- 2.9 ms of a 170 ms step.)  The bf16 parameters of a
         multi-tensor bucket are re-pointed at slices of one flat buffer (values unchanged), as DDP / FSDP flat parameters are."""
-        return cls(reducer.all_params, layout=reducer.layout(), **kw)
+        opt = cls(reducer.all_params, layout=reducer.layout(), **kw)
+        # tables whose gradient arrives as (row ids, rows): AdamW then touches only the rows that ever received a gradient (exact without weight decay, see step())
+        opt._sparse_src = {id(st["p"]): st for st in reducer._sp.values()}
+        return opt
 
     def _init_flat(self, layout):
         order = {id(p): i for i, p in enumerate(self.params)}
         self.master, self.m, self.v = [None] * len(self.params), [None] * len(self.params), [None] * len(self.params)
         self._flat = []
+        self._flat_single = []     # the one 2-D parameter a flat entry consists of (None for multi-tensor buckets)
         with torch.no_grad():
             for flat_g, items in layout:
                 n = flat_g.numel()
@@ -408,6 +413,7 @@ class FusedAdamW:
                 fm = flat_p.float()
                 fmm, fv = torch.zeros_like(fm), torch.zeros_like(fm)
                 self._flat.append((flat_p, fm, flat_g, fmm, fv))
+                self._flat_single.append(items[0][0] if len(items) == 1 and items[0][0].dim() == 2 and items[0][2] == n else None)
                 for p, off, k in items:
                     i = order[id(p)]
                     self.master[i], self.m[i], self.v[i] = fm[off:off + k].view(p.shape), fmm[off:off + k].view(p.shape), fv[off:off + k].view(p.shape)
@@ -430,6 +436,7 @@ class FusedAdamW:
                 "master": [w.detach().cpu() for w in self.master], "m": [x.detach().cpu() for x in self.m], "v": [x.detach().cpu() for x in self.v]}
 
     def load_state_dict(self, sd, write_params: bool = True):
+        self._row_mask = {}     # rebuilt from the loaded moments at the next step
         if len(sd["master"]) != len(self.params) or any(a.shape != b.shape for a, b in zip(sd["master"], self.master)):
             raise ValueError("optimizer state does not match the parameter list (count or shapes differ)")
         self.t, self.lr, self.betas, self.eps, self.wd, self.max_norm = int(sd["t"]), sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"], sd["max_grad_norm"]
@@ -459,7 +466,23 @@ class FusedAdamW:
             if clip:
                 for i, (_, _, g, _, _) in enumerate(self._flat):
                     ops.sumsq_det_(g, self._partials, self._acc, accumulate=i > 0)
-            for fp, fm, g, mm, vv in self._flat:
+            for i, (fp, fm, g, mm, vv) in enumerate(self._flat):
+                p1 = self._flat_single[i]
+                st = self._sparse_src.get(id(p1)) if p1 is not None else None
+                if st is not None and self.wd == 0.0 and p1.shape[1] % 8 == 0:
+                    # embed_tokens: only rows that ever received a gradient are updated.  A never-touched row has g = m = v = 0, and without weight decay
+                    # AdamW leaves it bit-for-bit unchanged, so this equals the dense update (tests/test_train_gpu.py) while streaming <= S of 152 064 rows.
+                    mask = self._row_mask.get(i)
+                    if mask is None:
+                        mask = self._row_mask[i] = self._rows_with_state(mm, vv, p1.shape)
+                    ids = st.get("last_ids")
+                    if ids is not None:
+                        if ids.numel():
+                            mask.index_fill_(0, ids, 1)
+                        ops.adamw_step_clip_rows_(fp.view(p1.shape), fm.view(p1.shape), g.view(p1.shape), mm.view(p1.shape), vv.view(p1.shape), mask, lr, self.betas[0],
+                                                  self.betas[1], self.eps, self.t, self._acc if clip else None, self.max_norm if clip else 0.0)
+                        continue
+                    self._row_mask.pop(i)     # the rows of this step are unknown (finish() was not called): dense update, the mask is rebuilt from the moments
                 ops.adamw_step_clip_(fp, fm, g, mm, vv, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, self._acc if clip else None,
                                      self.max_norm if clip else 0.0)
             self._bump_versions()
@@ -474,6 +497,11 @@ class FusedAdamW:
             ops.adamw_step_clip_(p.data, w, g, m, v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
                                  self._acc if clip else None, self.max_norm if clip else 0.0)
         self._bump_versions()
+
+    @staticmethod
+    def _rows_with_state(m, v, shape):
+        """uint8 [rows]: 1 where a row of the moments is not all zero (fresh optimizer: all 0; after load_state_dict: the rows trained so far)."""
+        return ((m.view(shape) != 0).any(1) | (v.view(shape) != 0).any(1)).to(torch.uint8)
 
     def _bump_versions(self):
         """The update kernels write the parameters through raw pointers; derived tensors cached by (data_ptr, version) elsewhere (the ConvTranspose weight
