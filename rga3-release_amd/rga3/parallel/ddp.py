@@ -299,7 +299,7 @@ class GradBucketReducer:
                 rid = all_ids[r * cap:r * cap + n]
                 _scatter_add(d, rid, all_rows[r * cap:r * cap + n], 1.0 / self.world)
                 touched.append(rid)
-        st["last_ids"] = torch.cat(touched) if touched else None
+        st["last_ids"] = torch.unique(torch.cat(touched)) if touched else None   # unique: the optimizer sums the gradient norm over exactly these rows
 
     def remove(self):
         for h in self._hooks:
@@ -465,6 +465,11 @@ class FusedAdamW:
         if self._flat is not None:   # one launch per bucket (gradients are the reducer's flat buckets themselves)
             if clip:
                 for i, (_, _, g, _, _) in enumerate(self._flat):
+                    p1 = self._flat_single[i]
+                    st = self._sparse_src.get(id(p1)) if p1 is not None else None
+                    ids = st.get("last_ids") if st is not None else None
+                    if ids is not None:      # the dense buffer of a sparse table is zero outside this step's rows: sum those (<= S rows instead of 1.09 GB)
+                        g = ops.gather_rows(g.view(p1.shape), ids).view(-1) if ids.numel() else g[:8]
                     ops.sumsq_det_(g, self._partials, self._acc, accumulate=i > 0)
             for i, (fp, fm, g, mm, vv) in enumerate(self._flat):
                 p1 = self._flat_single[i]

@@ -1,9 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests/test_train_gpu.py tests/test_unigr_gpu.py -x -q -m gpu > $O/r3j_tests.log 2>&1; tail -5 $O/r3j_tests.log | cut -c1-250
+timeout 1500 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" > $O/r3k_tests.log 2>&1; tail -3 $O/r3k_tests.log | cut -c1-250
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --mode train_full --steps 10 --warmup 3 --no-cpu-baseline > $O/r3j_train.json 2> $O/r3j_train.err; python3 -c "
-import json;d=json.loads(open('$O/r3j_train.json').read().strip().splitlines()[-1]);print('TRAIN',d['value'],d['ms_per_step'],d['config'].get('adamw_embed_rows_updated'))"
-python3 $R/bench.py --mode forward --steps 20 --warmup 5 --no-cpu-baseline > $O/r3j_fwd.json 2> $O/r3j_fwd.err; python3 -c "
-import json;d=json.loads(open('$O/r3j_fwd.json').read().strip().splitlines()[-1]);print('FWD',d['ms_per_step'],d['roofline']['frac'],d['roofline'].get('whole_forward_frac'))"
+timeout 900 python3 $R/tools/gemm_tile_probe.py > $O/r3k_tiles.txt 2>&1; grep -v amdgpu.ids $O/r3k_tiles.txt | grep "M=2112" | cut -c1-220
