@@ -113,6 +113,13 @@ int rga3_rmsnorm_fwd(const void* x, const void* add, const void* weight, void* y
  * act: 0 none, 1 exact GELU applied to the normalised output (MaskDownSampler / output_upscaling, :611-643, :1976-1986). */
 int rga3_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int64_t dim,
                        int64_t ldx, int64_t ldy, float eps, int act, void* stream);
+/* LayerNorm folded into the consuming product (Hiera norm1 -> qkv, norm2 -> fc1, reference model/sam2.py:1035-1117): rga3_layernorm_stats writes
+ * stats [rows][2] f32 = (mean, 1/sqrt(var + eps)) -- one read of x instead of LayerNorm's read + write -- and rga3_gemm_ln_bf16 computes
+ * C = act(LayerNorm(A) W^T + b) as rinv_r (A Wf^T - mean_r c_n) + bias_n with Wf = W diag(gamma) (bf16), colc_n = sum_k Wf_nk (f32), bias = beta W^T + b (bf16).
+ * act none / gelu / relu; tile -1 or 3 / 5 / 12 / 13 / 20 (see rga3_gemm_bf16); K % 8 == 0, N % 4 == 0. */
+int rga3_layernorm_stats(const void* x, float* stats, int64_t rows, int64_t dim, int64_t ldx, float eps, void* stream);
+int rga3_gemm_ln_bf16(const void* A, const void* Wf, const void* bias, const float* colc, const float* rowstat, void* C, int64_t M, int64_t N, int64_t K,
+                      int64_t lda, int64_t ldw, int64_t ldc, int act, int tile, void* stream);
 
 /* In-place rotary embedding on q and k heads living inside one [T, nheads_total, D] buffer (fused QKV output):
  * x = x*cos + rotate_half(x)*sin in fp32, cos/sin: [T, D] f32 tables (HF apply_rotary_pos_emb_vision

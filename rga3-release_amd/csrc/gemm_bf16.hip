@@ -41,6 +41,8 @@ struct GemmArgs {
     int group_m;  // tile rows per group of the tile order (see launchers)
     void* ws;     // caller workspace for the stream-K / split-K tilings (may be null)
     long ws_bytes;
+    const float* rowstat;  // LNF epilogues: [M][2] = (mean, 1/sqrt(var + eps)) of the rows of A (rga3_layernorm_stats)
+    const float* colc;     // LNF epilogues: [N] column sums of the gamma-folded weight
     int ksl;      // gemm_nt_kernel only: K-tiles per grid.y slice (0: no split); slice y accumulates K-tiles [y ksl, (y+1) ksl) into f32 slab y of C
 };
 
@@ -69,9 +71,13 @@ constexpr int epi_wave_bytes() {  // LDS staging bytes one wave needs in gemm_ep
     return 16 * (((ACT == ACT_SWIGLU) ? NTL / 2 : NTL) * 16 * (OUT_F32 ? 4 : 2) + 16);
 }
 
-template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32>
+// LNF (LayerNorm folded into the product, rga3_gemm_ln_bf16): A holds the UN-normalised rows x, W the weight with gamma folded in (W' = W . diag(gamma)), and
+//   LN(x) W^T + b  =  rinv_r (x W'^T - mean_r c_n) + d_n,   c_n = sum_k W'_nk,   d_n = sum_k beta_k W_nk + b_n  (handed over as the bias),
+// so the normalised activations are never written or re-read: a row-statistics pass (one read of x) replaces the LayerNorm pass (read + write).
+template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmArgs& p, char* est, int lane, int m0, int n0,
                                               int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr) {
+    static_assert(!(LNF && ACT == ACT_SWIGLU), "the LayerNorm-folded epilogue has no SwiGLU form");
     // part1 / part2 (stream-K owner slices only): this lane's view of up to two f32 partial-sum slabs in accumulator order
     // (quad (i, j) at [(i * NTL + j) * 64]).  They are added to the accumulators as those are READ, one m-tile ahead of use,
     // so the accumulator registers are never modified after the main loop (a post-loop "acc += slab" makes the register
@@ -105,11 +111,19 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     };
     auto pick = [](const u32x2& pk, int r) -> float { return __uint_as_float((r & 1) ? (pk[r >> 1] & 0xffff0000u) : (pk[r >> 1] << 16)); };
     u32x2 bpk[NTL];
+    f32x4 cc[LNF ? NTL : 1];
     {
         const int g4 = (lane >> 4) * 4;
         if (p.bias) {
 #pragma unroll
             for (int j = 0; j < NTL; ++j) bpk[j] = load4(p.bias, n0 + wn * WTN + j * 16 + g4, p.N);
+        }
+        if constexpr (LNF) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int col = n0 + wn * WTN + j * 16 + g4;
+                cc[j] = (col + 3 < p.N) ? *(const f32x4*)(p.colc + col) : f32x4{0.f, 0.f, 0.f, 0.f};   // N % 4 == 0 (checked by the entry point)
+            }
         }
     }
 
@@ -136,6 +150,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
         }
         u32x2 pk[OUT_NT];
         f32x4 vf[OUT_F32 ? OUT_NT : 1];
+        float ln_mean = 0.f, ln_rinv = 1.f;
+        if constexpr (LNF) {
+            const int rrow = min(m0 + wm * WTM + i * 16 + (lane & 15), p.M - 1);
+            const float2 st2 = *(const float2*)(p.rowstat + 2L * rrow);
+            ln_mean = st2.x;
+            ln_rinv = st2.y;
+        }
 #pragma unroll
         for (int jo = 0; jo < OUT_NT; ++jo) {
             float v[4];
@@ -158,6 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[i][jo][r] + pc[jo][r];
+                    if constexpr (LNF) x = ln_rinv * (x - ln_mean * cc[jo][r]);
                     if (p.bias) x += pick(bpk[jo], r);
                     if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
                     if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
@@ -249,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     }
 }
 
-template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE>
+template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE, bool LNF = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int BK = 64;
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     }
     }
     __syncthreads();  // all waves done with the last stage: LDS is free for the epilogue staging
-    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wm, wn);
+    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wm, wn);
 }
 
 // =====================================================================================================================
@@ -390,7 +412,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
 //    into a region whose last read was >= 2 phases earlier, then waits until all but the 4 youngest half-tiles (8 loads
 //    per lane) have landed => S[<= g+2] are complete, and they are first read in phase g+1 (two barriers later).
 // LDS: 2 buffers x 4 half-tiles x 16 KiB = 128 KiB, one workgroup per CU, 2 waves per SIMD.
-template <int ACT, bool OUT_F32>
+template <int ACT, bool OUT_F32, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
     constexpr int HALF = 128 * ROWB;  // 16 KiB
@@ -548,7 +570,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the groups
     __syncthreads();  // LDS is free for the epilogue staging
-    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wr, wc);
+    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wr, wc);
 }
 
 // In-place accumulate (C-in register == C-out register).  The builtin lets the register allocator pick a different
@@ -953,7 +975,7 @@ static int sk_workspace(void* ws, int64_t ws_bytes, SkWorkspace& out) {
     return 0;
 }
 
-template <int ACT, bool OUT_F32>
+template <int ACT, bool OUT_F32, bool LNF = false>
 static int launch_pp(const GemmArgs& a0, hipStream_t st);
 
 template <int ACT, bool OUT_F32, int MH = 4>
@@ -1047,14 +1069,14 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
-template <int ACT, bool OUT_F32>
+template <int ACT, bool OUT_F32, bool LNF>
 static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.group_m = pick_group_m(a.ntm, 256);
     constexpr int LDS = 2 * 4 * 128 * 128;
-    auto kern = gemm_nt_pp_kernel<ACT, OUT_F32>;
+    auto kern = gemm_nt_pp_kernel<ACT, OUT_F32, LNF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1066,7 +1088,7 @@ static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE>
+template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE, bool LNF = false>
 static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, BM);
@@ -1074,7 +1096,7 @@ static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     a.group_m = pick_group_m(a.ntm, BM);
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int LDS = 2 * STAGE;
-    auto kern = gemm_nt_kernel<BM, BN, WM, WN, ACT, OUT_F32, PIPE>;
+    auto kern = gemm_nt_kernel<BM, BN, WM, WN, ACT, OUT_F32, PIPE, LNF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1465,7 +1487,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.colscale = (const unsigned short*)colscale;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
-    a.ws = workspace; a.ws_bytes = workspace_bytes; a.ksl = 0;
+    a.ws = workspace; a.ws_bytes = workspace_bytes; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
     hipStream_t st = (hipStream_t)stream;
     RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
     int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
@@ -1476,6 +1498,41 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
         case ACT_SWIGLU: return launch_act<ACT_SWIGLU, false>(a, tl, st);
         default: return launch_act<ACT_RELU, false>(a, tl, st);
     }
+}
+
+template <int ACT>
+static int launch_ln(const GemmArgs& a, int tile, hipStream_t st) {
+    switch (tile) {
+        case 3: return launch_cfg<128, 256, 2, 4, ACT, false, 0, true>(a, st);
+        case 5: return launch_cfg<128, 192, 2, 4, ACT, false, 0, true>(a, st);
+        case 13: return launch_cfg<64, 64, 2, 2, ACT, false, 0, true>(a, st);
+        case 20: return launch_pp<ACT, false, true>(a, st);
+        default: return launch_cfg<128, 128, 2, 2, ACT, false, 0, true>(a, st);
+    }
+}
+
+// C[M, N] (bf16) = act(LayerNorm(A) . W^T + b) with the LayerNorm folded into the product (see gemm_epilogue, LNF): A [M, K] un-normalised rows, Wf [N, K] the
+// weight with gamma folded in, colc [N] f32 column sums of Wf, bias [N] bf16 = beta . W^T + b, rowstat [M][2] f32 from rga3_layernorm_stats.
+// act: none / gelu / relu.  tile: -1 (128 x 128) or 3 / 5 / 12 / 13 / 20.
+extern "C" int rga3_gemm_ln_bf16(const void* A, const void* Wf, const void* bias, const float* colc, const float* rowstat, void* C, int64_t M, int64_t N, int64_t K,
+                                 int64_t lda, int64_t ldw, int64_t ldc, int act, int tile, void* stream) {
+    RGA3_CHECK_ARG(A && Wf && C && colc && rowstat, "gemm_ln: null pointer");
+    RGA3_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0, "gemm_ln: bad shape M=%ld N=%ld K=%ld (K %% 8, N %% 4)", (long)M, (long)N, (long)K);
+    RGA3_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "gemm_ln: lda/ldw must be multiples of 8 elements");
+    RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)C | (uintptr_t)colc) & 15) == 0 && (((uintptr_t)rowstat) & 7) == 0, "gemm_ln: pointer alignment");
+    RGA3_CHECK_ARG(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU, "gemm_ln: act %d", act);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 5 || tile == 12 || tile == 13 || tile == 20, "gemm_ln: tile %d", tile);
+    RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm_ln: operands must be < 2^32 elements");
+    GemmArgs a;
+    a.A = (const unsigned short*)A; a.W = (const unsigned short*)Wf; a.C = C;
+    a.bias = (const unsigned short*)bias; a.res = nullptr; a.colscale = nullptr;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = 0;
+    a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = rowstat; a.colc = colc;
+    hipStream_t st = (hipStream_t)stream;
+    if (act == ACT_GELU) return launch_ln<ACT_GELU>(a, tile, st);
+    if (act == ACT_RELU) return launch_ln<ACT_RELU>(a, tile, st);
+    return launch_ln<ACT_NONE>(a, tile, st);
 }
 
 // C[M, N] (bf16 or f32) = A^T . B (+ bias[n]) with A [K, M], B [K, N] bf16 row-major: the weight-gradient product dW = dY^T X without
@@ -1494,7 +1551,7 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = 0; a.ldw = 0; a.ldc = ldc; a.ldr = 0;
     a.ntm = (int)cdiv(M, 128); a.ntn = (int)cdiv(N, 128); a.group_m = 1;
-    a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0;
+    a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
     TnArgs t;
     t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
     const int nk = (int)cdiv(K, 32);

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void rmsnorm_block_kernel(const unsigned short
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                                         const unsigned short* __restrict__ b, unsigned short* __restrict__ y,
-                                                        long rows, int dim, long ldx, long ldy, float eps, int act) {
+                                                        long rows, int dim, long ldx, long ldy, float eps, int act, float* __restrict__ stats = nullptr) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -170,6 +170,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
         }
     }
     const float rinv = rsqrtf(wave_sum(s2) / (float)dim + eps);
+    if (stats) {   // statistics only (the normalisation itself is folded into the consuming product: rga3_gemm_ln_bf16)
+        if (lane == 0) *(float2*)(stats + 2 * row) = make_float2(mean, rinv);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int ch = lane + i * 64;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const unsigned short* __
 template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                                              const unsigned short* __restrict__ b, unsigned short* __restrict__ y,
-                                                             long rows, int dim, long ldx, long ldy, float eps, int act) {
+                                                             long rows, int dim, long ldx, long ldy, float eps, int act, float* __restrict__ stats = nullptr) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
@@ -227,6 +231,10 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const unsigned shor
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
     const float rinv = rsqrtf(s2 / (float)dim + eps);
+    if (stats) {
+        if (live && sub == 0) *(float2*)(stats + 2 * row) = make_float2(mean, rinv);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int ch = sub + i * LPR;
@@ -484,13 +492,30 @@ extern "C" int rga3_layernorm_fwd(const void* x, const void* weight, const void*
     const unsigned short *xp = (const unsigned short*)x, *wp = (const unsigned short*)weight, *bp = (const unsigned short*)bias;
     unsigned short* yp = (unsigned short*)y;
     if (dim <= 16 * 8 * 2) {          // <= 32 chunks: 16 lanes per row, 4 rows per wave
-        hipLaunchKernelGGL(layernorm_rows_kernel<16>, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+        hipLaunchKernelGGL(layernorm_rows_kernel<16>, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act, (float*)nullptr);
     } else if (dim <= 32 * 8 * 2) {   // <= 64 chunks: 32 lanes per row, 2 rows per wave
-        hipLaunchKernelGGL(layernorm_rows_kernel<32>, dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
-    } else if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
-    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
-    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act);
+        hipLaunchKernelGGL(layernorm_rows_kernel<32>, dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act, (float*)nullptr);
+    } else if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act, (float*)nullptr);
+    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act, (float*)nullptr);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, wp, bp, yp, (long)rows, (int)dim, (long)ldx, (long)ldy, eps, act, (float*)nullptr);
     RGA3_CHECK_LAUNCH("layernorm_kernel");
+    return 0;
+}
+
+// stats [rows][2] f32 = (mean, 1 / sqrt(var + eps)) of every row of x (biased variance, two passes over the register-resident row: LayerNorm's own statistics)
+extern "C" int rga3_layernorm_stats(const void* x, float* stats, int64_t rows, int64_t dim, int64_t ldx, float eps, void* stream) {
+    RGA3_CHECK_ARG(x && stats && rows > 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && dim <= 8192, "layernorm_stats: rows=%ld dim=%ld", (long)rows, (long)dim);
+    RGA3_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)stats) & 7) == 0, "layernorm_stats: pointer alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned short* xp = (const unsigned short*)x;
+    const unsigned short* nul = nullptr;
+    dim3 grid((unsigned)cdiv(rows, 4));
+    if (dim <= 16 * 8 * 2) hipLaunchKernelGGL(layernorm_rows_kernel<16>, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
+    else if (dim <= 32 * 8 * 2) hipLaunchKernelGGL(layernorm_rows_kernel<32>, dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
+    else if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
+    else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
+    RGA3_CHECK_LAUNCH("layernorm_stats");
     return 0;
 }
 

@@ -26,6 +26,8 @@ SIGNATURES = {
     "rga3_attn_varlen_fwd_rope": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _p, _p, _p, _p, _p],
     "rga3_rmsnorm_fwd": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _p],
     "rga3_layernorm_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _i, _p],
+    "rga3_layernorm_stats": [_p, _p, _i64, _i64, _i64, _f, _p],
+    "rga3_gemm_ln_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p],
     "rga3_rope_inplace": [_p, _p, _p, _i64, _i, _i, _i, _i64, _i64, _p],
     "rga3_gather_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "rga3_scatter_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],

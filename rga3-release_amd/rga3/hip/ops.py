@@ -114,6 +114,56 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     return out
 
 
+def layernorm_stats(x, eps: float):
+    """[rows, 2] f32 = (mean, 1/sqrt(var + eps)) of the rows of x [rows, dim] bf16 (row stride free): the input of gemm_ln."""
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    st = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rga3_layernorm_stats(x.data_ptr(), st.data_ptr(), x.shape[0], x.shape[1], x.stride(0), float(eps), _stream()), "layernorm_stats")
+    return st
+
+
+def fold_layernorm(weight, bias, gamma, beta):
+    """(Wf, colc, biasf) for gemm_ln: LayerNorm(x; gamma, beta) @ weight.T + bias  ==  rinv (x @ Wf.T - mean colc) + biasf.
+    Wf = bf16(weight * gamma) [N, K]; colc = row sums of THAT bf16 matrix in f32 (what the product really multiplies); biasf = bf16(beta @ weight.T + bias)."""
+    w = weight.detach().float()
+    wf = (w * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+    colc = wf.float().sum(1).contiguous()
+    bf = w @ beta.detach().float() if beta is not None else torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+    if bias is not None:
+        bf = bf + bias.detach().float()
+    return wf, colc, bf.to(torch.bfloat16).contiguous()
+
+
+_LN_TILES = (20, 3, 5, 12, 13)
+
+
+def gemm_ln(a, stats, wf, colc, biasf, act: str = "none", out=None, tile: int = -1):
+    """act(LayerNorm(a) @ W.T + b) with the LayerNorm folded into the product: a [M, K] UN-normalised bf16 rows, stats = layernorm_stats(a), (wf, colc, biasf) =
+    fold_layernorm(...).  The normalised activations are never materialised."""
+    _need_cuda(a, stats, wf, colc, biasf, out)
+    assert a.dtype == wf.dtype == torch.bfloat16 and a.dim() == 2 and wf.dim() == 2 and a.shape[1] == wf.shape[1] and a.stride(1) == 1 and wf.is_contiguous()
+    assert stats.dtype == colc.dtype == torch.float32 and stats.shape == (a.shape[0], 2) and stats.is_contiguous() and colc.numel() == wf.shape[0]
+    assert act in ("none", "gelu", "relu") and a.shape[1] % 8 == 0 and wf.shape[0] % 4 == 0
+    M, K = a.shape
+    N = wf.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.bfloat16
+    fn = _lib.load().rga3_gemm_ln_bf16
+
+    def run(t):
+        _lib.check(fn(a.data_ptr(), wf.data_ptr(), _ptr(biasf), colc.data_ptr(), stats.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), wf.stride(0), out.stride(0),
+                      ACT[act], t, _stream()), "gemm_ln_bf16")
+
+    if tile == -1 and M * N * K >= (1 << 24):
+        tile = _tuner.pick(_tuner.key_of(M, N, K, "ln+" + act, BF16, biasf is not None, False), run, candidates=_LN_TILES)
+        if tile not in _LN_TILES:    # a tiling forced for the plain GEMMs (tuner.force) that this entry point does not have
+            tile = -1
+    run(tile)
+    return out
+
+
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None) -> torch.Tensor:
     """out [M, N] = a^T @ b for a [K, M], b [K, N] bf16 (row stride free): dW = dY^T X without transposing either operand."""
     _need_cuda(a, b, out)

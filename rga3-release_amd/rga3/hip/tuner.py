@@ -48,7 +48,7 @@ def key_of(M, N, K, act, out_f32, has_bias, has_res):
     return ((M + 255) // 256, N, K, act, out_f32, has_bias, has_res)
 
 
-def pick(key, run, extra=()):
+def pick(key, run, extra=(), candidates=None):
     """run(tile) launches the GEMM once with that tiling.  Returns the cached / measured best tile id."""
     if _forced[0] is not None:
         return _forced[0]
@@ -61,7 +61,7 @@ def pick(key, run, extra=()):
         return -1
     best, best_ms = -1, float("inf")
     _times[key] = {}
-    for tile in tuple(CANDIDATES) + tuple(extra):
+    for tile in tuple(CANDIDATES if candidates is None else candidates) + tuple(extra):
         run(tile)  # warm (also sets the func attribute for large dynamic LDS)
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record()

@@ -19,6 +19,8 @@ MI355X-first choices (vs. the reference's per-op eager graph):
 """
 from __future__ import annotations
 
+import contextlib
+
 import json
 import math
 import os
@@ -587,7 +589,11 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         for px, grid, tok in ((pixel_values, image_grid_thw, c.image_token_id), (pixel_values_videos, video_grid_thw, c.video_token_id)):
             if px is None:
                 continue
-            emb = self.visual(px, _np(grid))
+            # a frozen tower with constant pixels needs no graph: under no_grad the windowed blocks take the attention kernel that rotates q / k while loading
+            # (no stand-alone rope pass) -- the reference freezes the vision tower during RGA3 training (train_joint.py:193-251 trains LoRA, heads, mask decoder)
+            frozen = not px.requires_grad and not any(p_.requires_grad for p_ in self.visual.parameters())
+            with torch.no_grad() if frozen else contextlib.nullcontext():
+                emb = self.visual(px, _np(grid))
             key = ("where", tok)
             if key not in pl:
                 where = np.flatnonzero(ids_packed_np == tok)

@@ -18,6 +18,7 @@ MI355X-first design differences (outputs proven equal on fixtures, tests/test_sa
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -31,6 +32,9 @@ from .qwen2_5_vl import Linear
 
 
 _DEBUG = None   # set to a dict by tools/grad_locate.py (diagnostic)
+
+
+_LN_FOLD = os.environ.get("RGA3_LN_FOLD", "1") != "0"   # A/B switch: 0 keeps the stand-alone LayerNorm passes in the Hiera trunk
 
 
 def _ag():
@@ -169,6 +173,16 @@ class MultiScaleBlock(nn.Module):
         self.mlp = MLP(dim_out, dim_out * 4, dim_out, 2, act="gelu")
         if dim != dim_out:
             self.proj = Linear(dim, dim_out)
+        self._fold_cache = {}
+
+    def _folded(self, which):
+        """(Wf, colc, biasf) of a projection with the preceding LayerNorm folded in (ops.fold_layernorm), rebuilt when either module's parameters change."""
+        lin, norm = {"qkv": (self.attn.qkv, self.norm1), "proj": (getattr(self, "proj", None), self.norm1), "fc1": (self.mlp.layers[0], self.norm2)}[which]
+        key = (lin.weight.data_ptr(), lin.weight._version, None if lin.bias is None else lin.bias._version, norm.weight.data_ptr(), norm.weight._version, norm.bias._version)
+        c = self._fold_cache.get(which)
+        if c is None or c[0] != key:
+            c = self._fold_cache[which] = (key, ops.fold_layernorm(lin.weight, lin.bias, norm.weight, norm.bias))
+        return c[1]
 
     def forward(self, x, Fn, H, W, layout_w):
         """x [Fn*H*W, dim] in window-major(layout_w) order. Returns (x, H, W, layout_w)."""
@@ -179,19 +193,23 @@ class MultiScaleBlock(nn.Module):
             x = relayout(x, Fn, H, W, layout_w, ws)
             layout_w = ws
         heads, do = self.attn.num_heads, self.dim_out
-        h = self.norm1(x)
+        # frozen trunk (no autograd): both LayerNorms are folded into the products that consume them -- a row-statistics pass (one read of x) and a
+        # gamma-folded weight replace the LayerNorm pass (read + write) and the re-read of its output (rga3_gemm_ln_bf16)
+        fold = _LN_FOLD and not _ag() and x.is_contiguous() and self.dim % 8 == 0
+        st1 = ops.layernorm_stats(x, self.norm1.eps) if fold else None
+        h = None if fold else self.norm1(x)
         T = H * W
         nwin = Fn * (T // (ws * ws)) if ws > 0 else Fn
         seg = ws * ws if ws > 0 else T
         shortcut = x
         if self.dim != self.dim_out:
-            shortcut = self.proj(h)
+            shortcut = ops.gemm_ln(x, st1, *self._folded("proj")) if fold else self.proj(h)
         if self.pool_q:
             if ws == 0:
                 raise NotImplementedError("q-pooling inside a global-attention block does not occur in Hiera configs used by SAM2")
             if self.dim != self.dim_out:
                 shortcut = ops.maxpool2x2_win(shortcut, nwin, ws)
-        qkv = self.attn.qkv(h)                                  # [N, 3*do]
+        qkv = ops.gemm_ln(x, st1, *self._folded("qkv")) if fold else self.attn.qkv(h)   # [N, 3*do]
         q = qkv[:, :do]
         seg_q = seg
         if self.pool_q:
@@ -215,7 +233,11 @@ class MultiScaleBlock(nn.Module):
         x = self.attn.proj(att.view(att.shape[0], do), residual=shortcut)
         if self.pool_q:
             H, W, layout_w = H // 2, W // 2, ws // 2
-        x = self.mlp(self.norm2(x), residual=x)
+        if fold and self.dim_out % 8 == 0:
+            hmid = ops.gemm_ln(x, ops.layernorm_stats(x, self.norm2.eps), *self._folded("fc1"), act="gelu")
+            x = self.mlp.layers[1](hmid, residual=x)
+        else:
+            x = self.mlp(self.norm2(x), residual=x)
         return x, H, W, layout_w
 
 

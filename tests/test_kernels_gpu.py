@@ -67,6 +67,35 @@ def test_gemm_split64_skinny(dev, M, N, K, f32):
     assert torch.equal(ops.gemm(a, w, bias=bias, out_dtype=odt, tile=14), ops.gemm(a, w, bias=bias, out_dtype=odt, tile=13))
 
 
+@pytest.mark.parametrize("M,N,K,act,tile", [(4096, 1728, 576, "none", -1), (4096, 2304, 576, "gelu", 5), (3000, 432, 144, "none", 13), (2500, 1152, 288, "gelu", 3),
+                                            (1000, 576, 576, "none", 20), (700, 48, 16, "none", -1), (513, 260, 72, "relu", 12), (65536, 1728, 576, "none", -1)])
+def test_gemm_layernorm_folded(dev, M, N, K, act, tile):
+    """LayerNorm folded into the consuming product (rga3_layernorm_stats + rga3_gemm_ln_bf16, Hiera norm1 -> qkv / norm2 -> fc1): against fp32 LayerNorm + linear
+    (+ GELU) of the same bf16 operands, and against the un-folded kernels (ops.layernorm + ops.gemm); rows with a large common offset exercise the
+    mean-times-column-sum cancellation."""
+    import torch.nn.functional as F
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 0.7 + torch.randn(M, 1, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    b = (torch.randn(N, generator=g) * 0.2).to(torch.bfloat16).to(dev)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev)
+    beta = (0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev)
+    st = ops.layernorm_stats(x, 1e-6)
+    xf = x.float().cpu()
+    assert torch.allclose(st[:, 0].cpu(), xf.mean(1), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(st[:, 1].cpu(), torch.rsqrt(xf.var(1, unbiased=False) + 1e-6), atol=1e-5, rtol=2e-5)
+    wf, colc, bf = ops.fold_layernorm(w, b, gamma, beta)
+    out = ops.gemm_ln(x, st, wf, colc, bf, act=act, tile=tile)
+    ref = F.layer_norm(xf, (K,), gamma.float().cpu(), beta.float().cpu(), 1e-6) @ w.float().cpu().t() + b.float().cpu()
+    ref = F.gelu(ref) if act == "gelu" else (F.relu(ref) if act == "relu" else ref)
+    unf = ops.gemm(ops.layernorm(x, gamma, beta, 1e-6), w, b, act=act)
+    assert _rel_l2(out, ref) < 8e-3, (M, N, K, act, tile)
+    assert _rel_l2(unf, ref) < 8e-3
+    assert _rel_l2(out, unf.float().cpu()) < 8e-3
+
+
 def test_gemm_stream_k_split_shapes(dev):
     """Tiles 22 / 32 (256- / 192-row stream-K) on shapes whose last round is split over K (1, 2 contributors per tile, ragged M): equal to the unsplit result up to
     the f32 re-association of the split tiles, reproducible run to run, and no slab wait ever timed out."""
