@@ -134,7 +134,7 @@ class GemmTimer:
         self.ops, self.ev, self.flops, self.bytes = ops, [], 0.0, 0.0
         self._real = {}
 
-    def _wrap(self, name, shape_of):
+    def _wrap(self, name, shape_of, w_index=1):
         real = getattr(self.ops, name)
         self._real[name] = real
 
@@ -146,7 +146,7 @@ class GemmTimer:
             self.ev.append((s, e))
             M, N, K = shape_of(a)
             self.flops += 2.0 * M * N * K
-            self.bytes += a[0].numel() * a[0].element_size() + a[1].numel() * a[1].element_size() + r.numel() * r.element_size()
+            self.bytes += a[0].numel() * a[0].element_size() + a[w_index].numel() * a[w_index].element_size() + r.numel() * r.element_size()
             return r
         setattr(self.ops, name, timed)
 
@@ -154,6 +154,7 @@ class GemmTimer:
         self._wrap("gemm", lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]))
         self._wrap("gemm_tn", lambda a: (a[0].shape[1], a[1].shape[1], a[0].shape[0]))
         self._wrap("gemm_fp8", lambda a: (a[0].shape[0], a[2].shape[0], a[0].shape[1]))
+        self._wrap("gemm_ln", lambda a: (a[0].shape[0], a[2].shape[0], a[0].shape[1]), w_index=2)   # LayerNorm-folded products of the Hiera trunk
         return self
 
     def __exit__(self, *exc):
