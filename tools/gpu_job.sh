@@ -1,4 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python3 $R/tools/gemm_tile_probe.py > $O/r3m_tiles.txt 2>&1; grep -v amdgpu.ids $O/r3m_tiles.txt | cut -c1-230
+timeout 600 python3 $R/tools/hiera_attn_probe.py > $O/r3p_a.txt 2>&1; grep "global" $O/r3p_a.txt | head -2
+RGA3_ATTN_96=1 timeout 600 python3 $R/tools/hiera_attn_probe.py > $O/r3p_b.txt 2>&1; grep "global" $O/r3p_b.txt | head -2
