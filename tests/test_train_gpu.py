@@ -139,6 +139,38 @@ def test_llm_training_step_gradients(dev):
     assert rel_l2(out.hidden_states[-1][m], ref["hidden"][m].detach()) < 3e-2  # LoRA updates (scale 2, B ~ 0.2) add bf16 rounding on q and v
 
 
+def test_lora_step_cache_follows_parameter_updates(dev):
+    """The derived LoRA operands (sA, A^T, (sB)^T, built once per step for all layers: rga3.model.qwen_train.lora_refresh) must follow in-place parameter updates:
+    a model that has already run a step and then receives new LoRA weights (in place, version bump -- what the optimizer does) must give, bit for bit, the loss and
+    the gradients of a fresh model built with those weights."""
+    G = gold()
+    px = torch.cat([det_tensor("pixel_values_full0", (192, 1176), 1.0, seed=5), det_tensor("pixel_values_full1", (192, 1176), 1.0, seed=6)], 0).to(torch.bfloat16)
+    ids, am, labels = (torch.from_numpy(G[k]) for k in ("full_input_ids", "full_attention_mask", "full_labels"))
+
+    def run(model):
+        for p in model.parameters():
+            p.grad = None
+        out = model(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev), pixel_values_videos=px.to(dev),
+                    video_grid_thw=torch.from_numpy(G["full_grid"]), second_per_grid_ts=torch.tensor([1.0, 1.0]))
+        out.loss.backward()
+        return out.loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+
+    used, _ = _build_lora_model(dev, G)
+    run(used)                                    # builds the cache for the first set of LoRA weights
+    fresh, _ = _build_lora_model(dev, G)
+    new = {n: det_tensor(n + "#2", tuple(p.shape), 0.15, seed=23).to(torch.bfloat16) for n, p in fresh.named_parameters() if "lora_" in n}
+    with torch.no_grad():
+        for model in (used, fresh):
+            for n, p in model.named_parameters():
+                if n in new:
+                    p.copy_(new[n].to(dev))      # in place: same storage, version + 1
+    l1, g1 = run(used)
+    l2, g2 = run(fresh)
+    assert torch.equal(l1, l2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+
+
 def test_dropout_kernel_matches_oracle_mask(dev):
     from rga3.hip import ops
 

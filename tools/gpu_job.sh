@@ -1,5 +1,5 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-timeout 600 python3 $R/tools/hiera_attn_probe.py > $O/r3p_a.txt 2>&1; grep "global" $O/r3p_a.txt | head -2
-RGA3_ATTN_96=1 timeout 600 python3 $R/tools/hiera_attn_probe.py > $O/r3p_b.txt 2>&1; grep "global" $O/r3p_b.txt | head -2
+cd $R
+timeout 1500 python -m pytest tests/test_train_gpu.py -x -q -m gpu -k "lora" > $O/r3q_tests.log 2>&1; tail -5 $O/r3q_tests.log | cut -c1-250
+python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -2
