@@ -129,7 +129,8 @@ def fold_layernorm(weight, bias, gamma, beta):
     w = weight.detach().float()
     wf = (w * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
     colc = wf.float().sum(1).contiguous()
-    bf = w @ beta.detach().float() if beta is not None else torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+    # (elementwise product + row sum rather than `w @ beta`: no vendor-BLAS launch on the product path, even at pack time)
+    bf = (w * beta.detach().float()[None, :]).sum(1) if beta is not None else torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
     if bias is not None:
         bf = bf + bias.detach().float()
     return wf, colc, bf.to(torch.bfloat16).contiguous()
