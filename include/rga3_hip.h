@@ -183,6 +183,9 @@ int rga3_rope_axial_inplace(void* x, const float* cos, const float* sin, int64_t
 int rga3_pixel_shuffle2x(const void* g, const void* bias, const void* add, void* out, int64_t F, int H, int W, int Co, int act, void* stream);
 /* per-mask {sum BCE-with-logits, sum sigmoid*t, sum sigmoid, sum t} (model/qwen_2_5_vl_sam2.py:17-60); out4 f32 [n_masks,4] */
 int rga3_bce_dice_sums(const float* logits, const float* targets, float* out4, int64_t n_masks, int64_t hw, void* stream);
+/* the same sums, reproducible run to run (per-block partial sums in `ws`, rga3_bce_dice_sums_ws_floats() f32 elements, added in block order; no atomics) */
+int64_t rga3_bce_dice_sums_ws_floats(int64_t n_masks, int64_t hw);
+int rga3_bce_dice_sums_det(const float* logits, const float* targets, float* out4, float* ws, int64_t ws_floats, int64_t n_masks, int64_t hw, void* stream);
 
 /* ---- training step (backward + optimiser) ---------------------------------------------------------------- */
 

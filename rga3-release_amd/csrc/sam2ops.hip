@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const unsigned short
 
 // ---- per-mask partial sums for BCE-with-logits and dice (reference qwen_2_5_vl_sam2.py:17-60):
 //      out[n] = { sum bce(x,t), sum sigmoid(x)*t, sum sigmoid(x), sum t }; one block per (mask, slice), atomics into out.
-__global__ __launch_bounds__(256) void bce_dice_kernel(const float* __restrict__ x, const float* __restrict__ tg, float* __restrict__ out, long hw) {
+__global__ __launch_bounds__(256) void bce_dice_kernel(const float* __restrict__ x, const float* __restrict__ tg, float* __restrict__ out, long hw,
+                                                       float* __restrict__ part = nullptr) {
     __shared__ float red[4][4];
     const long n = blockIdx.y;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -306,7 +307,17 @@ __global__ __launch_bounds__(256) void bce_dice_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x < 4) {
         const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(out + n * 4 + threadIdx.x, v);
+        if (part) part[((long)n * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = v;   // summed in block order by bce_dice_finish_kernel: reproducible
+        else atomicAdd(out + n * 4 + threadIdx.x, v);
+    }
+}
+
+__global__ __launch_bounds__(64) void bce_dice_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nb) {
+    const long n = blockIdx.x;
+    if (threadIdx.x < 4) {
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += part[(n * nb + b) * 4 + threadIdx.x];
+        out[n * 4 + threadIdx.x] = s;
     }
 }
 
@@ -419,7 +430,30 @@ extern "C" int rga3_bce_dice_sums(const float* logits, const float* targets, flo
     unsigned gx = (unsigned)cdiv(hw, 256 * 8);
     if (gx < 1) gx = 1;
     if (gx > 512) gx = 512;
-    hipLaunchKernelGGL(bce_dice_kernel, dim3(gx, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, logits, targets, out4, (long)hw);
+    hipLaunchKernelGGL(bce_dice_kernel, dim3(gx, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, logits, targets, out4, (long)hw, (float*)nullptr);
     RGA3_CHECK_LAUNCH("bce_dice_sums");
+    return 0;
+}
+
+static unsigned bce_dice_blocks(int64_t hw) {
+    unsigned gx = (unsigned)cdiv(hw, 256 * 8);
+    if (gx < 1) gx = 1;
+    if (gx > 128) gx = 128;
+    return gx;
+}
+
+extern "C" int64_t rga3_bce_dice_sums_ws_floats(int64_t n_masks, int64_t hw) { return n_masks * (int64_t)bce_dice_blocks(hw) * 4; }
+
+// The same four sums per mask, reproducible run to run: per-block partial sums in the caller's workspace (rga3_bce_dice_sums_ws_floats() f32 elements), added in
+// block order; no memset, no atomics (the atomic form above adds its <= 512 block sums in arrival order: the mask losses and their gradients moved in the last bits
+// from run to run).
+extern "C" int rga3_bce_dice_sums_det(const float* logits, const float* targets, float* out4, float* ws, int64_t ws_floats, int64_t n_masks, int64_t hw, void* stream) {
+    RGA3_CHECK_ARG(logits && targets && out4 && ws && n_masks > 0 && hw > 0 && n_masks <= 65535, "bce_dice_sums_det: bad args");
+    const unsigned gx = bce_dice_blocks(hw);
+    RGA3_CHECK_ARG(ws_floats >= n_masks * (int64_t)gx * 4, "bce_dice_sums_det: workspace of rga3_bce_dice_sums_ws_floats() f32 elements needed");
+    hipLaunchKernelGGL(bce_dice_kernel, dim3(gx, (unsigned)n_masks), dim3(256), 0, (hipStream_t)stream, logits, targets, out4, (long)hw, ws);
+    RGA3_CHECK_LAUNCH("bce_dice_sums_det");
+    hipLaunchKernelGGL(bce_dice_finish_kernel, dim3((unsigned)n_masks), dim3(64), 0, (hipStream_t)stream, (const float*)ws, out4, (int)gx);
+    RGA3_CHECK_LAUNCH("bce_dice_finish");
     return 0;
 }

@@ -470,7 +470,11 @@ def bce_dice_sums(logits, targets):
     out = torch.empty((n, 4), dtype=torch.float32, device=logits.device)
     if n == 0:
         return out
-    _lib.check(_lib.load().rga3_bce_dice_sums(logits.data_ptr(), targets.data_ptr(), out.data_ptr(), n, logits[0].numel(), _stream()), "bce_dice_sums")
+    L = _lib.load()
+    hw = logits[0].numel()
+    nws = int(L.rga3_bce_dice_sums_ws_floats(n, hw))
+    ws = torch.empty(nws, dtype=torch.float32, device=logits.device)
+    _lib.check(L.rga3_bce_dice_sums_det(logits.data_ptr(), targets.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, n, hw, _stream()), "bce_dice_sums_det")   # reproducible sums
     return out
 
 

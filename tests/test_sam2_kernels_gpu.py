@@ -130,6 +130,12 @@ def test_bce_dice_sums(dev):
     p = torch.sigmoid(x)
     ref = torch.stack([bce, (p * t).flatten(1).sum(1), p.flatten(1).sum(1), t.flatten(1).sum(1)], 1)
     assert ((out - ref).abs() / ref.abs().clamp_min(1)).max().item() < 1e-4
+    # large planes (many blocks per mask): the block sums are added in block order, so two runs agree bit for bit
+    x, t = (torch.randn(5, 480, 854) * 3).to(dev), (torch.randn(5, 480, 854) > 0.2).float().to(dev)
+    a, b = ops.bce_dice_sums(x, t), ops.bce_dice_sums(x, t)
+    assert torch.equal(a, b)
+    refb = F.binary_cross_entropy_with_logits(x.cpu(), t.cpu(), reduction="none").flatten(1).sum(1)
+    assert ((a[:, 0].cpu() - refb).abs() / refb.abs()).max().item() < 1e-4
 
 
 def test_layernorm_narrow_rows(dev):

@@ -217,6 +217,38 @@ def test_training_gradients_through_mask_path(dev, G):
             assert rl(got[k], torch.from_numpy(G[gk])) < max(4e-2, 2.0 * yard.get(k, 0.0) + 1.5e-2), k
 
 
+def test_training_step_is_reproducible_bit_for_bit(dev, G):
+    """Two forward + backward passes of the joint model on the same batch from the same state: every loss and every gradient identical to the last bit (no kernel on the
+    training path adds floats in arrival order: stream-K sums, attention backward, LayerNorm / bias gradients, mask-loss sums, clipping norm are all fixed-order)."""
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
+
+    cfg = UniGRConfig(train_mask_decoder=True, out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=SEG,
+                      sam_pretrained=None, sam_config=SAM_TINY, **product_cfg_kwargs())
+    m = UniGRModel(cfg)
+    m.initialize_sam_modules(cfg)
+    P0, PS0 = params(G)
+    sd = dict(P0)
+    sd.update({"grounding_encoder.sam2_model." + k: v for k, v in PS0.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(torch.bfloat16).to(dev)
+    for n, p in m.named_parameters():
+        p.requires_grad_(("sam_mask_decoder" in n) or ("text_hidden_fcs" in n) or n in ("lm_head.weight", "model.embed_tokens.weight"))
+    b = to_dev(make_batch(CASES["11"], seed=4), dev)
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        out = m(**b, inference=False)
+        out["loss"].backward()
+        runs.append(({k: v.detach().clone() for k, v in out.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = runs
+    for k in l0:
+        assert torch.equal(l0[k], l1[k]), k
+    assert set(g0) == set(g1) and len(g0) > 10
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
 @pytest.mark.parametrize("tag,flags,seed", [("1", (True,), 11), ("0", (False,), 12)])
 def test_model_forward_inference_branch(model, dev, G, tag, flags, seed):
     """model_forward(inference=True): what validate() drives (reference qwen_2_5_vl_sam2.py:236-257, train_joint.py:586-648).  Bool masks against the
