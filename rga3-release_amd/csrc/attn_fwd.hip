@@ -70,7 +70,7 @@ __device__ __forceinline__ u32x4 rope_chunk(u32x4 z, const unsigned short* row_p
 
 constexpr int KV_TILE = 64;
 
-template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, bool SPLIT = false, bool ROPE = false>
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, bool SPLIT = false, bool ROPE = false, int KT = KV_TILE>
 __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     static_assert(!(PAIR && SPLIT), "pairing and KV splitting are alternatives");
     constexpr int NT = 64 * NWAVE;
@@ -79,13 +79,13 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     constexpr int STRIDE = DP * 2 + 32;   // LDS row stride in bytes (see header comment)
     constexpr int DS = DP / 32;           // 32-wide d steps of the QK^T contraction
     constexpr int DT = DP / 16;           // 16-wide d tiles of the output
-    constexpr int LOADS = (KV_TILE * CH + NT - 1) / NT;   // the last pass may cover only part of the threads (D = 96 with 8 waves: 768 chunks over 512 threads)
-    constexpr bool EVEN = (KV_TILE * CH) % NT == 0;
+    constexpr int LOADS = (KT * CH + NT - 1) / NT;   // the last pass may cover only part of the threads (D = 96 with 8 waves: 768 chunks over 512 threads)
+    constexpr bool EVEN = (KT * CH) % NT == 0;
     constexpr int RING = (LOADS <= 2) ? 3 : (LOADS <= 3) ? 2 : 1;  // K/V register slots in flight (8 * LOADS registers each)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
-    char* Vs = smem + KV_TILE * STRIDE;
+    char* Vs = smem + KT * STRIDE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     int kv_end = Lk;
     if (p.causal) kv_end = min(Lk, qb0 + BLOCK_M + shift);  // last visible key + 1 (for the block's last row)
     if (kv_end < 0) kv_end = 0;
-    int kt_begin = 0, ntiles = (kv_end + KV_TILE - 1) / KV_TILE;
+    int kt_begin = 0, ntiles = (kv_end + KT - 1) / KT;
     if constexpr (SPLIT) {
         const int per = (ntiles + p.nsplit - 1) / p.nsplit;
         kt_begin = min(sp * per, ntiles);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     // loop ran at one global-load latency per 64-key tile (~3 us for a 34-tile causal row at S = 2112, 7 % MFMA use).
     u32x4 kreg[RING][LOADS], vreg[RING][LOADS];
     // per-lane element offsets of this thread's chunks in tile 0 (32-bit: K/V of one call are < 2^31 elements from the
-    // segment/head base); the tile index only adds kt * KV_TILE * stride
+    // segment/head base); the tile index only adds kt * KT * stride
     const unsigned short* kbase = p.k + (long)ks * p.k_st + (long)hk * p.k_sh;
     const unsigned short* vbase = p.v + (long)ks * p.v_st + (long)hk * p.v_sh;
     int koff0[LOADS], voff0[LOADS];
@@ -178,15 +178,15 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     }
     auto load_tile = [&](auto SLOT, int kt) {
         constexpr int slot = decltype(SLOT)::value;
-        const unsigned short* kt_k = kbase + (long)kt * KV_TILE * p.k_st;
-        const unsigned short* kt_v = vbase + (long)kt * KV_TILE * p.v_st;
+        const unsigned short* kt_k = kbase + (long)kt * KT * p.k_st;
+        const unsigned short* kt_v = vbase + (long)kt * KT * p.v_st;
 #pragma unroll
         for (int i = 0; i < LOADS; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / CH, ch = idx % CH;
-            const int key = kt * KV_TILE + r;
+            const int key = kt * KT + r;
             u32x4 zk = {0u, 0u, 0u, 0u}, zv = {0u, 0u, 0u, 0u};
-            if ((EVEN || idx < KV_TILE * CH) && key < Lk && ch * 8 < p.D) {
+            if ((EVEN || idx < KT * CH) && key < Lk && ch * 8 < p.D) {
                 zk = *(const u32x4*)(kt_k + koff0[i]);
                 zv = *(const u32x4*)(kt_v + voff0[i]);
                 if constexpr (ROPE) if (p.rope_kcos) zk = rope_chunk(zk, kt_k + koff0[i] - ch * 8, ch * 8, p.D, p.rope_kcos + (long)(ks + key) * p.D, p.rope_ksin + (long)(ks + key) * p.D);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
         for (int i = 0; i < LOADS; ++i) {
             const int idx = tid + i * NT;
             const int r = idx / CH, ch = idx % CH;
-            if (EVEN || idx < KV_TILE * CH) {
+            if (EVEN || idx < KT * CH) {
                 *(u32x4*)(Ks + r * STRIDE + ch * 16) = kreg[slot][i];
                 *(u32x4*)(Vs + r * STRIDE + ch * 16) = vreg[slot][i];
             }
@@ -215,13 +215,13 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
         if (kt + RING < ntiles) load_tile(SLOT, kt + RING);  // refill the slot just emptied: RING tiles stay in flight
 
         // ---- S^T tiles: s[t][j] = keys 16j..16j+15 (lane holds keys 16j + 4g + r) x query c of q-tile t
-        f32x4 s[QT][4];
+        f32x4 s[QT][KT / 16];
 #pragma unroll
         for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < KT / 16; ++j) s[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < KT / 16; ++j) {
 #pragma unroll
             for (int ds = 0; ds < DS; ++ds) {
                 bf16x8 kf = *(const bf16x8*)(Ks + (j * 16 + c) * STRIDE + ds * 64 + g * 16);
@@ -231,9 +231,9 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
         }
 
         // ---- scale, mask, online softmax (per lane: one query per q-tile).  Interior tiles take the mask-free body.
-        const int k0 = kt * KV_TILE;
-        const bool need_mask = (k0 + KV_TILE > Lk) || (p.causal && (k0 + KV_TILE - 1 > qb0 + shift)) || (p.bq_shift >= 0);
-        bf16x8 pf[QT][2];
+        const int k0 = kt * KT;
+        const bool need_mask = (k0 + KT > Lk) || (p.causal && (k0 + KT - 1 > qb0 + shift)) || (p.bq_shift >= 0);
+        bf16x8 pf[QT][KT / 32];
         auto softmax_tile = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
                 const int qi = qw0 + t * 16 + c;
                 float mx = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < KT / 16; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float x = s[t][j][r] * p.scale_log2;  // scores are scaled first, as the reference does (folding the scale into the exp FMA saves
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
                 m_run[t] = m_new;
                 float ps = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < KT / 16; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float e = __builtin_amdgcn_exp2f(s[t][j][r] - m_use);   // raw v_exp_f32: arguments <= 0, flush of tiny values is harmless
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
                 }
                 // P^T B-operand fragments: 32-key step ss uses s[t][2ss] (elements 0..3) and s[t][2ss+1] (4..7)
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
+                for (int ss = 0; ss < KT / 32; ++ss) {
                     u32x4 pk;
                     pk[0] = pack_bf2(s[t][2 * ss][0], s[t][2 * ss][1]);
                     pk[1] = pack_bf2(s[t][2 * ss][2], s[t][2 * ss][3]);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
+            for (int ss = 0; ss < KT / 32; ++ss) {
                 bf16x8 vf;
                 if constexpr (USE_TR) {
                     // lane i of group g supplies row (key) i>>2, columns 4*(i&3)..+3 of the 4x16 block
@@ -603,10 +603,10 @@ __global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnArgs p) {
     if (p.lse && lane == 0) p.lse[(long)hq * p.total_q + tq] = wsum > 0.f ? (m + log2f(wsum)) * 0.6931471805599453f : -INFINITY;
 }
 
-template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR>
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, int KT = KV_TILE>
 static int launch_attn_p(const AttnArgs& a, int nseg, unsigned gx, hipStream_t st) {
-    constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
-    auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, PAIR>;
+    constexpr int LDS = 2 * KT * (DP * 2 + 32);
+    auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, PAIR, false, false, KT>;
     static bool attr_done = false;
     if (!attr_done && LDS > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -627,7 +627,12 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     // the paired-q-block form only for the long causal rows of the decoder (D = 64 / 128, 8 waves): elsewhere it would only
     // cost registers
     if constexpr (NWAVE == 8) {
-        if (a.causal && nqb >= 4) return launch_attn_p<DP, QT, NWAVE, USE_TR, true>(a, nseg, (nqb + 1) / 2, st);
+        if (a.causal && nqb >= 4) {
+            // the decoder's causal rows walk 128-key tiles: half the barriers, softmax rescales and tile bookkeeping per key (same 205 VGPRs: one register slot
+            // of four loads instead of three of two) -- 66.3 -> 61.5 us at S = 2112, 219.5 -> 203.6 us at S = 4160 on one box
+            if constexpr (DP == 128 && QT == 1) return launch_attn_p<DP, QT, NWAVE, USE_TR, true, 128>(a, nseg, (nqb + 1) / 2, st);
+            else return launch_attn_p<DP, QT, NWAVE, USE_TR, true>(a, nseg, (nqb + 1) / 2, st);
+        }
     }
     if (a.nsplit > 1) {
         constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
@@ -646,7 +651,10 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
         RGA3_CHECK_LAUNCH("attn_split_combine_kernel");
         return 0;
     }
-    return launch_attn_p<DP, QT, NWAVE, USE_TR, false>(a, nseg, nqb, st);
+    // 128-key tiles also for the non-paired long rows at D = 128 (3 280 -> 3 159 us at B16 H64 L2048); at D = 64 they lose (1 633 -> 2 000 us: the 8 loads of a
+    // tile leave one register slot instead of three)
+    if constexpr (DP == 128 && QT == 1 && NWAVE == 8) return launch_attn_p<DP, QT, NWAVE, USE_TR, false, 128>(a, nseg, nqb, st);
+    else return launch_attn_p<DP, QT, NWAVE, USE_TR, false>(a, nseg, nqb, st);
 }
 
 // RoPE-while-loading variant: windows of <= 64 queries (one query block of 4 waves x 16 rows per segment and head)
