@@ -1,4 +1,6 @@
 #!/bin/bash
+# scratch job for /usr/local/graft/bin/gpurun -- 'bash tools/gpu_job.sh' (edited per experiment; the last useful content: the round's GPU suite + default bench)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-for gm in 0 2 8 16; do echo "== GROUPM=$gm"; RGA3_GEMM_GROUPM=$gm timeout 600 python3 $R/tools/gemm_tile_probe.py 2>&1 | grep "M=65536\|M=262144\|M=8192" | cut -c1-200; done
+cd $R
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/job_tests.log 2>&1; tail -3 $O/job_tests.log | cut -c1-200
+python3 bench.py > $O/job_bench.json 2> $O/job_bench.err; tail -c 400 $O/job_bench.json
