@@ -1,6 +1,5 @@
 #!/bin/bash
-# scratch job for /usr/local/graft/bin/gpurun -- 'bash tools/gpu_job.sh' (edited per experiment; the last useful content: the round's GPU suite + default bench)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-cd $R
-timeout 2400 python -m pytest tests -x -q -m gpu > $O/job_tests.log 2>&1; tail -3 $O/job_tests.log | cut -c1-200
-python3 bench.py > $O/job_bench.json 2> $O/job_bench.err; tail -c 400 $O/job_bench.json
+cd /tmp && export TMPDIR=/tmp
+for v in "" "--refine" "" "--refine"; do T0=$(date +%s); python3 $R/bench.py --mode train_full --steps 10 --warmup 3 --no-cpu-baseline $v > $O/r4l.json 2> $O/r4l.err; python3 -c "
+import json;d=json.loads(open('$O/r4l.json').read().strip().splitlines()[-1]);print('TRAIN [$v]',d['value'],d['ms_per_step'])"; echo "  wall $(( $(date +%s) - T0 )) s"; grep -c "tuner.refine" $O/r4l.err; done
