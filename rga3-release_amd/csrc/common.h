@@ -1,21 +1,10 @@
 // Shared device/host helpers for the rga3 HIP library (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stddef.h>
 
-#include "../../include/rga3_hip.h"
+#include "errors.h"
 
 namespace rga3 {
-
-// ---- error convention: 0 = ok, negative code otherwise; message is thread-local.
-void set_error(const char* fmt, ...);
-int fail(int code, const char* fmt, ...);
-
-#define RGA3_CHECK_ARG(cond, ...)                                   \
-    do {                                                            \
-        if (!(cond)) return ::rga3::fail(RGA3_EINVAL, __VA_ARGS__); \
-    } while (0)
 
 #define RGA3_CHECK_LAUNCH(name)                                                                  \
     do {                                                                                         \

@@ -1,5 +1,5 @@
-// Error plumbing and version for librga3_hip.so (C ABI: include/rga3_hip.h).
-#include "common.h"
+// Error plumbing and version for librga3_hip.so (C ABI: include/rga3_hip.h).  Host-only, no HIP headers (also built under the CPU sanitizers).
+#include "errors.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>

@@ -1,5 +1,6 @@
-/* AddressSanitizer / UBSan harness for the HOST-ONLY C entry points of librga3_hip: built and run on the CPU by
-   tests/test_host_sanitizer.py with hipcc -fsanitize=address,undefined -fno-gpu-sanitize (GPU sanitizers are not available on this pool). */
+/* AddressSanitizer / UBSan harness for the HOST-ONLY C entry points of librga3_hip: built and run on the CPU
+   only, by sanitize/Makefile, with gcc and csrc/host_*.cpp (plain C++, no device code).  This directory is listed in .gpurunignore: it never travels to
+   the GPU box. */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
