@@ -202,6 +202,9 @@ int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
 /* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up in launches that used this workspace (expected 0;
  * < 0 = error); synchronises the device */
 int rga3_gemm_stream_k_timeouts(const void* workspace);
+/* byte offset of that 32-bit counter inside a workspace of the current device (< 0 = error): lets the caller fetch it with its own asynchronous copy, so a
+ * training loop can watch it every few steps without a device synchronisation (no reference counterpart: the reference's GEMMs are vendor BLAS calls) */
+int64_t rga3_gemm_timeout_counter_offset(void);
 /* dx = d rmsnorm(x; weight)/dx . dy (+ add): backward of HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:74-79) w.r.t. x */
 int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim, float eps,
                      void* stream);

@@ -323,12 +323,12 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     if (kt_begin < ntiles) load_tile(S0{}, kt_begin);
-    if (RING > 1 && kt_begin + 1 < ntiles) load_tile(S1{}, kt_begin + 1);
-    if (RING > 2 && kt_begin + 2 < ntiles) load_tile(std::integral_constant<int, (RING > 2 ? 2 : 0)>{}, kt_begin + 2);
+    if constexpr (RING > 1) { if (kt_begin + 1 < ntiles) load_tile(S1{}, kt_begin + 1); }
+    if constexpr (RING > 2) { if (kt_begin + 2 < ntiles) load_tile(std::integral_constant<int, 2>{}, kt_begin + 2); }
     for (int kt = kt_begin; kt < ntiles; kt += RING) {
         tile_body(S0{}, kt);
-        if (RING > 1 && kt + 1 < ntiles) tile_body(S1{}, kt + 1);
-        if (RING > 2 && kt + 2 < ntiles) tile_body(std::integral_constant<int, (RING > 2 ? 2 : 0)>{}, kt + 2);
+        if constexpr (RING > 1) { if (kt + 1 < ntiles) tile_body(S1{}, kt + 1); }
+        if constexpr (RING > 2) { if (kt + 2 < ntiles) tile_body(std::integral_constant<int, 2>{}, kt + 2); }
     }
 
     // ---- finalize: lane holds query c, output dims 16d + 4g + r
@@ -813,7 +813,11 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
     a.bq_shift = a.bk_shift = -1;
     a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1; a.gx = 1;
     hipStream_t st = (hipStream_t)stream;
+#ifdef RGA3_AB   // measurement builds only (tools/): the product library has one behaviour
     static const bool old_rope = [] { const char* e = getenv("RGA3_ATTN_ROPE_OLD"); return e && atoi(e) != 0; }();   // A/B switch: the pipelined rope kernel
+#else
+    constexpr bool old_rope = false;
+#endif
     if (!old_rope && !causal && cu_q == cu_k && D <= 96 && D % 8 == 0)   // self-attention windows: key range = query range <= 64
         return (D <= 64) ? launch_win<64, 4, 1, true>(a, nseg, max_q, max_q, st) : launch_win<96, 4, 1, true>(a, nseg, max_q, max_q, st);
     if (D <= 32) return launch_rope_win<32>(a, nseg, st);

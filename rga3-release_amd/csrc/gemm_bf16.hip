@@ -937,8 +937,10 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(SlabReduceArgs p)
 // a weight matrix larger than the 256 MiB Infinity Cache that is 3 passes over HBM; one group spanning all rows streams the
 // weights once and re-reads the small activation block from the Infinity Cache instead.
 static int pick_group_m(int ntm, int tile_m) {
+#ifdef RGA3_AB   // measurement builds only (tools/): the product library has one behaviour
     static const int forced = [] { const char* e = getenv("RGA3_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced;
+#endif
     (void)tile_m;
     return (ntm <= 16) ? ntm : 4;
 }
@@ -1382,7 +1384,11 @@ static int launch_gemv(const GemmArgs& a, hipStream_t st) {
     g.M = a.M; g.N = a.N; g.K = a.K; g.lda = a.lda; g.ldw = a.ldw; g.ldc = a.ldc; g.ldr = a.ldr;
     const int nout = (ACT == ACT_SWIGLU) ? a.N / 2 : a.N;
     const unsigned grid = (unsigned)cdiv(nout, 16);
+#ifdef RGA3_AB   // measurement builds only (tools/): the product library has one behaviour
     static const bool nt = [] { const char* e = getenv("RGA3_GEMV_NT"); return e ? atoi(e) != 0 : true; }();   // A/B switch (default: nontemporal weight loads)
+#else
+    constexpr bool nt = true;
+#endif
     if (nt) {
         if (a.M == 1) hipLaunchKernelGGL((gemv_kernel<1, ACT, OUT_F32, true>), dim3(grid), dim3(256), 0, st, g);
         else if (a.M == 2) hipLaunchKernelGGL((gemv_kernel<2, ACT, OUT_F32, true>), dim3(grid), dim3(256), 0, st, g);
@@ -1462,6 +1468,14 @@ extern "C" int rga3_gemm_stream_k_timeouts(const void* workspace) {
     unsigned v = 0;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, ws.flags + ws.P, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}
+
+// Byte offset, inside a workspace of this device, of the 32-bit give-up counter rga3_gemm_stream_k_timeouts reads -- so a training loop can fetch it with its
+// own asynchronous copy instead of a device synchronisation (rga3.hip.ops.GemmHealthWatch).  < 0 on error.
+extern "C" int64_t rga3_gemm_timeout_counter_offset(void) {
+    const int cus = cu_count();
+    if (cus <= 0 || cus * 4 + 16 > (int)kSkFlagBytes) return -1;
+    return (int64_t)cus * 4;
 }
 
 extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,

@@ -671,6 +671,41 @@ def check_gemm_health(device=None):
         raise _lib.Rga3Error(f"stream-K GEMM hand-off timed out {n} time(s): results since the last check are not trustworthy (workspace flags re-zeroed)")
 
 
+class GemmHealthWatch:
+    """check_gemm_health without the device synchronisation, for the product path (FusedAdamW.step polls it): every `every` polls the give-up counter of each
+    GEMM workspace is fetched by a non-blocking copy into pinned memory, and the fetch of the PREVIOUS round -- long finished by then -- is examined.  A
+    stream-K hand-off that timed out is therefore reported within 2 * every optimizer steps instead of writing a wrong C silently for the rest of the run."""
+
+    def __init__(self, every: int = 16):
+        self.every, self.n, self.pending = max(1, int(every)), 0, []
+
+    def poll(self):
+        self.n += 1
+        if self.n % self.every:
+            return
+        self.examine()
+        for (dev, _), t in _gemm_ws.items():
+            with torch.cuda.device(dev):
+                off = int(_lib.load().rga3_gemm_timeout_counter_offset())
+                if off < 0:
+                    continue
+                host = torch.empty(1, dtype=torch.int32).pin_memory()
+                host.copy_(t[off:off + 4].view(torch.int32), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self.pending.append((host, ev))
+
+    def examine(self):
+        pend, self.pending = self.pending, []
+        for host, ev in pend:
+            ev.synchronize()      # recorded `every` steps ago: already complete
+            if int(host[0]) != 0:
+                for t in _gemm_ws.values():
+                    t[:4096].zero_()
+                raise _lib.Rga3Error(f"stream-K GEMM hand-off timed out {int(host[0])} time(s) in the last {2 * self.every} optimizer steps: their results are not "
+                                     "trustworthy (workspace flags re-zeroed)")
+
+
 # ------------------------------------------------------------------------------------------------ mask-path backward kernels
 def layernorm_bwd(x, weight, dy, eps: float, want_param_grads=True):
     _need_cuda(x, weight, dy)

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from ..hip import autograd as AG
 from ..hip import ops
+from ..utils.staging import host_of, upload
 from .qwen2_5_vl import CausalLMOutput, Linear, Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
 from .sam2 import SAM2
 
@@ -140,7 +141,7 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
             return torch.zeros((0, self.config.out_dim), dtype=hidden_last.dtype, device=hidden_last.device), counts
         pl = pl if pl is not None else {}
         if "seg_rows" not in pl:
-            pl["seg_rows"] = torch.from_numpy(where).to(hidden_last.device)
+            pl["seg_rows"] = upload(where, hidden_last.device)
         idx = pl["seg_rows"]
         fc = self.text_hidden_fcs[0]
         if torch.is_grad_enabled():
@@ -170,10 +171,10 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
                                  image_grid_thw=image_grid_thw, video_grid_thw=video_grid_thw, second_per_grid_ts=second_per_grid_ts)
         ce_loss = output.loss * self.config.ce_loss_weight
         pl = self.__dict__.get("_last_plan") or {}   # host plan of the forward just run: holds the labels' host copy (no second device -> host read)
-        labels_np = pl["labels_np"] if pl.get("labels_np") is not None else labels.detach().cpu().numpy()
+        labels_np = pl["labels_np"] if pl.get("labels_np") is not None else host_of(labels)
         seg_mask = self._shifted_seg_mask(labels_np, self.config.seg_token_idx)
         pred_embeddings, counts = self._seg_embeddings(output.hidden_states[-1], seg_mask, pl)
-        seg_token_offset = np.concatenate([[0], np.cumsum(counts)])[np.asarray(offset.detach().cpu() if isinstance(offset, torch.Tensor) else offset)]
+        seg_token_offset = np.concatenate([[0], np.cumsum(counts)])[np.asarray(host_of(offset))]
         gm = self.grounding_encoder
         out_dim = self.config.out_dim
 
@@ -230,7 +231,7 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
         """reference :325-393 -> (hf_output, [bool masks [T, h, w] per [SEG]])"""
         with torch.no_grad():
             assert images_sam.shape[0] == 1
-            seg_mask = self._shifted_seg_mask(input_ids.detach().cpu().numpy(), self.config.seg_token_idx)
+            seg_mask = self._shifted_seg_mask(host_of(input_ids), self.config.seg_token_idx)
             output = super().forward(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pixel_values,
                                      pixel_values_videos=pixel_values_videos, image_grid_thw=image_grid_thw, video_grid_thw=video_grid_thw,
                                      second_per_grid_ts=second_per_grid_ts, output_hidden_states=True)

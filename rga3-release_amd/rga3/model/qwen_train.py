@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from ..hip import ops
+from ..utils.staging import upload
 from .qwen2_5_vl import GatedMLP, Linear, _versions
 
 
@@ -426,7 +427,7 @@ class EmbedFn(torch.autograd.Function):
             uniq, counts = np.unique(ids[order], return_counts=True)
             off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
             dev = weight.device
-            plan["embed_bwd"] = (torch.from_numpy(rows[order].astype(np.int64)).to(dev), torch.from_numpy(off).to(dev), torch.from_numpy(uniq.astype(np.int64)).to(dev),
+            plan["embed_bwd"] = (upload(rows[order].astype(np.int64), dev), upload(off, dev), upload(uniq.astype(np.int64), dev),
                                  uniq.astype(np.int64))
         ctx.csr = plan["embed_bwd"]
         if ctx.sink is not None:
@@ -511,7 +512,7 @@ def lm_train_forward(model, x, pos3, cu, max_len, labels_np, am_cur, flat_keep, 
         tgt = nxt.reshape(-1)[flat_keep]
         valid = np.flatnonzero(tgt != -100)
         dev = x.device
-        plan["train_targets"] = (torch.from_numpy(valid.astype(np.int64)).to(dev), torch.from_numpy(tgt[valid]).to(dev), int(valid.size))
+        plan["train_targets"] = (upload(valid.astype(np.int64), dev), upload(tgt[valid], dev), int(valid.size))
     valid_dev, tgt_dev, n_valid = plan["train_targets"]
     loss, hn = NormHeadCEFn.apply(x, model.lm_head.weight, tm.norm.weight, tm.norm.variance_epsilon, valid_dev, tgt_dev, n_valid)
     return loss, hn

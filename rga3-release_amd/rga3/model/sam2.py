@@ -34,7 +34,7 @@ from .qwen2_5_vl import Linear
 _DEBUG = None   # set to a dict by tools/grad_locate.py (diagnostic)
 
 
-_LN_FOLD = os.environ.get("RGA3_LN_FOLD", "1") != "0"   # A/B switch: 0 keeps the stand-alone LayerNorm passes in the Hiera trunk
+_LN_FOLD = True   # LayerNorm of the frozen Hiera trunk folded into the consuming product (tools/ flip this module attribute for A/B runs; no environment switch)
 
 
 def _ag():

@@ -30,6 +30,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ..utils.staging import upload as _upload
+
 _ALIGN = 8   # bucket slices start at multiples of 8 elements (16 B for bf16): the optimizer kernels use 16-byte accesses
 
 # id(parameter) -> reducer that takes that parameter's gradient as (row ids, rows) instead of a dense tensor (see rga3.model.qwen_train.EmbedFn)
@@ -38,6 +40,16 @@ _sparse_sinks: "weakref.WeakValueDictionary[int, GradBucketReducer]" = weakref.W
 
 def sparse_sink_for(param):
     return _sparse_sinks.get(id(param))
+
+
+def sparse_candidates(model):
+    """Parameters whose gradient may be exchanged as rows: the input embedding table, unless it is tied to the LM head (Qwen2.5-VL-3B,
+    tie_word_embeddings): then the head's dense dW lands in the same tensor and the table goes through a dense bucket like everything else."""
+    emb = model.get_input_embeddings().weight
+    head = model.get_output_embeddings().weight
+    if not emb.requires_grad or emb is head:
+        return []
+    return [emb]
 
 
 class GradBucketReducer:
@@ -81,8 +93,18 @@ class GradBucketReducer:
             assert p.dim() == 2
             self._sp[id(p)] = {"p": p, "dense": torch.zeros_like(p.data), "union": np.zeros(0, dtype=np.int64), "last_ids": None, "counts": None}
             _sparse_sinks[id(p)] = self
+            # a sparse parameter must receive its gradient ONLY as rows: a dense gradient (tied word embeddings: lm_head.weight IS embed_tokens.weight, so the
+            # LM head's dW accumulates into the same .grad) would never be exchanged, never reach the optimizer and never be cleared.  Refuse it loudly; the
+            # caller registers such a parameter as dense (rga3.parallel.ddp.sparse_candidates does that).
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._dense_on_sparse))
         self.sparse_bytes_last = 0
         self.begin_step()
+
+    @staticmethod
+    def _dense_on_sparse(p):
+        if p.grad is not None:
+            raise RuntimeError("GradBucketReducer: a parameter registered as sparse (row-wise gradient) received a dense gradient -- with tied word embeddings "
+                               "(lm_head.weight is embed_tokens.weight) register it as a dense parameter (sparse_candidates(model))")
 
     # ---------------------------------------------------------------------------------------------- views for the optimizer
     def grad_view(self, p):
@@ -200,7 +222,7 @@ class GradBucketReducer:
         else:   # a local-only step (finish() under no_sync): nothing is exchanged; the rows touched are still remembered for the clean-up
             for st in self._sp.values():
                 mine = st.get("dev_ids") or []
-                st["last_ids"] = mine[0] if len(mine) == 1 and mine[0].numel() == st["union"].size else torch.from_numpy(st["union"]).to(st["dense"].device)
+                st["last_ids"] = mine[0] if len(mine) == 1 and mine[0].numel() == st["union"].size else _upload(st["union"], st["dense"].device)
         for bi, h in self.handles:
             h.wait()
             if not self._avg and self.world > 1:
@@ -260,7 +282,7 @@ class GradBucketReducer:
         mine = st.get("dev_ids") or []
         # the union of this step's row ids on the device: with one micro-step it is the tensor backward handed over (an upload of the host copy would be a
         # stream sync at the end of backward, with the optimizer's launches still to be issued)
-        ids = mine[0] if len(mine) == 1 and mine[0].numel() == ids_np.size else torch.from_numpy(ids_np).to(dev)
+        ids = mine[0] if len(mine) == 1 and mine[0].numel() == ids_np.size else _upload(ids_np, dev)
         if self.world == 1:
             st["last_ids"] = ids
             self.sparse_bytes_last = 0
@@ -373,6 +395,7 @@ class FusedAdamW:
         self.schedule = schedule
         self._flat = None
         self._sparse_src, self._row_mask = {}, {}
+        self.health_every, self._health = 16, None     # poll the GEMM give-up counters every N steps (0 = off)
         if layout is not None:
             self._init_flat(layout)
         else:
@@ -462,6 +485,10 @@ class FusedAdamW:
         lr = self.current_lr()
         self.t += 1
         clip = self.max_norm is not None
+        if self.params[0].is_cuda and self.health_every:     # a stream-K hand-off that gave up must not go unnoticed in a real run (no sync: GemmHealthWatch)
+            if self._health is None:
+                self._health = ops.GemmHealthWatch(self.health_every)
+            self._health.poll()
         if self._flat is not None:   # one launch per bucket (gradients are the reducer's flat buckets themselves)
             if clip:
                 for i, (_, _, g, _, _) in enumerate(self._flat):

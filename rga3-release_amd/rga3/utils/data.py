@@ -8,6 +8,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .staging import dict_to_cuda
+
 IGNORE_INDEX = -100
 
 
@@ -32,10 +34,12 @@ def mask_labels(input_ids: np.ndarray, im_start_id: int, im_end_id: int, user_id
 
 
 def make_batch(cfg, device, batch=1, frames_mllm=16, frames_sam=16, side=448, sam_side=1024, n_text=64, seed=0, seg=True, label_hw=(480, 640),
-               dtype=torch.bfloat16):
+               dtype=torch.bfloat16, seg_pos=-3, ints_only=False):
     """Synthetic UniGRModel kwargs of the shape the reference's collate_fn produces:
     frames_mllm frames side x side -> video_grid_thw [[frames/2, side/14, side/14]], n_text non-video tokens incl. the
-    answer "Sure, [SEG]." (6 supervised tokens), random rectangle GT masks."""
+    answer "Sure, [SEG]." (6 supervised tokens, [SEG] at `seg_pos` in [-5, -2]), random rectangle GT masks.  The batch is built on the CPU, as the
+    reference's collate_fn builds it, and moved by dict_to_cuda (device=None: the CPU dict is returned; ints_only: only the integer tensors -- what
+    changes from step to step when a benchmark keeps a pool of pixel tensors resident in HBM)."""
     g = torch.Generator().manual_seed(seed)
     gt, gh = frames_mllm // 2, side // 14
     n_vid = gt * (gh // 2) * (gh // 2)
@@ -46,11 +50,14 @@ def make_batch(cfg, device, batch=1, frames_mllm=16, frames_sam=16, side=448, sa
                          torch.tensor([cfg.vision_end_token_id]), text[12:]])
         lab = torch.full_like(seq, IGNORE_INDEX)
         if seg:
-            seq[-3] = cfg.seg_token_idx
+            seq[seg_pos] = cfg.seg_token_idx
         lab[-6:] = seq[-6:]
         ids.append(seq)
         labels.append(lab)
     input_ids, labels = torch.stack(ids), torch.stack(labels)
+    ints = dict(input_ids=input_ids, attention_mask=torch.ones_like(input_ids), labels=labels)
+    if ints_only:
+        return ints if device is None else dict_to_cuda(ints, device)
     px = torch.randn(batch * gt * gh * gh, 1176, generator=g).clamp_(-1.8, 2.2).to(dtype)
     images_sam = torch.randn(batch, frames_sam, 3, sam_side, sam_side, generator=g).to(dtype)
     masks = []
@@ -60,11 +67,12 @@ def make_batch(cfg, device, batch=1, frames_mllm=16, frames_sam=16, side=448, sa
             y0, x0 = int(torch.randint(0, label_hw[0] // 2, (1,), generator=g)), int(torch.randint(0, label_hw[1] // 2, (1,), generator=g))
             m[t, y0:y0 + label_hw[0] // 3, x0:x0 + label_hw[1] // 3] = 1
         masks.append(m)
-    to = lambda t: t.to(device)
-    return dict(input_ids=to(input_ids), attention_mask=to(torch.ones_like(input_ids)), labels=to(labels), pixel_values_videos=to(px),
-                video_grid_thw=torch.tensor([[gt, gh, gh]] * batch), second_per_grid_ts=torch.ones(batch), images_sam=to(images_sam),
-                offset=torch.arange(batch + 1), masks_list=[to(m) for m in masks], label_list=[torch.zeros(label_hw) for _ in range(batch)],
-                resize_list=[(sam_side, sam_side)] * batch, inference=False)
+    label_list = [torch.zeros(label_hw) for _ in range(batch)]     # only its shape is read (reference qwen_2_5_vl_sam2.py:268): stays on the host
+    d = dict(ints, pixel_values_videos=px, video_grid_thw=torch.tensor([[gt, gh, gh]] * batch), second_per_grid_ts=torch.ones(batch), images_sam=images_sam,
+             offset=torch.arange(batch + 1), masks_list=masks)
+    if device is not None:
+        d = dict_to_cuda(d, device)
+    return dict(d, label_list=label_list, resize_list=[(sam_side, sam_side)] * batch, inference=False)
 
 
 # ------------------------------------------------------------------------------------------------ frame selection (host side)

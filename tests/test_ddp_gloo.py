@@ -179,3 +179,36 @@ def test_sparse_row_exchange_two_ranks():
     res = _run(_worker_sparse)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]   # bitwise-identical sums on both ranks
+
+
+def test_sparse_parameter_refuses_dense_gradient():
+    """with tied word embeddings the LM head's dense dW lands in the table's .grad; a table registered as sparse would silently drop it.  The reducer
+    refuses it loudly, and sparse_candidates() does not offer a tied table in the first place."""
+    import pytest
+    from rga3.parallel.ddp import GradBucketReducer, sparse_candidates
+
+    table = torch.nn.Parameter(torch.zeros(10, 8))
+    w = torch.nn.Parameter(torch.ones(4))
+    red = GradBucketReducer([table, w], bucket_mb=1.0, sparse_params=[table])
+    red.begin_step()
+    with pytest.raises(RuntimeError, match="dense gradient"):
+        (table.sum() + w.sum()).backward()
+    red.remove()
+
+    class M(torch.nn.Module):
+        def __init__(self, tied):
+            super().__init__()
+            self.emb = torch.nn.Embedding(10, 8)
+            self.head = torch.nn.Linear(8, 10, bias=False)
+            if tied:
+                self.head.weight = self.emb.weight
+
+        def get_input_embeddings(self):
+            return self.emb
+
+        def get_output_embeddings(self):
+            return self.head
+
+    assert sparse_candidates(M(True)) == []
+    m = M(False)
+    assert sparse_candidates(m) == [m.emb.weight] or sparse_candidates(m)[0] is m.emb.weight

@@ -249,6 +249,60 @@ def test_training_step_is_reproducible_bit_for_bit(dev, G):
         assert torch.equal(g0[n], g1[n]), n
 
 
+def test_fresh_batch_step_reads_nothing_back_from_the_device(dev, G):
+    """A training loop feeds a NEW batch every step (reference train_joint.py:500-519: next(train_iter) -> dict_to_cuda -> model(**input_dict)).  With the batch moved by
+    rga3.utils.staging.dict_to_cuda the forward + backward of the joint model must (a) give the same losses and gradients, to the last bit, as with plain device tensors
+    (whose integer inputs are read back), and (b) issue NO synchronising call: the host plan comes from the collate function's CPU copies, index tables go up through
+    pinned staging.  (b) is asserted with torch's sync debug mode on a second, different batch, after a warm-up step built every cached table."""
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
+    from rga3.utils.staging import dict_to_cuda, has_host
+
+    cfg = UniGRConfig(train_mask_decoder=True, out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=SEG,
+                      sam_pretrained=None, sam_config=SAM_TINY, **product_cfg_kwargs())
+    m = UniGRModel(cfg)
+    m.initialize_sam_modules(cfg)
+    P0, PS0 = params(G)
+    sd = dict(P0)
+    sd.update({"grounding_encoder.sam2_model." + k: v for k, v in PS0.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(torch.bfloat16).to(dev)
+    for n, p in m.named_parameters():
+        p.requires_grad_(("sam_mask_decoder" in n) or ("text_hidden_fcs" in n) or n in ("lm_head.weight", "model.embed_tokens.weight"))
+
+    def cpu_batch(seed):
+        b = make_batch(CASES["11"], seed=seed)
+        return {k: (v.to(torch.bfloat16) if isinstance(v, torch.Tensor) and v.is_floating_point() and k in ("pixel_values_videos", "images_sam") else v) for k, v in b.items()}
+
+    def run(b):
+        for p in m.parameters():
+            p.grad = None
+        out = m(**b, inference=False)
+        out["loss"].backward()
+        return {k: v.detach().clone() for k, v in out.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l_plain, g_plain = run(to_dev(make_batch(CASES["11"], seed=4), dev))
+    moved = dict_to_cuda(cpu_batch(4), dev)
+    assert has_host(moved["input_ids"]) and has_host(moved["labels"]) and has_host(moved["video_grid_thw"])
+    l_fresh, g_fresh = run(moved)
+    for k in l_plain:
+        assert torch.equal(l_plain[k], l_fresh[k]), k
+    assert set(g_plain) == set(g_fresh)
+    for n in g_plain:
+        assert torch.equal(g_plain[n], g_fresh[n]), n
+    nxt = cpu_batch(5)                       # a different sample: nothing of the previous plan applies
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        moved = dict_to_cuda(nxt, dev)
+        for p in m.parameters():
+            p.grad = None
+        out = m(**moved, inference=False)
+        out["loss"].backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(out["loss"]).item()
+
+
 @pytest.mark.parametrize("tag,flags,seed", [("1", (True,), 11), ("0", (False,), 12)])
 def test_model_forward_inference_branch(model, dev, G, tag, flags, seed):
     """model_forward(inference=True): what validate() drives (reference qwen_2_5_vl_sam2.py:236-257, train_joint.py:586-648).  Bool masks against the
