@@ -199,6 +199,14 @@ int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
                          void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
                          int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale, int causal,
                          float* dkv_ws, int64_t total_k, void* stream);
+/* SAM2 memory cross-attention with the values kept in memory space (csrc/memattn.hip): out [Nq, 64] bf16 = softmax(scale * q k^T) m for ONE 256-wide head,
+ * q [Nq, 256], k [Nk, 256] (projected + rotated), m [Nk, 64] the un-projected memory rows; the caller applies the value projection to the 64-wide result
+ * (softmax rows sum to one: softmax(S) (m Wv^T + bv) = (softmax(S) m) Wv^T + bv).  Replaces, for reference model/sam2.py:1519-1548 (RoPEAttention.forward of
+ * cross_attn_image, kv_in_dim 64), v_proj over the whole bank + F.scaled_dot_product_attention.  Strides in elements; nsplit key slices (1..32);
+ * ws = rga3_memattn_cross_ws_floats(Nq, nsplit) floats of caller workspace (< 0 = bad arguments).  Deterministic (no atomics). */
+int64_t rga3_memattn_cross_ws_floats(int64_t Nq, int nsplit);
+int rga3_memattn_cross(const void* q, const void* k, const void* m, void* out, int64_t Nq, int64_t Nk, int64_t q_stride, int64_t k_stride, int64_t m_stride,
+                       int64_t out_stride, float scale, int nsplit, float* ws, void* stream);
 /* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up in launches that used this workspace (expected 0;
  * < 0 = error); synchronises the device */
 int rga3_gemm_stream_k_timeouts(const void* workspace);

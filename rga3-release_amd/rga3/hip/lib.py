@@ -48,6 +48,8 @@ SIGNATURES = {
     "rga3_bce_dice_sums_ws_floats": [_i64, _i64],
     "rga3_bce_dice_sums_det": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "rga3_attn_varlen_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _p, _f, _i, _p, _i64, _p],
+    "rga3_memattn_cross_ws_floats": [_i64, _i],
+    "rga3_memattn_cross": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _p, _p],
     "rga3_gemm_stream_k_timeouts": [_p],
     "rga3_gemm_timeout_counter_offset": [],
     "rga3_quant_fp8_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
@@ -86,7 +88,7 @@ SIGNATURES = {
     "rga3_bce_dice_grad_dev": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p],
 }
 
-_INT64_RESULTS = ("rga3_gemm_workspace_bytes", "rga3_gemm_timeout_counter_offset", "rga3_layernorm_bwd_ws_floats", "rga3_colsum_ws_floats", "rga3_mask_product_bwd_ws_floats", "rga3_bce_dice_sums_ws_floats")
+_INT64_RESULTS = ("rga3_gemm_workspace_bytes", "rga3_memattn_cross_ws_floats", "rga3_gemm_timeout_counter_offset", "rga3_layernorm_bwd_ws_floats", "rga3_colsum_ws_floats", "rga3_mask_product_bwd_ws_floats", "rga3_bce_dice_sums_ws_floats")
 
 _lib = None
 

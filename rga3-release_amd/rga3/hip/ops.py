@@ -451,6 +451,35 @@ def rope_axial_(x, cos, sin, n_rope: int):
     return x
 
 
+_memattn_ws = {}
+
+
+def memattn_cross(q, k, m, scale: float, nsplit: int = 0):
+    """SAM2 memory cross-attention with the values kept in memory space (csrc/memattn.hip): softmax(scale q k^T) m -> [Nq, 64] bf16.
+    q [Nq, 256], k [Nk, 256] bf16 (projected and rotated; row strides free), m [Nk, 64] bf16 the un-projected memory rows.  The caller applies the value
+    projection to the result.  nsplit = 0 picks the number of key slices that fills the chip (one 256-row query block x slice per CU)."""
+    _need_cuda(q, k, m)
+    assert q.dtype == k.dtype == m.dtype == torch.bfloat16 and q.dim() == k.dim() == m.dim() == 2
+    assert q.shape[1] == 256 and k.shape[1] == 256 and m.shape[1] == 64 and k.shape[0] == m.shape[0], (q.shape, k.shape, m.shape)
+    assert q.stride(1) == 1 and k.stride(1) == 1 and m.stride(1) == 1
+    Nq, Nk = q.shape[0], k.shape[0]
+    if nsplit <= 0:
+        nqb = (Nq + 255) // 256
+        nsplit = max(1, min(32, 256 // nqb, (Nk + 63) // 64))
+    L = _lib.load()
+    n = int(L.rga3_memattn_cross_ws_floats(Nq, nsplit))
+    if n < 0:
+        raise _lib.Rga3Error("memattn_cross: bad workspace query")
+    key = (q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+    ws = _memattn_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _memattn_ws[key] = torch.empty(n, dtype=torch.float32, device=q.device)
+    out = torch.empty((Nq, 64), dtype=torch.bfloat16, device=q.device)
+    _lib.check(L.rga3_memattn_cross(q.data_ptr(), k.data_ptr(), m.data_ptr(), out.data_ptr(), Nq, Nk, q.stride(0), k.stride(0), m.stride(0), out.stride(0),
+                                    float(scale), int(nsplit), ws.data_ptr(), _stream()), "memattn_cross")
+    return out
+
+
 def pixel_shuffle2x(g, bias, add, F: int, H: int, W: int, act: str = "none"):
     """g [F*H*W, 4*Co] -> [F*2H*2W, Co] (+bias, +add, then optional GELU)."""
     _need_cuda(g, bias, add)

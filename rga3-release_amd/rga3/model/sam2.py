@@ -595,20 +595,90 @@ class MemoryAttentionLayer(nn.Module):
 
 
 class MemoryAttention(nn.Module):
-    """reference sam2.py:533-600 (single object / single sequence per call; dropout inactive in eval)."""
+    """reference sam2.py:533-600 (single object / single sequence per call; dropout inactive in eval).
+
+    Inference path, MI355X form (round 3; the layers' own forward above stays as the plain restatement and as the path for LoRA-wrapped projections):
+      * the key projection of ALL layers is one product over the bank, [nk, 64] x [64, L*256], + one axial-RoPE pass (the bank does not depend on the layer input);
+      * the bank is never projected to values: the cross-attention kernel accumulates softmax(S) memory in the 64-wide memory space (csrc/memattn.hip) and the value
+        projection is applied to the 4096 query rows, folded with the output projection: out = PM (Wo Wv)^T + (Wo bv + bo);
+      * q / k / v of the self-attention are one product ([256 -> 768]) and one RoPE pass over the q | k columns."""
 
     def __init__(self, d_model, num_layers, dim_feedforward, kv_in_dim):
         super().__init__()
         self.d_model = d_model
         self.layers = nn.ModuleList(MemoryAttentionLayer(d_model, dim_feedforward, kv_in_dim) for _ in range(num_layers))
         self.norm = NormParams(d_model, 1e-5)
+        self._pk = None
+
+    def _fusable(self):
+        return not any(hasattr(m_, "lora_A") for l in self.layers for m_ in (l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj, l.self_attn.out_proj,
+                                                                             l.cross_attn_image.q_proj, l.cross_attn_image.k_proj, l.cross_attn_image.v_proj,
+                                                                             l.cross_attn_image.out_proj))
+
+    def _packs(self):
+        """Derived operands, rebuilt only when a source weight changes (frozen at inference: built once).  Elementwise torch ops + this library's own GEMM."""
+        from .qwen2_5_vl import _versions
+        srcs = []
+        for l in self.layers:
+            for a in (l.self_attn, l.cross_attn_image):
+                for m_ in (a.q_proj, a.k_proj, a.v_proj, a.out_proj):
+                    srcs += [m_.weight, m_.bias]
+        ver = _versions(*srcs)
+        if self._pk is not None and self._pk[0] == ver:
+            return self._pk[1]
+        with torch.no_grad():
+            pk = {"wk_all": torch.cat([l.cross_attn_image.k_proj.weight for l in self.layers], 0).contiguous(),
+                  "bk_all": torch.cat([l.cross_attn_image.k_proj.bias for l in self.layers], 0).contiguous(), "layers": []}
+            for l in self.layers:
+                sa, ca = l.self_attn, l.cross_attn_image
+                wov = ops.gemm(ca.out_proj.weight, ops.transpose(ca.v_proj.weight.contiguous()), out_dtype=torch.float32).to(ca.out_proj.weight.dtype)   # Wo Wv [256, 64]
+                bov = ops.gemm(ca.v_proj.bias.view(1, -1).contiguous(), ca.out_proj.weight, bias=ca.out_proj.bias, out_dtype=torch.float32).view(-1).to(ca.out_proj.weight.dtype)
+                pk["layers"].append({"wqkv": torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).contiguous(),
+                                     "bqkv": torch.cat([sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias], 0).contiguous(), "wov": wov.contiguous(), "bov": bov.contiguous()})
+        self._pk = (ver, pk)
+        return pk
+
+    def _tables(self, nq, reps, device):
+        """cos / sin of the axial RoPE tiled `reps` times along the columns (one pass rotates `reps` 256-wide column groups of a fused projection)."""
+        ra = self.layers[0].self_attn
+        key = ("tiled", nq, reps, str(device))
+        if key not in ra._tab:
+            cos, sin = ra.table(nq, device)
+            ra._tab[key] = (cos.repeat(1, reps).contiguous(), sin.repeat(1, reps).contiguous())
+        return ra._tab[key]
 
     def forward(self, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens):
         nq, nk = curr.shape[0], memory.shape[0]
         x = ops.add_bcast(curr, curr_pos, alpha=0.1)
         mem_k = ops.add(memory, memory_pos)
-        for layer in self.layers:
-            x = layer(x, mem_k, memory, nq, nk, num_obj_ptr_tokens)
+        if _ag() or not self._fusable() or self.d_model != 256 or memory.shape[1] != 64:
+            for layer in self.layers:
+                x = layer(x, mem_k, memory, nq, nk, num_obj_ptr_tokens)
+            return self.norm(x)
+        pk = self._packs()
+        L, D = len(self.layers), self.d_model
+        k_all = ops.gemm(mem_k, pk["wk_all"], pk["bk_all"])                           # keys of every layer: [nk, L * 256]
+        cosL, sinL = self._tables(nq, L, x.device)
+        ops.rope_axial_(k_all, cosL, sinL, nk - num_obj_ptr_tokens)
+        cos2, sin2 = self._tables(nq, 2, x.device)
+        cos1, sin1 = self.layers[0].self_attn.table(nq, x.device)
+        cu = _cu(1, nq, x.device)
+        memory = memory.contiguous()
+        for li, layer in enumerate(self.layers):
+            lp = pk["layers"][li]
+            t = layer.norm1(x)
+            qkv = ops.gemm(t, lp["wqkv"], lp["bqkv"])                                 # [nq, 768] = q | k | v
+            ops.rope_axial_(qkv[:, :2 * D], cos2, sin2, nq)
+            q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(1, (1, D)) for i in range(3))
+            o = ops.attn_varlen(q3, k3, v3, cu, cu, nq, D ** -0.5)
+            x = layer.self_attn.out_proj(o.view(nq, D), residual=x)
+            t = layer.norm2(x)
+            qp = layer.cross_attn_image.q_proj(t)
+            ops.rope_axial_(qp, cos1, sin1, nq)
+            pm = ops.memattn_cross(qp, k_all[:, li * D:(li + 1) * D], memory, D ** -0.5)   # softmax(S) memory, [nq, 64]
+            x = ops.gemm(pm, lp["wov"], lp["bov"], residual=x)                        # value + output projection on the query rows
+            t = layer.norm3(x)
+            x = layer.linear2(layer.linear1(t, act="relu"), residual=x)
         return self.norm(x)
 
 

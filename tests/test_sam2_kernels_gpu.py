@@ -219,3 +219,27 @@ def test_mask_product_forward_backward(dev, B, P, C):
     assert rel(du, ur.grad.view(B * P, C)) < 4e-3 and rel(dh, hr.grad) < 4e-3
     dh2, du2 = ops.mask_product_bwd(dm.to(dev), hyper, up, P)
     assert torch.equal(dh, dh2) and torch.equal(du, du2)
+
+
+@pytest.mark.parametrize("Nq,Nk,nsplit", [(4096, 28736, 0), (300, 1000, 0), (256, 70, 0), (513, 4160, 1), (64, 4096 + 4, 7), (4096, 4096 + 4, 0)])
+def test_memattn_cross_low_rank_values(dev, Nq, Nk, nsplit):
+    """csrc/memattn.hip: softmax(scale q k^T) m with the values kept in the 64-wide memory space, against fp32 attention on the same bf16 inputs -- the full
+    SAM2-L bank (4096 x 28 736), ragged query / key counts (partial 256-row blocks, a last tile of 40 / 6 / 4 keys), one slice and an uneven slice count, and keys
+    whose scores grow along the bank (the running maximum moves in every tile, so the rescaling path of the online softmax is exercised, not skipped)."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    q = (torch.randn(Nq, 256, generator=g) * 1.0).to(torch.bfloat16)
+    k = (torch.randn(Nk, 256, generator=g) * (0.5 + 1.5 * torch.linspace(0, 1, Nk)[:, None])).to(torch.bfloat16)
+    m = torch.randn(Nk, 64, generator=g).to(torch.bfloat16)
+    out = ops.memattn_cross(q.to(dev), k.to(dev), m.to(dev), 256 ** -0.5, nsplit=nsplit)
+    assert tuple(out.shape) == (Nq, 64) and out.dtype == torch.bfloat16
+    torch.set_num_threads(max(1, min(64, (__import__("os").cpu_count() or 2) // 2)))
+    ref = torch.softmax(q.float() @ k.float().t() * 256 ** -0.5, dim=-1) @ m.float()
+    assert rel(out, ref) < 1e-2, rel(out, ref)
+    # strided operands (a 256-wide column group of a fused [*, 1024] projection) give the same bits
+    kw = torch.zeros(Nk, 1024, dtype=torch.bfloat16)
+    kw[:, 512:768] = k
+    out2 = ops.memattn_cross(q.to(dev), kw.to(dev)[:, 512:768], m.to(dev), 256 ** -0.5, nsplit=nsplit)
+    assert torch.equal(out, out2)
+    assert torch.equal(out, ops.memattn_cross(q.to(dev), k.to(dev), m.to(dev), 256 ** -0.5, nsplit=nsplit))     # run-to-run identical (fixed summation order)
