@@ -207,11 +207,11 @@ class GemmTimer:
         return sum(s.elapsed_time(e) for s, e in self.ev)
 
 
-def _traffic(tag):
-    """HBM-side traffic per GEMM launch cannot be sampled inside the timed run (PMC needs rocprofv3): it comes from the committed two-pass
+def _traffic(tag, family="gemm"):
+    """HBM-side traffic per launch of a kernel family cannot be sampled inside the timed run (PMC needs rocprofv3): it comes from the committed two-pass
     FETCH_SIZE / WRITE_SIZE collection of this same command, summarised by tools/pmc_traffic.py."""
-    for r in ("r02",):
-        path = os.path.join(ROOT, "profiles", f"{r}_bench_{tag}_gemm_traffic.json")
+    for r in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{r}_bench_{tag}_{family}_traffic.json")
         if os.path.exists(path):
             tj = json.load(open(path))
             return round(tj["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)"
@@ -267,7 +267,7 @@ def _oracle_layer_params(R, lora=False):
     return L
 
 
-def cpu_baseline(train: bool, sam_frames: int = 16):
+def cpu_baseline(train: bool, sam_frames: int = 16, seq: int = 2112, grid_t: int = 8, micro_steps: int = 1):
     """Oracle (fp32 restatement of the reference's algorithm, 'port') on the host cores, bounded sample: one windowed + one full ViT block, one decoder
     layer and a 1/16 lm_head slice at 7B dims (train: + their backward as the reference runs it under gradient checkpointing, + one SAM2-L frame
     through Hiera-L/FPN and the mask decoder fwd+bwd), extrapolated to a whole sample (28 + 4 ViT blocks, 28 layers, lm_head, sam_frames frames)."""
@@ -278,8 +278,8 @@ def cpu_baseline(train: bool, sam_frames: int = 16):
     R = lambda *s: torch.randn(*s, generator=g) * 0.02
     tc = Q.TextCfg(num_hidden_layers=1, vocab_size=152064 // 16)
     P = _oracle_vit_params(R)
-    px = torch.randn(8192, 1176, generator=g)
-    grid = np.array([[8, 32, 32]])
+    px = torch.randn(grid_t * 1024, 1176, generator=g)
+    grid = np.array([[grid_t, 32, 32]])
 
     def vit_time(depth, full):
         with torch.no_grad():
@@ -293,8 +293,8 @@ def cpu_baseline(train: bool, sam_frames: int = 16):
     t_vit = t_em + 28 * t_win + 4 * t_full
     cfg1 = Q.QwenCfg(vision=Q.VisionCfg(depth=0, fullatt_block_indexes=()), text=tc)
     L = _oracle_layer_params(R, lora=train)
-    x = torch.randn(1, 2112, 3584, generator=g)
-    pos = torch.arange(2112)[None, None].expand(3, 1, -1)
+    x = torch.randn(1, seq, 3584, generator=g)
+    pos = torch.arange(seq)[None, None].expand(3, 1, -1)
     with torch.no_grad():
         t0 = time.perf_counter()
         h = Q.llm_forward(L, x, pos, None, cfg1)
@@ -304,7 +304,7 @@ def cpu_baseline(train: bool, sam_frames: int = 16):
         t0 = time.perf_counter()
         (h[0] @ wl.t()).float()
         t_lm_f = (time.perf_counter() - t0) * 16
-    parts = f"patch-embed+merger {t_em:.2f}s, 1 windowed ViT block {t_win:.2f}s, 1 full-attention ViT block {t_full:.2f}s, 1 decoder layer S=2112 fwd {t_layer_f:.2f}s, lm_head fwd (1/16 slice x16) {t_lm_f:.2f}s"
+    parts = f"patch-embed+merger {t_em:.2f}s, 1 windowed ViT block {t_win:.2f}s, 1 full-attention ViT block {t_full:.2f}s, 1 decoder layer S={seq} fwd {t_layer_f:.2f}s, lm_head fwd (1/16 slice x16) {t_lm_f:.2f}s"
     if not train:
         total = t_vit + 28 * t_layer_f + t_lm_f
         return {"value": round(1.0 / total, 6), "unit": "samples/s", "cores": cores, "kind": "port",
@@ -320,6 +320,12 @@ def cpu_baseline(train: bool, sam_frames: int = 16):
     t0 = time.perf_counter()
     torch.logsumexp((hg @ wlg.t()).float(), -1).mean().backward()
     t_lm_fb = (time.perf_counter() - t0) * 16
+    if sam_frames == 0:     # configs[4]: the LoRA step has no mask path; micro_steps micro-batches per optimizer step
+        total = t_vit + 28 * (t_layer_f + t_layer_fb) + t_lm_fb
+        return {"value": round(1.0 / total, 6), "unit": "samples/s", "cores": cores, "kind": "port",
+                "sample": (f"oracle fp32 at 7B dims on {cores} host threads (of {os.cpu_count()}): {parts}, decoder layer recompute+backward {t_layer_fb:.2f}s, lm_head+CE fwd+bwd "
+                           f"(1/16 slice x16) {t_lm_fb:.2f}s; extrapolated to 28+4 ViT blocks (fwd, frozen), 28 checkpointed layers, full-logits CE -> {total:.1f}s per sample "
+                           f"({micro_steps} samples per optimizer step = {micro_steps * total:.1f}s); the CPU leg runs fp32 (the reference's CPU path has no e4m3 arithmetic); +-2x with host load")}
     # ---- SAM2-L: one frame through the frozen Hiera-L + FPN, mask decoder fwd+bwd
     from oracle import sam2 as S
     from rga3.model.sam2 import SAM2
@@ -352,6 +358,41 @@ def cpu_baseline(train: bool, sam_frames: int = 16):
                        f"28+4 ViT blocks (fwd, frozen), 28 checkpointed layers (fwd + recompute + bwd), full-logits CE, {sam_frames} SAM2 frames -> {total:.1f}s per training sample"),
             "reference_stack_note": "SURVEY.md 8(d): the reference itself (transformers 5.15 + model/sam2.py, fp32, 8 cores of the survey container) ran the same forward in about 195 s; "
                                     "its Python cannot travel to this box"}
+
+
+def cpu_baseline_stream():
+    """configs[3] on the host: the oracle's memory path for ONE steady-state frame at SAM2-L dims -- memory attention (4 layers, 4096 queries x 7 x 4096 + 64 keys), mask
+    decoder heads, memory encoder -- with image features given (as in the timed GPU stream)."""
+    from oracle import sam2 as S
+    from rga3.model.sam2 import SAM2
+
+    cores = _host_threads()
+    g = torch.Generator().manual_seed(0)
+    sm = SAM2()
+    PS = {}
+    with torch.no_grad():
+        for k, v in sm.sam2_model.state_dict().items():
+            PS[k] = (torch.randn(v.shape, generator=g) * 0.02) if v.dim() >= 2 else (torch.ones(v.shape) if "norm" in k and k.endswith("weight") else torch.zeros(v.shape))
+    del sm
+    cfg = S.Sam2Cfg()
+    nq, nk, nptr = 4096, 7 * 4096 + 64, 64
+    R = lambda *s: torch.randn(*s, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        pix = S.memory_attention(PS, R(nq, 1, 256), R(nq, 1, 256), R(nk, 1, 64), R(nk, 1, 64), nptr, cfg)
+        t_ma = time.perf_counter() - t0
+        pixm = pix.permute(1, 2, 0).reshape(1, 256, 64, 64)
+        high = [R(1, 32, 256, 256), R(1, 64, 128, 128)]
+        t0 = time.perf_counter()
+        o = S.forward_sam_heads(PS, pixm, high, None, cfg, True)
+        t_dec = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        S.memory_encoder(PS, R(1, 256, 64, 64), o["high_res_masks"], cfg)
+        t_me = time.perf_counter() - t0
+    total = t_ma + t_dec + t_me
+    return {"value": round(1.0 / total, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle fp32 at SAM2-L dims on {cores} host threads (of {os.cpu_count()}), ONE steady-state frame with image features given: memory attention over "
+                       f"28 736 keys {t_ma:.2f}s, mask decoder heads {t_dec:.2f}s, memory encoder {t_me:.2f}s -> {total:.2f}s per frame; +-2x with host load")}
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -483,6 +524,37 @@ def sam2_stream(args, dev, rank, world, dist):
             m.language_embd_inference(sess_p, embs)
         barrier()
         elapsed_prompt = max(time.perf_counter() - t2, 1e-9)
+    # ---- dominant kernel of the stream, live: HIP events around every memory cross-attention launch of one EAGER stream (events cannot sit inside a replayed graph;
+    # same kernel, same operands), algorithmic flops / bytes of the launched shapes
+    dom = None
+    if rank == 0 and not timed_only:
+        from rga3.hip import ops as _ops
+        real, evs, acc = _ops.memattn_cross, [], [0.0, 0.0]
+
+        def timed(q, k, mm, scale, nsplit=0):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            r_ = real(q, k, mm, scale, nsplit)
+            e_.record()
+            evs.append((s_, e_))
+            acc[0] += 2.0 * q.shape[0] * k.shape[0] * (256 + 64)                               # QK^T over 256 + PM over 64
+            acc[1] += 2.0 * (q.numel() + k.numel() + mm.numel() + q.shape[0] * 64)             # q, k, memory read once, PM written (bf16)
+            return r_
+        _ops.memattn_cross = timed
+        try:
+            with torch.no_grad():
+                step(use_graph=False)
+            torch.cuda.synchronize()
+        finally:
+            _ops.memattn_cross = real
+        tot = sum(a.elapsed_time(b) for a, b in evs)
+        n = len(evs)
+        tr, src = _traffic("sam2_stream", "memattn")
+        dom = {"bound": "mfma", "kernel": "memattn_cross_kernel + memattn_combine_kernel (csrc/memattn.hip: 32x32x16 bf16 MFMA, values kept in the 64-wide memory space)",
+               "launches_per_stream": n, "avg_launch_ms": round(tot / max(n, 1), 5), "achieved": round(acc[0] / (tot * 1e-3) / 1e12, 1), "peak": PEAK_BF16 / 1e12,
+               "unit": "TFLOP/s", "frac": round(acc[0] / (tot * 1e-3) / PEAK_BF16, 4), "algorithmic_flops_per_launch": acc[0] / max(n, 1),
+               "algorithmic_bytes_per_launch": acc[1] / max(n, 1), "traffic": tr, "traffic_source": src,
+               "note": "flops as THIS kernel computes them (2 Nq Nk (256 + 64)); the reference's formulation (values projected to 256 first) would be 2 Nq Nk 512"}
     if dist is not None:
         t = torch.tensor([elapsed, elapsed_enc, elapsed_prompt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -508,14 +580,16 @@ def sam2_stream(args, dev, rank, world, dist):
                                        "embedding, frames 1.. propagate (memory attention over <= 7 memory frames + <= 16 object pointers, mask decoder, "
                                        "memory encoder); image features precomputed outside the timed region", "frames": T, "parallelism": f"replicas x{world}",
                            "prompt_every_frame_frames_per_s": round(world * T / (elapsed_prompt / args.steps), 2), "encoder_inclusive_frames_per_s": round(world * T / (elapsed_enc / args.steps), 2), "counts": sess.counts},
-                "roofline": {"bound": "mfma", "achieved": round(fl / sec / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                             "frac": round(fl / sec / PEAK_BF16, 4), "traffic": None,
-                             "note": "whole-stream algorithmic FLOPs / stream time; the attention cores are MFMA-bound, the streaming stages HBM-bound (SURVEY.md 8(d): report both roofs)"},
+                "roofline": dom if dom is not None else {"bound": "mfma", "achieved": None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": None, "traffic": None},
+                "roofline_stream": {"bound": "mfma", "achieved": round(fl / sec / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                                    "frac": round(fl / sec / PEAK_BF16, 4), "traffic": None,
+                                    "note": "whole-stream algorithmic FLOPs (SURVEY.md 8(d) formulation: values projected to 256) / stream time; the attention cores are MFMA-bound, "
+                                            "the streaming stages HBM-bound (report both roofs)"},
                 "roofline_hbm": {"bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(by / sec / PEAK_HBM, 4), "traffic": None,
                                  "algorithmic_bytes_per_frame": round(by / (T - 1)),
                                  "note": "whole-stream algorithmic HBM bytes (frame features, bank + position table once per frame, new memory slot, selected mask write + re-read, "
                                          "module weights) / stream time"},
-                "cpu_baseline": None}
+                "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or timed_only) else cpu_baseline_stream()}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -844,7 +918,11 @@ def main():
                            "approx_flops_per_step": fl, "batches": args.batches, "adamw_embed_rows_updated": rows_updated, "variants": variants},
                 "roofline": {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / peak, 4),
                              "traffic": None, "gemm_family": roof_tr, "note": "whole-step algorithmic FLOPs / step time against the dense fp8 (5 PF) or bf16 (2.5 PF) MFMA peak"},
-                "loss_first_last": [round(float(lv[0]), 5), round(float(lv[-1]), 5)], "comm": comm, "cpu_baseline": None}
+                "loss_first_last": [round(float(lv[0]), 5), round(float(lv[-1]), 5)], "comm": comm,
+                "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(train=True, sam_frames=0, seq=4160, grid_t=16, micro_steps=accum)}
+        tr8, src8 = _traffic("lora_fp8", "gemm")
+        if tr8 is not None:
+            line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr8, src8
         print(json.dumps(line), flush=True)
     elif rank == 0:
         fl = train_flops(args.sam_frames) if full else (10.8 + 30.8 - 2.3 + 28.5) * 1e12

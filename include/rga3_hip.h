@@ -199,6 +199,17 @@ int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
                          void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
                          int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale, int causal,
                          float* dkv_ws, int64_t total_k, void* stream);
+/* Token-side tail of the SAM2 mask decoder at inference (csrc/dechead.hip).
+ * rga3_mlp3_rows: n (<= 8) three-layer MLPs (Linear+ReLU, Linear+ReLU, Linear [+ sigmoid]) on ONE row per frame, B frames, one launch -- replaces the per-layer calls of
+ * reference model/sam2.py:2142-2155 (output_hypernetworks_mlps, iou_prediction_head, pred_obj_score_head; MLP.forward :2319-2329).  HOST arrays:
+ * ptrs = n x 8 device pointers {x, w0, b0, w1, b1, w2, b2, y} (bf16; weights [out, in] row-major, 16-byte aligned), dims = n x 6 {x frame stride, y frame stride
+ * (elements), in, hidden, out, final_act (0 none, 1 sigmoid)}; in / hidden multiples of 8, all <= 512.
+ * rga3_sam_select_objptr: reference model/sam2.py:3396-3421 -- best = argmax of IoU 1..3 (first maximum), sel = b * 4 + 1 + best, the chosen multimask token through
+ * obj_ptr_proj, replaced by no_obj_ptr where the object score is <= 0.  iou [B, 4], obj [B, 1], toks = mask tokens [B, 4, C] with frame stride tok_bstride;
+ * best = int64 [2, B] (row 0 the argmax, row 1 the plane index again as int64), sel = int32 [B]. */
+int rga3_mlp3_rows(const void* const* ptrs, const int64_t* dims, int n, int64_t B, void* stream);
+int rga3_sam_select_objptr(const void* iou, const void* obj, const void* toks, int64_t tok_bstride, int C, const void* w0, const void* b0, const void* w1, const void* b1,
+                           const void* w2, const void* b2, const void* no_obj_ptr, int64_t* best, int32_t* sel, void* obj_ptr, int64_t B, void* stream);
 /* SAM2 memory cross-attention with the values kept in memory space (csrc/memattn.hip): out [Nq, 64] bf16 = softmax(scale * q k^T) m for ONE 256-wide head,
  * q [Nq, 256], k [Nk, 256] (projected + rotated), m [Nk, 64] the un-projected memory rows; the caller applies the value projection to the 64-wide result
  * (softmax rows sum to one: softmax(S) (m Wv^T + bv) = (softmax(S) m) Wv^T + bv).  Replaces, for reference model/sam2.py:1519-1548 (RoPEAttention.forward of

@@ -200,8 +200,14 @@ __global__ __launch_bounds__(256) void im2col3x3s2_kernel(const unsigned short* 
 }
 
 // ---- depthwise Conv2d(k=7, p=3) on token-major maps [F, H, W, C]; w [C, 1, 7, 7]; 8 channels per thread.
+// The 49 x C filter taps are staged ONCE per workgroup as f32 [tap][C] in LDS (the first form fetched every tap of every channel with a scalar 2-byte global load:
+// 392 dependent loads per thread, 60 us for one 64 x 64 x 256 map); a thread then reads its 8 channels of a tap with two ds_read_b128.  Same taps, same order,
+// same f32 sums: bit-identical results.
 __global__ __launch_bounds__(256) void dwconv7_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                                       const unsigned short* __restrict__ bias, unsigned short* __restrict__ y, long F, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float dw_taps[];   // [49][C]
+    for (int i = threadIdx.x; i < 49 * C; i += 256) dw_taps[(i % 49) * C + i / 49] = bf2f(w[i]);
+    __syncthreads();
     const int nch = C / 8;
     const long total = F * H * W * nch;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -220,8 +226,13 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const unsigned short* __re
                 if (sx < 0 || sx >= W) continue;
                 float fx[8];
                 up8(*(const u32x4*)(x + ((f * H + sy) * (long)W + sx) * C + ch * 8), fx);
+                const float* wk = dw_taps + (kh * 7 + kw) * C + ch * 8;
+                const f32x4 w0 = *(const f32x4*)wk, w1 = *(const f32x4*)(wk + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += fx[e] * bf2f(w[(ch * 8 + e) * 49 + kh * 7 + kw]);
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] += fx[e] * w0[e];
+                    acc[4 + e] += fx[4 + e] * w1[e];
+                }
             }
         }
         *(u32x4*)(y + t * C + ch * 8) = pk8(acc);
@@ -401,8 +412,17 @@ extern "C" int rga3_im2col3x3s2(const void* x, void* cols, int64_t F, int H, int
 }
 
 extern "C" int rga3_dwconv7x7(const void* x, const void* w, const void* bias, void* y, int64_t F, int H, int W, int C, void* stream) {
-    RGA3_CHECK_ARG(x && w && y && F > 0 && C % 8 == 0, "dwconv7x7: bad args");
-    hipLaunchKernelGGL(dwconv7_kernel, dim3(grid1(F * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, (cus)x, (cus)w, (cus)bias, (us)y, (long)F, H, W, C);
+    RGA3_CHECK_ARG(x && w && y && F > 0 && C % 8 == 0 && C <= 512, "dwconv7x7: bad args (C %d: multiple of 8, <= 512)", C);
+    const int lds = 49 * C * 4;
+    static int lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)dwconv7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(-(int)e, "dwconv7x7: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        lds_set = lds;
+    }
+    unsigned gx = (unsigned)cdiv(F * H * W * (C / 8), 256);
+    if (gx > 1024) gx = 1024;     // every workgroup stages the taps once, then strides over the pixels
+    hipLaunchKernelGGL(dwconv7_kernel, dim3(gx), dim3(256), lds, (hipStream_t)stream, (cus)x, (cus)w, (cus)bias, (us)y, (long)F, H, W, C);
     RGA3_CHECK_LAUNCH("dwconv7x7");
     return 0;
 }

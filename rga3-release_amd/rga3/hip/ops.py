@@ -451,6 +451,47 @@ def rope_axial_(x, cos, sin, n_rope: int):
     return x
 
 
+def mlp3_rows(specs, B: int):
+    """Several 3-layer MLPs (Linear+ReLU, Linear+ReLU, Linear [+ sigmoid]) on one row per frame in ONE launch (csrc/dechead.hip).
+    specs: list of (x, x_frame_stride, (w0, b0, w1, b1, w2, b2), sigmoid[, y]) with x a bf16 tensor whose data_ptr is frame 0's row and y an optional [B, out] view
+    to write into (any frame stride).  -> list of [B, out] bf16."""
+    import ctypes
+    n = len(specs)
+    assert 1 <= n <= 8
+    ptrs, dims, outs, keep = (ctypes.c_void_p * (8 * n))(), (ctypes.c_int64 * (6 * n))(), [], []
+    for i, sp in enumerate(specs):
+        x, xs, (w0, b0, w1, b1, w2, b2), sig = sp[:4]
+        _need_cuda(x, w0, b0, w1, b1, w2, b2)
+        for t in (w0, w1, w2):
+            assert t.dtype == torch.bfloat16 and t.is_contiguous()
+        assert x.dtype == torch.bfloat16 and tuple(w1.shape) == (w0.shape[0], w0.shape[0]) and w2.shape[1] == w0.shape[0], (w0.shape, w1.shape, w2.shape)
+        y = sp[4] if len(sp) > 4 and sp[4] is not None else torch.empty((B, w2.shape[0]), dtype=torch.bfloat16, device=x.device)
+        assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, w2.shape[0]) and y.stride(1) == 1
+        for j, t in enumerate((x, w0, b0, w1, b1, w2, b2, y)):
+            ptrs[8 * i + j] = _ptr(t)
+        for j, v in enumerate((int(xs), y.stride(0), w0.shape[1], w0.shape[0], w2.shape[0], 1 if sig else 0)):
+            dims[6 * i + j] = v
+        outs.append(y)
+    _lib.check(_lib.load().rga3_mlp3_rows(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dims, ctypes.c_void_p), n, int(B), _stream()), "mlp3_rows")
+    return outs
+
+
+def sam_select_objptr(iou, obj, toks, proj, no_obj_ptr):
+    """-> (best [B] int64, sel [B] int32, sel64 [B] int64, obj_ptr [B, C] bf16): argmax over IoU 1..3, plane index b*4+1+best, obj_ptr_proj of the chosen multimask token, gated by obj > 0.
+    iou [B, 4], obj [B, 1] bf16 contiguous; toks [B, 4, C] bf16 (any frame stride); proj = (w0, b0, w1, b1, w2, b2)."""
+    _need_cuda(iou, obj, toks, no_obj_ptr, *proj)
+    B, _, C = toks.shape
+    assert iou.dtype == obj.dtype == toks.dtype == torch.bfloat16 and iou.is_contiguous() and obj.is_contiguous() and toks.stride(2) == 1 and toks.stride(1) == C
+    best = torch.empty((2, B), dtype=torch.int64, device=toks.device)
+    sel = torch.empty(B, dtype=torch.int32, device=toks.device)
+    ptr = torch.empty((B, C), dtype=torch.bfloat16, device=toks.device)
+    w0, b0, w1, b1, w2, b2 = proj
+    _lib.check(_lib.load().rga3_sam_select_objptr(iou.data_ptr(), obj.data_ptr(), toks.data_ptr(), toks.stride(0), C, w0.data_ptr(), _ptr(b0), w1.data_ptr(), _ptr(b1),
+                                                  w2.data_ptr(), _ptr(b2), no_obj_ptr.data_ptr(), best.data_ptr(), sel.data_ptr(), ptr.data_ptr(), B, _stream()),
+               "sam_select_objptr")
+    return best[0], sel, best[1], ptr
+
+
 _memattn_ws = {}
 
 

@@ -502,11 +502,37 @@ class MaskDecoder(nn.Module):
             up = ln1(up, act="gelu")
             g2 = ops.gemm(up, dc2.as_linear())
             up = ops.pixel_shuffle2x(g2, dc2.bias, feat_s0, B, 2 * h, 2 * w, act="gelu")          # [B*16hw, C/8]
+            heads = self._fused_heads(hs, B, nq)
+            if heads is not None:     # the six 3-layer MLPs on single token rows in ONE launch (csrc/dechead.hip)
+                hyper, iou, obj = heads
+                masks = ops.mask_product(hyper, up, npx).view(B, 4, 4 * h, 4 * w)
+                return masks, iou, mask_toks, obj
             hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i].contiguous()) for i in range(4)], dim=1)  # [B, 4, C/8]
             masks = ops.mask_product(hyper.contiguous(), up, npx).view(B, 4, 4 * h, 4 * w)   # masks[b] = hyper[b] @ up[b]^T, planes row-major, f32
         iou = self.iou_prediction_head(iou_tok.contiguous())
         obj = self.pred_obj_score_head(hs[:, 0].contiguous())
         return masks, iou, mask_toks, obj
+
+    def _fused_heads(self, hs, B, nq):
+        """hyper [B, 4, C/8], iou [B, 4] (sigmoid), obj [B, 1] from the decoder's output tokens hs [B, nq, C]: one launch.  None when a head is LoRA-wrapped or has an
+        unusual shape (the per-layer path above then runs)."""
+        C = self.transformer_dim
+        mlps = list(self.output_hypernetworks_mlps) + [self.iou_prediction_head, self.pred_obj_score_head]
+        if C % 8 or C > 512 or any(m_.num_layers != 3 or m_.act != "relu" or any(hasattr(l, "lora_A") for l in m_.layers) or m_.layers[0].out_features % 8
+                                   or m_.layers[0].out_features > 512 for m_ in mlps):
+            return None
+        if self.iou_prediction_head.layers[2].out_features != 4 or not self.iou_prediction_head.sigmoid_output:
+            return None
+        hs = hs.contiguous()
+        flat = hs.view(-1)
+        specs = []
+        hyper = torch.empty((B, 4, mlps[0].layers[2].out_features), dtype=hs.dtype, device=hs.device)
+        for i, m_ in enumerate(mlps):
+            tok = (2 + i) if i < 4 else (1 if i == 4 else 0)      # mask tokens 2..5, IoU token 1, object-score token 0
+            w = tuple(t for l in m_.layers for t in (l.weight, l.bias))
+            specs.append((flat[tok * C:], nq * C, w, i == 4, hyper[:, i] if i < 4 else None))
+        outs = ops.mlp3_rows(specs, B)
+        return hyper, outs[4], outs[5]
 
 
 class PositionEmbeddingRandom(nn.Module):
@@ -828,6 +854,16 @@ class SAM2VideoPredictor(nn.Module):
             s0, s1 = s0[a * 16 * h * w: b * 16 * h * w], s1[a * 4 * h * w: b * 4 * h * w]
         masks, iou, toks, obj = self.sam_mask_decoder(src, pe.dense_pe_tokens(src.dtype), sparse, s0, s1, B, h, w)
         ious = iou[:, 1:].float()
+        proj = self.obj_ptr_proj
+        if (not _ag() and proj.num_layers == 3 and proj.act == "relu" and not any(hasattr(l, "lora_A") for l in proj.layers) and toks.shape[2] % 8 == 0
+                and toks.shape[2] <= 512 and iou.dtype == torch.bfloat16):
+            # argmax over the multimask IoUs, chosen token -> obj_ptr_proj, object gating: one launch (csrc/dechead.hip)
+            best, sel, sel64, obj_ptr = ops.sam_select_objptr(iou.contiguous(), obj.contiguous(), toks, tuple(t for l in proj.layers for t in (l.weight, l.bias)),
+                                                       self.no_obj_ptr.view(-1))
+            low = masks.reshape(B * 4, 4 * h, 4 * w)[sel64].unsqueeze(1)                              # chosen candidate, f32
+            high = ops.bilinear(masks.view(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
+            return {"low_res_multimasks": masks[:, 1:], "ious": ious, "low_res_masks": low, "high_res_masks": high, "obj_ptr": obj_ptr,
+                    "object_score_logits": obj, "best_iou_inds": best}
         best = torch.argmax(ious, dim=-1)
         bi = torch.arange(B, device=best.device)
         sel = (bi * 4 + 1 + best).to(torch.int32)

@@ -243,3 +243,54 @@ def test_memattn_cross_low_rank_values(dev, Nq, Nk, nsplit):
     out2 = ops.memattn_cross(q.to(dev), kw.to(dev)[:, 512:768], m.to(dev), 256 ** -0.5, nsplit=nsplit)
     assert torch.equal(out, out2)
     assert torch.equal(out, ops.memattn_cross(q.to(dev), k.to(dev), m.to(dev), 256 ** -0.5, nsplit=nsplit))     # run-to-run identical (fixed summation order)
+
+
+def test_fused_decoder_heads_and_selection(dev):
+    """csrc/dechead.hip: (a) three-layer MLPs on single token rows, several MLPs x several frames in one launch (mixed output widths, sigmoid on one, outputs written
+    into strided views) against fp32 F.linear / relu on the same bf16 weights; (b) argmax over IoU 1..3 (first maximum on ties), plane index, obj_ptr_proj of the chosen
+    token and the hard object gate against the same arithmetic in torch -- indices bit-exact."""
+    from rga3.hip import ops
+
+    B, nq, C = 5, 9, 256
+    g = torch.Generator().manual_seed(5)
+    hs = torch.randn(B, nq, C, generator=g).to(torch.bfloat16)
+    def mk(i, h, o):
+        return [(torch.randn(a, b, generator=g) * 0.08).to(torch.bfloat16) if k == 0 else (torch.randn(a, generator=g) * 0.1).to(torch.bfloat16)
+                for a, b in ((h, i), (h, h), (o, h)) for k in (0, 1)]
+    sets = [mk(C, 256, 32), mk(C, 256, 32), mk(C, 64, 4), mk(C, 256, 1)]
+    toks = [2, 3, 1, 0]
+    hsd = hs.to(dev)
+    hyper = torch.empty((B, 2, 32), dtype=torch.bfloat16, device=dev)
+    specs = []
+    for i, (w, t) in enumerate(zip(sets, toks)):
+        specs.append((hsd.view(-1)[t * C:], nq * C, tuple(x.to(dev) for x in w), i == 2, hyper[:, i] if i < 2 else None))
+    outs = ops.mlp3_rows(specs, B)
+    for i, (w, t) in enumerate(zip(sets, toks)):
+        x = hs[:, t].float()
+        for li in range(3):
+            x = F.linear(x, w[2 * li].float(), w[2 * li + 1].float())
+            x = x.to(torch.bfloat16).float()
+            if li < 2:
+                x = F.relu(x)
+        if i == 2:
+            x = torch.sigmoid(x)
+        assert rel(outs[i], x) < 6e-3, (i, rel(outs[i], x))
+    assert torch.equal(outs[0], hyper[:, 0]) and torch.equal(outs[1], hyper[:, 1])
+    # (b) selection
+    iou = torch.tensor([[0.9, 0.2, 0.7, 0.7], [0.1, 0.5, 0.5, 0.4], [0.3, 0.1, 0.2, 0.6], [0.0, 0.8, 0.1, 0.3], [0.2, 0.25, 0.5, 0.125]]).to(torch.bfloat16)
+    obj = torch.tensor([[1.5], [-0.5], [0.0], [2.0], [0.25]]).to(torch.bfloat16)
+    proj = mk(C, C, C)
+    no_obj = (torch.randn(C, generator=g)).to(torch.bfloat16)
+    mask_toks = hsd[:, 2:6]
+    best, sel, sel64, ptr = ops.sam_select_objptr(iou.to(dev), obj.to(dev), mask_toks, tuple(x.to(dev) for x in proj), no_obj.to(dev))
+    rbest = torch.argmax(iou[:, 1:].float(), dim=-1)
+    assert torch.equal(best.cpu(), rbest) and rbest.tolist() == [1, 0, 2, 0, 1]
+    assert torch.equal(sel.cpu().long(), torch.arange(B) * 4 + 1 + rbest) and torch.equal(sel64.cpu(), sel.cpu().long())
+    x = hs[torch.arange(B), 3 + rbest].float()
+    for li in range(3):
+        x = F.linear(x, proj[2 * li].float(), proj[2 * li + 1].float()).to(torch.bfloat16).float()
+        if li < 2:
+            x = F.relu(x)
+    ref = torch.where(obj.float() > 0, x, no_obj.float()[None])
+    assert rel(ptr, ref) < 6e-3
+    assert torch.equal(ptr[1].cpu(), no_obj) and torch.equal(ptr[2].cpu(), no_obj)
