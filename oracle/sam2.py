@@ -463,8 +463,9 @@ def memory_attention(P, curr, curr_pos, memory, memory_pos, num_obj_ptr_tokens, 
     return layer_norm(x, P, "memory_attention.norm", 1e-5).transpose(0, 1)
 
 
-def prepare_memory_conditioned_features(P, frame_idx, is_init_cond_frame, vf, vpos, sizes, output_dict, num_frames, cfg: Sam2Cfg):
-    """S:2820-2989 (forward tracking, stride r=1, eval: only past pointers, no tpos on pointers)."""
+def prepare_memory_conditioned_features(P, frame_idx, is_init_cond_frame, vf, vpos, sizes, output_dict, num_frames, cfg: Sam2Cfg, track_in_reverse=False):
+    """S:2820-2989 (stride r=1, eval: only pointers on the already-tracked side, no tpos on pointers).  track_in_reverse (S:2829, :2866-2893, :2927-2944): the
+    "previous" frames are frame_idx + t_rel -- whatever pass left a memory there -- and pointers come from frames t >= frame_idx."""
     B = vf[-1].shape[1]
     C, (H, W) = cfg.d_model, sizes[-1]
     if is_init_cond_frame:
@@ -475,7 +476,7 @@ def prepare_memory_conditioned_features(P, frame_idx, is_init_cond_frame, vf, vp
     prevs = [(0, o) for o in sel.values()]
     for t_pos in range(1, cfg.num_maskmem):
         t_rel = cfg.num_maskmem - t_pos
-        prev_idx = frame_idx - t_rel
+        prev_idx = frame_idx + t_rel if track_in_reverse else frame_idx - t_rel
         out = output_dict["non_cond_frame_outputs"].get(prev_idx, None)
         if out is None:
             out = unsel.get(prev_idx, None)
@@ -487,10 +488,10 @@ def prepare_memory_conditioned_features(P, frame_idx, is_init_cond_frame, vf, vp
         enc = prev["maskmem_pos_enc"].flatten(2).permute(2, 0, 1)
         to_cat_pos.append(enc + P["maskmem_tpos_enc"][cfg.num_maskmem - t_pos - 1])
     max_ptrs = min(num_frames, cfg.max_obj_ptrs_in_encoder)
-    ptrs = [(abs(frame_idx - t), o["obj_ptr"]) for t, o in sel.items() if t <= frame_idx]
+    ptrs = [(abs(frame_idx - t), o["obj_ptr"]) for t, o in sel.items() if (t >= frame_idx if track_in_reverse else t <= frame_idx)]
     for t_diff in range(1, max_ptrs):
-        t = frame_idx - t_diff
-        if t < 0:
+        t = frame_idx + t_diff if track_in_reverse else frame_idx - t_diff
+        if t < 0 or t >= num_frames:
             break
         o = output_dict["non_cond_frame_outputs"].get(t, unsel.get(t, None))
         if o is not None:
@@ -510,11 +511,11 @@ def prepare_memory_conditioned_features(P, frame_idx, is_init_cond_frame, vf, vp
     return out.permute(1, 2, 0).view(B, C, H, W)
 
 
-def track_step(P, frame_idx, is_init_cond_frame, feats, output_dict, num_frames, cfg, run_mem_encoder, language_embd=None):
+def track_step(P, frame_idx, is_init_cond_frame, feats, output_dict, num_frames, cfg, run_mem_encoder, language_embd=None, track_in_reverse=False):
     """S:3160-3259"""
     vf, vpos, sizes = feats
     high = [x.permute(1, 2, 0).view(x.shape[1], x.shape[2], *s) for x, s in zip(vf[:-1], sizes[:-1])]
-    pix = prepare_memory_conditioned_features(P, frame_idx, is_init_cond_frame, vf[-1:], vpos[-1:], sizes[-1:], output_dict, num_frames, cfg)
+    pix = prepare_memory_conditioned_features(P, frame_idx, is_init_cond_frame, vf[-1:], vpos[-1:], sizes[-1:], output_dict, num_frames, cfg, track_in_reverse)
     # multimask: multimask_output_in_sam and (init or multimask_output_for_tracking) and 0 <= 0 pts <= 1 -> always True
     o = forward_sam_heads(P, pix, high, language_embd, cfg, True)
     cur = {"pred_masks": o["low_res_masks"], "pred_masks_high_res": o["high_res_masks"], "obj_ptr": o["obj_ptr"], "best_iou_inds": o["best_iou_inds"],
@@ -563,17 +564,22 @@ class VideoSession:
                                                  "maskmem_features": mf.to(torch.bfloat16), "maskmem_pos_enc": mp}
         self.temp_cond = {}
 
-    def propagate(self):
-        """S:4049-4132: yields (frame_idx, video_res_masks [1,1,S,S])."""
+    def propagate(self, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
+        """S:4049-4132: yields (frame_idx, video_res_masks [1,1,S,S]) in processing order."""
         self._preflight()
-        start = min(self.out["cond_frame_outputs"])
+        start = min(self.out["cond_frame_outputs"]) if start_frame_idx is None else start_frame_idx
+        n_track = self.num_frames if max_frame_num_to_track is None else max_frame_num_to_track
+        if reverse:     # S:4085-4090
+            order = range(start, max(start - n_track, 0) - 1, -1) if start > 0 else []
+        else:           # S:4091-4095
+            order = range(start, min(start + n_track, self.num_frames - 1) + 1)
         res = []
-        for t in range(start, self.num_frames):
+        for t in order:
             if t in self.out["cond_frame_outputs"]:
                 pm = self.out["cond_frame_outputs"][t]["pred_masks"]
             else:
                 feats = self._feats(t)
-                cur = track_step(self.P, t, False, feats, self.out, self.num_frames, self.cfg, True)
+                cur = track_step(self.P, t, False, feats, self.out, self.num_frames, self.cfg, True, track_in_reverse=reverse)
                 self.counts["memattn"] += 1
                 self.counts["dec"] += 1
                 self.counts["memenc"] += 1

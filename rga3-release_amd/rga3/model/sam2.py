@@ -1053,23 +1053,35 @@ class VideoSession:
             self.cond[t] = out
         self.temp_cond = {}
 
-    def _conditioned_features(self, t):
-        """reference sam2.py:2820-2989 (forward order, r = 1, only past pointers, no temporal enc on pointers)."""
+    def _memory_of(self, tt, out):
+        """maskmem features / positions of an already-tracked frame, encoded on first use: frames whose memory no later frame of the SAME pass reads are left without
+        one (propagate), and a later pass -- reverse tracking from a middle frame reads what the forward pass left on the frames after it -- encodes it then, from the
+        same low-resolution mask through the same bilinear map, i.e. the same numbers the reference stored at tracking time (reference sam2.py:3215-3259, :3017-3029)."""
+        if out.get("maskmem_features") is None:
+            out["maskmem_features"], out["maskmem_pos_enc"] = self._memory_for(tt, out["pred_masks"])
+        return out["maskmem_features"], out["maskmem_pos_enc"]
+
+    def _conditioned_features(self, t, reverse=False):
+        """reference sam2.py:2820-2989 (r = 1, no temporal enc on pointers).  Forward: memories of frames t - 6 .. t - 1 and pointers of the frames before t; reverse
+        (track_in_reverse): frames t + 1 .. t + 6 and pointers of the frames after t -- whichever pass left them (:2866-2893, :2927-2944)."""
         m = self.m
         h, w = self._ensure_feats()["hw"]
+        sgn = 1 if reverse else -1
         to_cat, to_cat_pos = [], []
-        prevs = [(0, o) for o in self.cond.values()]
+        prevs = [(0, tt, o) for tt, o in self.cond.items()]
         for t_pos in range(1, m.num_maskmem):
-            prevs.append((t_pos, self.non_cond.get(t - (m.num_maskmem - t_pos), None)))
-        for t_pos, prev in prevs:
+            tt = t + sgn * (m.num_maskmem - t_pos)
+            prevs.append((t_pos, tt, self.non_cond.get(tt, None)))
+        for t_pos, tt, prev in prevs:
             if prev is None:
                 continue
-            to_cat.append(prev["maskmem_features"])
-            to_cat_pos.append(ops.add_bcast(prev["maskmem_pos_enc"], m.maskmem_tpos_enc[m.num_maskmem - t_pos - 1].view(1, -1)))
-        ptrs = [o["obj_ptr"] for tt, o in self.cond.items() if tt <= t]
+            mf, mp = self._memory_of(tt, prev)
+            to_cat.append(mf)
+            to_cat_pos.append(ops.add_bcast(mp, m.maskmem_tpos_enc[m.num_maskmem - t_pos - 1].view(1, -1)))
+        ptrs = [o["obj_ptr"] for tt, o in self.cond.items() if (tt >= t if reverse else tt <= t)]
         for t_diff in range(1, min(self.num_frames, m.max_obj_ptrs_in_encoder)):
-            tt = t - t_diff
-            if tt < 0:
+            tt = t + sgn * t_diff
+            if tt < 0 or tt >= self.num_frames:
                 break
             o = self.non_cond.get(tt, None)
             if o is not None:
@@ -1156,18 +1168,27 @@ class VideoSession:
         pm, ptr, mf, mask = ent["outs"]
         return pm.clone(), ptr.clone(), mf.clone(), mask.clone()
 
-    def propagate(self, use_graph: bool = False):
-        """Yields (frame_idx, masks [1, 1, S, S] f32) for every frame from the first conditioning frame on.  use_graph: frames in steady
-        streams with one conditioning frame run every later frame as the replay of a captured hipGraph (one per bank state, kept on the
-        model) -- same kernels, same results."""
+    def propagate(self, use_graph: bool = False, start_frame_idx=None, max_frame_num_to_track=None, reverse: bool = False):
+        """reference propagate_in_video (sam2.py:4049-4132): (frame_idx, masks [1, 1, S, S] f32) in processing order -- by default every frame from the first
+        conditioning frame on; `start_frame_idx`, `max_frame_num_to_track`, `reverse` as the reference defines them (reverse from frame 0 yields nothing, :4087-4090).
+        use_graph: in a default forward stream with one conditioning frame every later frame runs as the replay of a captured hipGraph (one per bank state, kept on
+        the model) -- same kernels, same results."""
         S = self.m.image_size
         all_cond = set(self.temp_cond) | set(self.cond)
-        start = min(all_cond)
-        need_memory = any(t not in all_cond for t in range(start, self.num_frames))
+        if not all_cond:
+            raise RuntimeError("No points are provided; please add points first")     # the reference's message (:4066)
+        default = start_frame_idx is None and max_frame_num_to_track is None and not reverse
+        start = min(all_cond) if start_frame_idx is None else int(start_frame_idx)
+        n_track = self.num_frames if max_frame_num_to_track is None else int(max_frame_num_to_track)
+        if reverse:
+            order = list(range(start, max(start - n_track, 0) - 1, -1)) if start > 0 else []
+        else:
+            order = list(range(start, min(start + n_track, self.num_frames - 1) + 1))
+        need_memory = any(t not in all_cond for t in order)
         self._preflight(need_memory)
         res = []
-        graphed = use_graph and len(self.cond) == 1 and not _ag()
-        for t in range(start, self.num_frames):
+        graphed = use_graph and default and len(self.cond) == 1 and not _ag()
+        for i, t in enumerate(order):
             if graphed and t not in self.cond:
                 pm, ptr, mf, mask = self._graph_frame(t, start)
                 self.counts["memattn"] += 1
@@ -1179,11 +1200,11 @@ class VideoSession:
             if t in self.cond:
                 pm = self.cond[t]["pred_masks"]
             else:
-                pix = self._conditioned_features(t)
+                pix = self._conditioned_features(t, reverse)
                 o = self.m.forward_sam_heads(pix, self._ensure_feats(), None, frame_slice=(t, t + 1))
                 self.counts["dec"] += 1
                 cur = {"pred_masks": o["low_res_masks"], "obj_ptr": o["obj_ptr"], "best_iou_inds": o["best_iou_inds"]}
-                if any(tt not in self.cond for tt in range(t + 1, self.num_frames)):  # memory is dead after the last tracked frame
+                if any(tt not in self.cond for tt in order[i + 1:]):  # no later frame of this pass reads it otherwise (a later pass encodes it on first use: _memory_of)
                     self.counts["memenc"] += 1
                     cur["maskmem_features"], cur["maskmem_pos_enc"] = self.m.encode_new_memory(self._ensure_feats(), t, o["high_res_masks"])
                 self.non_cond[t] = cur

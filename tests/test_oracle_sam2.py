@@ -102,3 +102,31 @@ def test_g3_frame0_prompt_propagation_uses_memory_attention(G, P):
     ptrs = np.stack([(sess.out["cond_frame_outputs"] if t == 0 else sess.out["non_cond_frame_outputs"])[t]["obj_ptr"].numpy() for t in range(5)])
     assert close(ptrs, G["g3_prop0_obj_ptrs"], 2e-4)
     assert close(masks, G["g3_prop0_masks"], 2e-4)
+
+
+def test_g3_reverse_and_ranged_propagation(P):
+    """propagate_in_video(start_frame_idx, max_frame_num_to_track, reverse) and the track_in_reverse memory selection, against the reference's own outputs
+    (tests/golden/sam2_reverse.npz, made by make_sam2_reverse_fixtures.py): processing order exact, masks and object pointers <= 2e-4."""
+    import os
+    R = np.load(os.path.join(os.path.dirname(__file__), "golden", "sam2_reverse.npz"))
+    cfg = tiny_cfg()
+    img, emb = images(), lang()
+
+    def run(prompt, passes):
+        sess = S.VideoSession(P, img, cfg)
+        with torch.no_grad():
+            sess.add_language_embd(prompt, emb[0][None])
+            return sess, [sess.propagate(**kw) for kw in passes]
+
+    sess, (fa, ra) = run(2, [dict(), dict(start_frame_idx=2, reverse=True)])
+    assert [t for t, _ in fa] == R["A_fwd_frames"].tolist() and [t for t, _ in ra] == R["A_rev_frames"].tolist()
+    assert close(torch.cat([m for _, m in fa]), R["A_fwd_masks"], 2e-4) and close(torch.cat([m for _, m in ra]), R["A_rev_masks"], 2e-4)
+    od = sess.out
+    ptrs = torch.stack([(od["cond_frame_outputs"].get(t) or od["non_cond_frame_outputs"][t])["obj_ptr"] for t in range(5)])
+    assert close(ptrs, R["A_obj_ptrs"], 2e-4)
+    _, (rb,) = run(4, [dict(reverse=True, max_frame_num_to_track=2)])
+    assert [t for t, _ in rb] == R["B_frames"].tolist() and close(torch.cat([m for _, m in rb]), R["B_masks"], 2e-4)
+    _, (rc,) = run(1, [dict(start_frame_idx=1, max_frame_num_to_track=2)])
+    assert [t for t, _ in rc] == R["C_frames"].tolist() and close(torch.cat([m for _, m in rc]), R["C_masks"], 2e-4)
+    _, (rd,) = run(0, [dict(reverse=True)])
+    assert rd == [] and R["D_frames"].size == 0

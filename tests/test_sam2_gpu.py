@@ -131,6 +131,46 @@ def test_frame0_prompt_propagation(model, dev, P, G):
     assert rel(ptr, torch.from_numpy(G["g3_prop0_obj_ptrs"]).reshape(5, -1)) < 2e-2
 
 
+def test_reverse_and_ranged_propagation(model, dev, P):
+    """VideoSession.propagate(start_frame_idx, max_frame_num_to_track, reverse) against the reference's own propagate_in_video outputs (tests/golden/
+    sam2_reverse.npz) and the oracle: processing order exact; masks rel-L2 <= 2e-2 / IoU >= 0.99; object pointers <= 2e-2.  Case A runs a forward pass and then a
+    reverse pass on the same session: the reverse pass reads the memories the forward pass left on frames 3 and 4 -- one of which the forward pass never encoded
+    (nothing after frame 4 read it), so it is encoded on first use."""
+    import os
+    from rga3.model.sam2 import VideoSession
+
+    R = np.load(os.path.join(os.path.dirname(__file__), "golden", "sam2_reverse.npz"))
+    cfg = tiny_cfg()
+    img, emb = images().to(torch.bfloat16), lang().to(torch.bfloat16)
+
+    def run(prompt, passes):
+        with torch.no_grad():
+            sess = VideoSession(model.sam2_model, img.to(dev))
+            sess.add_language_embd(prompt, emb[0][None].to(dev))
+            return sess, [sess.propagate(**kw) for kw in passes]
+
+    def check(res, frames, gm):
+        assert [t for t, _ in res] == frames.tolist()
+        masks, gm = torch.cat([m for _, m in res]), torch.from_numpy(gm)
+        assert rel(masks, gm) < 2e-2, rel(masks, gm)
+        assert min(iou(masks[i] > 0, gm[i] > 0) for i in range(len(frames))) >= 0.99
+
+    sess, (fa, ra) = run(2, [dict(), dict(start_frame_idx=2, reverse=True)])
+    check(fa, R["A_fwd_frames"], R["A_fwd_masks"])
+    check(ra, R["A_rev_frames"], R["A_rev_masks"])
+    ptr = torch.stack([(sess.cond.get(t) or sess.non_cond[t])["obj_ptr"].float().cpu().reshape(-1) for t in range(5)])
+    assert rel(ptr, torch.from_numpy(R["A_obj_ptrs"]).reshape(5, -1)) < 2e-2
+    assert sess.counts["enc"] == 5      # every frame encoded once over both passes
+    _, (rb,) = run(4, [dict(reverse=True, max_frame_num_to_track=2)])
+    check(rb, R["B_frames"], R["B_masks"])
+    _, (rc,) = run(1, [dict(start_frame_idx=1, max_frame_num_to_track=2)])
+    check(rc, R["C_frames"], R["C_masks"])
+    _, (rd,) = run(0, [dict(reverse=True)])
+    assert rd == [] and R["D_frames"].size == 0
+    with pytest.raises(RuntimeError):
+        VideoSession(model.sam2_model, img.to(dev)).propagate()
+
+
 def test_graph_replay_equals_eager_stream(model, dev):
     """A 24-frame stream prompted on frame 0: every later frame runs as the replay of a captured hipGraph over static buffers (one graph per
     bank state: 15 growing states, then the steady one); masks, pointers and memories must equal the eager frame-by-frame path bit for bit

@@ -201,6 +201,17 @@ def test_training_gradients_through_mask_path(dev, G):
     print('EMU_ERRS median %.4f  SENS_ERRS median %.4f' % (float(np.median(list(emu.values()))), float(np.median(list(sens.values())))))
     bad = {k: (round(e, 4), round(yard[k], 4)) for k, e in errs.items() if e > max(3e-2, 2.0 * yard[k] + 1.5e-2)}
     assert not bad, (bad, sorted(errs.values())[-5:])
+    # a wrong kernel must not hide behind a noisy yardstick: whatever the yardstick says, every tensor that carries a non-negligible share of the gradient
+    # stays under a hard ceiling and points the same way as the oracle's.  (Round 3 found what makes this point noisy: ReLU units of the single-row MLPs -- hyper-
+    # networks, text_hidden_fcs -- that sit within bf16 rounding of zero flip between the bf16 forward and the fp32 oracle, and each flipped unit of a 256-wide row moves
+    # that row's gradient by several per cent.  With every ReLU firmly on or off the same kernels meet the flat 3e-2 at SAM2-L size:
+    # tests/test_fullsize_parity_gpu.py::test_mask_decoder_sam2_l_forward_backward.)
+    total = float(np.sqrt(sum(float(r_.float().norm()) ** 2 for k, (g_, r_) in pairs.items() if k in errs)))
+    for k, (g_, r_) in pairs.items():
+        if k in errs and float(r_.float().norm()) > 1e-3 * total:
+            gf, rf = g_.float().cpu().flatten(), r_.float().cpu().flatten()
+            assert errs[k] <= 0.25, (k, errs[k])
+            assert float((gf @ rf) / (gf.norm() * rf.norm())) > 0.97, k
     assert errs["lm_head.weight"] < 3e-2 and errs["model.embed_tokens.weight"] < 3e-2
     assert float(np.median(list(errs.values()))) < 2.0 * float(np.median(list(yard.values()))) + 1e-2
     # the direction of the whole mask-path gradient is stable: cosine of the concatenated decoder + text_hidden_fcs gradients

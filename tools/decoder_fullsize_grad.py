@@ -14,8 +14,9 @@ from tests.test_fullsize_parity_gpu import _mask_decoder_case, rel  # noqa: E402
 dbg = {}
 r = _mask_decoder_case(torch.device("cuda:0"), float(sys.argv[1]) if len(sys.argv) > 1 else 1.0, dbg, firm_relu=len(sys.argv) > 2 and sys.argv[2] == "firm")
 print("best", r["best"], "low", r["low"], "loss", r["loss"])
-for n, e in sorted(r["errs"].items(), key=lambda kv: -kv[1])[:45]:
-    print(f"{e:9.4f}  {n}")
+tot = sum(v * v for v in r["norms"].values()) ** 0.5
+for n, e in sorted(r["errs"].items(), key=lambda kv: -kv[1])[:60]:
+    print(f"{e:9.4f}  |g|/|G| {r['norms'][n] / tot:9.2e}  {n}")
 d, ri = dbg["product"], dbg["oracle"]
 B = ri["masks"].shape[0]
 h = ri["upscaled"].shape[2] // 4
