@@ -67,9 +67,11 @@ int64_t rga3_gemm_workspace_bytes(void);
 /* C[M,N] (bf16 / f32) = A^T . B (+ bias[n]); A [K,M], B [K,N] bf16 row-major (K = tokens): the weight-gradient product dW = dY^T X of
  * nn.Linear / LoRA (autograd under reference train_joint.py:534) without transposing the activations first.  M, N multiples of 8.
  * workspace (optional, caller-owned, 16-byte aligned): with few output tiles over many tokens (LoRA dW: 128 x 3584 over 2112-4160 tokens) K is
- * cut into <= 16 slices whose f32 partial sums (Z * M * N * 4 bytes) are added in fixed order by a second launch. */
+ * cut into <= 64 slices whose f32 partial sums (Z * M * N * 4 bytes) are added in fixed slice order -- by a second launch, or, with `counters` (>= 128 32-bit
+ * words, zeroed ONCE by the caller and kept for the calls of one stream: the kernel leaves them zero), inside the same launch by the workgroup that reaches an output
+ * tile last (which one is timing, the order of the additions is not: deterministic). */
 int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                      int64_t ldc, int out_dtype, void* workspace, int64_t workspace_bytes, void* stream);
+                      int64_t ldc, int out_dtype, void* workspace, int64_t workspace_bytes, void* counters, void* stream);
 
 
 /* Variable-length fused attention forward (online softmax, fp32 statistics), bf16 in/out.
@@ -237,6 +239,9 @@ int rga3_swiglu_fwd(const void* gu, void* a, int64_t T, int64_t I, void* stream)
 int rga3_swiglu_bwd(const void* gu, const void* da, void* dgu, int64_t T, int64_t I, void* stream);
 /* out[c, r] = in[r, c] (16-bit): operand layout for dW = dY^T X through the NT GEMM */
 int rga3_transpose16(const void* in, void* out, int64_t R, int64_t C, int64_t ld_in, int64_t ld_out, void* stream);
+/* the same for n (<= 64) CONTIGUOUS 16-bit matrices in one launch (the W^T operands of the mask path's dX products: reference autograd through nn.Linear,
+ * model/sam2.py:1417-1481, 2305-2329): HOST arrays ptrs = n x {in, out}, dims = n x {R, C}; out[i] is [C_i, R_i]. */
+int rga3_transpose16_many(const void* const* ptrs, const int64_t* dims, int n, void* stream);
 /* out[u,:] = sum_{j in [offsets[u], offsets[u+1])} x[rows[j],:]: embedding-table gradient rows (HF embed_tokens, trainable per
  * train_joint.py:242-243) without atomics */
 int rga3_segment_sum_rows(const void* x, const int64_t* rows, const int64_t* offsets, void* out, int64_t n_out, int64_t dim, int64_t ldx,

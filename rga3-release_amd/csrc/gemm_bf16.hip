@@ -1167,6 +1167,13 @@ struct TnArgs {
     int K;
     int kt_per_z;   // K-tiles (of 32) per grid.z slice; slices > 0 write f32 partial sums to slab z of p.C (see rga3_gemm_tn_bf16)
     long slab;      // elements per slab (0: no K split)
+    // fused slab sum (round 3): with `counters` the workgroup that arrives LAST at an output tile adds that tile's Z slabs in slice order and writes the result --
+    // which workgroup does it depends on timing, the order of the additions does not (deterministic); no second launch.  One counter word per output tile, zeroed once
+    // by the caller, left zero again by the kernel.
+    unsigned* counters;
+    void* out;      // final output (bf16 or f32, row stride ldo)
+    long ldo;
+    int out_f32;
 };
 
 template <bool OUT_F32>
@@ -1250,7 +1257,50 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+    const float* ws_base = (const float*)p.C - (t.slab ? (long)blockIdx.z * t.slab : 0);
     gemm_epilogue<4, 4, 64, 64, ACT_NONE, OUT_F32>(acc, p, smem, lane, m0, n0, wm, wn);
+    if constexpr (OUT_F32) {
+        if (t.counters) {
+            // hand-off (cdna_hip_programming.md Guideline 16): every wave drains its slab stores, one lane releases at agent scope and takes a ticket; the last
+            // arrival acquires, then the whole workgroup reads the other slices' slabs
+            __shared__ unsigned s_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned prev = __hip_atomic_fetch_add(t.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (prev == gridDim.z - 1) ? 1u : 0u;
+                if (s_last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __syncthreads();
+            if (s_last) {
+                const int Z = (int)gridDim.z;
+                for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+                    const int r = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+                    const int row = m0 + r, col = n0 + c4;
+                    if (row < p.M && col < p.N) {          // N % 8 == 0: a quad never straddles the edge
+                        const float* src = ws_base + (long)row * p.N + col;
+                        f32x4 sum = *(const f32x4*)src;
+                        for (int z = 1; z < Z; ++z) sum += *(const f32x4*)(src + (long)z * t.slab);
+                        if (t.out_f32) {
+                            *(f32x4*)((float*)t.out + (long)row * t.ldo + col) = sum;
+                        } else {
+                            u32x2 pk;
+                            pk[0] = pack_bf2(sum[0], sum[1]);
+                            pk[1] = pack_bf2(sum[2], sum[3]);
+                            *(u32x2*)((unsigned short*)t.out + (long)row * t.ldo + col) = pk;
+                        }
+                    }
+                }
+                if (tid == 0) __hip_atomic_store(t.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch on this stream
+            }
+        }
+    }
 }
 
 // out[i] = sum_z slabs[z][i] in fixed order (deterministic), to bf16 or f32; 4 elements per thread
@@ -1552,7 +1602,7 @@ extern "C" int rga3_gemm_ln_bf16(const void* A, const void* Wf, const void* bias
 // C[M, N] (bf16 or f32) = A^T . B (+ bias[n]) with A [K, M], B [K, N] bf16 row-major: the weight-gradient product dW = dY^T X without
 // transposing either operand first.  M, N multiples of 8; lda / ldb / ldc in elements.
 extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                                 int64_t ldb, int64_t ldc, int out_dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+                                 int64_t ldb, int64_t ldc, int out_dtype, void* workspace, int64_t workspace_bytes, void* counters, void* stream) {
     RGA3_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
     RGA3_CHECK_ARG(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0, "gemm_tn: bad shape M=%ld N=%ld K=%ld (M, N multiples of 8)", (long)M, (long)N, (long)K);
     RGA3_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_tn: lda/ldb must be multiples of 8 elements, ldc of 4");
@@ -1568,6 +1618,7 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
     TnArgs t;
     t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
+    t.counters = nullptr; t.out = nullptr; t.ldo = 0; t.out_f32 = 0;
     const int nk = (int)cdiv(K, 32);
     // few output tiles over many tokens (LoRA dW: 1 x 28 tiles, K = 2112 / 4160; mask-path dW: 1-4 tiles, K = 65 536 ..): cut K into Z slices, one workgroup each, f32 partial slabs in
     // the caller's workspace, summed in fixed order by a second launch (deterministic; no atomics)
@@ -1595,6 +1646,13 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     t.slab = M * N;
     a.C = workspace; a.ldc = N;
     dim3 grid((unsigned)a.ntn, (unsigned)a.ntm, (unsigned)Z);
+    if (counters && tiles <= 128) {   // the slab sum happens inside the launch (last workgroup per tile, fixed order)
+        RGA3_CHECK_ARG((((uintptr_t)counters) & 3) == 0, "gemm_tn: counters must be 4-byte aligned");
+        t.counters = (unsigned*)counters; t.out = C; t.ldo = ldc; t.out_f32 = out_dtype == RGA3_F32 ? 1 : 0;
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a, t);
+        RGA3_CHECK_LAUNCH("gemm_tn_kernel<fused sum>");
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a, t);
     RGA3_CHECK_LAUNCH("gemm_tn_kernel");
     hipLaunchKernelGGL(tn_slab_sum_kernel, dim3((unsigned)cdiv(M * N / 4, 256)), dim3(256), 0, st, (const float*)workspace, C, (long)(M * N), (long)ldc, (int)N, Z,

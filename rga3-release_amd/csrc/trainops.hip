@@ -172,6 +172,34 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* 
     }
 }
 
+// the same for up to 64 matrices in ONE launch (blockIdx.z = matrix; tiles beyond a matrix's extent exit): the mask path's backward needs W^T of ~46 small
+// weight matrices per step -- as 46 launches at the ~5 us launch floor they were 0.4 ms of the step
+constexpr int TR_MANY = 64;
+struct TransposeMany {
+    const unsigned short* in[TR_MANY];
+    unsigned short* out[TR_MANY];
+    int R[TR_MANY], C[TR_MANY];
+};
+__global__ __launch_bounds__(256) void transpose16_many_kernel(TransposeMany p) {
+    __shared__ unsigned short tile[64][66];
+    const int m = blockIdx.z;
+    const long R = p.R[m], C = p.C[m];
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    if (r0 >= R || c0 >= C) return;
+    const unsigned short* in = p.in[m];
+    unsigned short* out = p.out[m];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const long r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[r * C + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const long c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[c * R + r] = tile[tx][i];
+    }
+}
+
 // out[u, :] = sum_{j in [off[u], off[u+1])} x[rows[j], :]   (fp32 accumulate, bf16 out); one block per output row
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const unsigned short* __restrict__ x, const long* __restrict__ rows,
                                                                const long* __restrict__ off, unsigned short* __restrict__ out, int dim, long ldx) {
@@ -407,6 +435,26 @@ extern "C" int rga3_transpose16(const void* in, void* out, int64_t R, int64_t C,
     hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, (cus)in, (us)out, (long)R,
                        (long)C, (long)ld_in, (long)ld_out);
     RGA3_CHECK_LAUNCH("transpose16");
+    return 0;
+}
+
+// n (<= 64) contiguous 16-bit matrices transposed in one launch: in[i] [R_i, C_i] -> out[i] [C_i, R_i].  HOST arrays: ptrs = n x {in, out}, dims = n x {R, C}.
+extern "C" int rga3_transpose16_many(const void* const* ptrs, const int64_t* dims, int n, void* stream) {
+    RGA3_CHECK_ARG(ptrs && dims && n >= 1 && n <= TR_MANY, "transpose16_many: n %d (1..64)", n);
+    TransposeMany p;
+    long mr = 0, mc = 0;
+    for (int i = 0; i < n; ++i) {
+        p.in[i] = (const unsigned short*)ptrs[2 * i];
+        p.out[i] = (unsigned short*)ptrs[2 * i + 1];
+        RGA3_CHECK_ARG(p.in[i] && p.out[i] && dims[2 * i] > 0 && dims[2 * i + 1] > 0 && dims[2 * i] < (1 << 30) && dims[2 * i + 1] < (1 << 30), "transpose16_many: matrix %d", i);
+        p.R[i] = (int)dims[2 * i];
+        p.C[i] = (int)dims[2 * i + 1];
+        if (p.R[i] > mr) mr = p.R[i];
+        if (p.C[i] > mc) mc = p.C[i];
+    }
+    RGA3_CHECK_ARG(cdiv(mr, 64) <= 65535, "transpose16_many: too many rows");
+    hipLaunchKernelGGL(transpose16_many_kernel, dim3((unsigned)cdiv(mc, 64), (unsigned)cdiv(mr, 64), (unsigned)n), dim3(256), 0, (hipStream_t)stream, p);
+    RGA3_CHECK_LAUNCH("transpose16_many");
     return 0;
 }
 

@@ -9,6 +9,29 @@ import torch
 from . import ops
 
 
+# W^T operands of the dX products: every weight whose input needs a gradient is noted in forward; the first backward that misses transposes ALL of them in one launch
+# (ops.transpose_many) -- ~46 transposes of small matrices per training step were ~46 launches at the launch floor (profiles/r02_train_step_timeline.txt, 105-115 ms).
+# Entries are checked against the weight's version, so an optimizer step in between simply misses.
+_wt_pending, _wt_cache = {}, {}
+
+
+def _transposed(w):
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _wt_cache.get(w.data_ptr())
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    todo = dict(_wt_pending)
+    todo[w.data_ptr()] = w
+    _wt_pending.clear()
+    _wt_cache.clear()
+    ws = list(todo.values())
+    # every entry keeps its SOURCE tensor alive: while an entry exists no other tensor can be allocated at its address, so (address, version, shape) identifies the
+    # weight (several of these are per-step temporaries -- ConvTranspose weights re-laid out, LoRA factors times their scale)
+    for t, tt in zip(ws, ops.transpose_many(ws)):
+        _wt_cache[t.data_ptr()] = ((t.data_ptr(), t._version, tuple(t.shape)), tt, t)
+    return _wt_cache[w.data_ptr()][1]
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(a @ w^T + bias) (+ residual); act in {"none", "relu"}; out bf16 or f32."""
 
@@ -17,6 +40,8 @@ class LinearFn(torch.autograd.Function):
         y = ops.gemm(a, w, bias, residual=residual, act=act, out_dtype=torch.float32 if out_f32 else torch.bfloat16)
         ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, residual is not None
         ctx.save_for_backward(a, w, y if act == "relu" else None)
+        if a.requires_grad and w.dim() == 2 and w.is_contiguous() and w.element_size() == 2:
+            _wt_pending[w.data_ptr()] = w.detach()
         return y
 
     @staticmethod
@@ -30,7 +55,8 @@ class LinearFn(torch.autograd.Function):
             dy = ops.act_bwd(y, dy, "relu")
         da = dw = db = None
         if ctx.needs_input_grad[0]:
-            da = ops.gemm(dy, ops.transpose(w.detach()))            # [M, K] = dy @ w   (ops.gemm pads ragged reduction dims)
+            wd = w.detach()
+            da = ops.gemm(dy, _transposed(wd) if (wd.dim() == 2 and wd.is_contiguous() and wd.element_size() == 2) else ops.transpose(wd))   # [M, K] = dy @ w
         if ctx.needs_input_grad[1]:
             dw = ops.gemm_tn(dy, a.detach()).to(w.dtype)    # [N, K] = dy^T @ a, contraction over rows as they lie (per-pixel products: up to 64 K-slices)
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -20,7 +20,7 @@ SIGNATURES = {
     "rga3_last_error": [C.c_char_p, _sz],
     "rga3_gemm_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _p, _i64, _p],
     "rga3_gemm_workspace_bytes": [],
-    "rga3_gemm_tn_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _p, _i64, _p],
+    "rga3_gemm_tn_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _p, _i64, _p, _p],
     "rga3_attn_varlen_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
                              _i64, _i64, _f, _i, _i, _p, _i64, _i, _i, _i, _p],
     "rga3_attn_varlen_fwd_rope": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _p, _p, _p, _p, _p],
@@ -48,6 +48,7 @@ SIGNATURES = {
     "rga3_bce_dice_sums_ws_floats": [_i64, _i64],
     "rga3_bce_dice_sums_det": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "rga3_attn_varlen_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _p, _f, _i, _p, _i64, _p],
+    "rga3_transpose16_many": [_p, _p, _i, _p],
     "rga3_mlp3_rows": [_p, _p, _i, _i64, _p],
     "rga3_sam_select_objptr": [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
     "rga3_memattn_cross_ws_floats": [_i64, _i],

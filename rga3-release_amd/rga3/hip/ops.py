@@ -177,14 +177,27 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == out_dtype
-    ws = None
+    ws = cnt = None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles < 128 and K >= 1024:      # few output tiles over many tokens: give the kernel room to split K (<= 64 f32 slabs)
         ws = torch.empty((min(64, 256 // tiles, max(2, K // 256)) * M * N,), dtype=torch.float32, device=a.device)
+        cnt = _tn_counters(a.device)   # the slab sum then runs inside the same launch (last workgroup per tile, fixed order)
     _lib.check(_lib.load().rga3_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-                                             BF16 if out_dtype == torch.bfloat16 else F32, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
+                                             BF16 if out_dtype == torch.bfloat16 else F32, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _ptr(cnt), _stream()),
                "gemm_tn_bf16")
     return out
+
+
+_tn_cnt = {}
+
+
+def _tn_counters(device):
+    """128 ticket words per (device, stream) for the fused slab sum of gemm_tn: zeroed once, the kernel leaves them zero."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    t = _tn_cnt.get(key)
+    if t is None:
+        t = _tn_cnt[key] = torch.zeros(128, dtype=torch.int32, device=device)
+    return t
 
 
 def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = False, out=None, return_lse=False,
@@ -666,6 +679,25 @@ def transpose(x):
     out = torch.empty((C, R), dtype=x.dtype, device=x.device)
     _lib.check(_lib.load().rga3_transpose16(x.data_ptr(), out.data_ptr(), R, C, x.stride(0), R, _stream()), "transpose16")
     return out
+
+
+def transpose_many(mats):
+    """Contiguous 2-D 16-bit matrices -> their contiguous transposes, 64 per launch (csrc/trainops.hip)."""
+    import ctypes
+    outs = []
+    for a in range(0, len(mats), 64):
+        grp = mats[a:a + 64]
+        n = len(grp)
+        ptrs, dims = (ctypes.c_void_p * (2 * n))(), (ctypes.c_int64 * (2 * n))()
+        for i, x in enumerate(grp):
+            _need_cuda(x)
+            assert x.dim() == 2 and x.is_contiguous() and x.element_size() == 2
+            o = torch.empty((x.shape[1], x.shape[0]), dtype=x.dtype, device=x.device)
+            ptrs[2 * i], ptrs[2 * i + 1] = x.data_ptr(), o.data_ptr()
+            dims[2 * i], dims[2 * i + 1] = x.shape[0], x.shape[1]
+            outs.append(o)
+        _lib.check(_lib.load().rga3_transpose16_many(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dims, ctypes.c_void_p), n, _stream()), "transpose16_many")
+    return outs
 
 
 def segment_sum_rows(x, rows, offsets):
