@@ -279,9 +279,11 @@ int rga3_layernorm_bwd(const void* x, const void* weight, const void* dy, void* 
                        float eps, float* ws, int64_t ws_floats, void* stream);
 /* out[c] += sum_r x[r,c] (bias gradients; any width, f32 atomics) */
 int rga3_colsum_accum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* stream);
-/* out[c] = sum_r x[r,c], written, deterministic two-stage sum; cols and ld multiples of 8, 16-byte aligned x; ws: rga3_colsum_ws_floats() f32 elements */
+/* out[c] = sum_r x[r,c], written, deterministic two-stage sum; cols and ld multiples of 8, 16-byte aligned x; ws: rga3_colsum_ws_floats() f32 elements;
+ * counters (optional: >= 128 32-bit words zeroed once by the caller and kept for the calls of one stream, left zero): both stages run in ONE launch -- the workgroup
+ * that finishes a column block last adds its partial rows, in the same order as the second launch would (bit-identical) */
 int64_t rga3_colsum_ws_floats(int64_t rows, int64_t cols);
-int rga3_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, float* ws, int64_t ws_floats, void* stream);
+int rga3_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, float* ws, int64_t ws_floats, void* counters, void* stream);
 /* kind 0: out = gelu(a); kind 1: out = dy * gelu'(a) (a = pre-activation); kind 2: out = dy * (a > 0) (a = relu output) */
 int rga3_act(const void* a, const void* dy, void* out, int64_t n, int kind, void* stream);
 /* backward of rga3_bilinear (gather form): plane_idx == NULL -> every element of din is written; with plane_idx -> one f32 atomic add per input pixel into

@@ -197,8 +197,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const unsigned 
 // Column sums in two deterministic stages.  Stage 1: a workgroup = CG 16-byte column chunks x RS row lanes walks rows_per_wg rows (four independent
 // loads in flight per thread), folds its row lanes through LDS and writes one partial row part[blockIdx.y][cols].  Stage 2 (colsum_finish_kernel) adds
 // the partial rows in index order.  x [rows, cols] bf16, cols % 8 == 0, 16-byte aligned rows.
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const unsigned short* __restrict__ x, float* __restrict__ part, long rows, int cols, long ld,
-                                                              int CG, int RS, long rows_per_wg) {
+// With `counters` (one word per blockIdx.x, zeroed once by the caller, left zero) the workgroup that finishes LAST for a column block also runs stage 2 for those
+// columns -- same order of additions as colsum_finish_kernel, so the result is bit-identical to the two-launch form -- and no second launch is needed.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const unsigned short* __restrict__ x, float* part, long rows, int cols, long ld,
+                                                              int CG, int RS, long rows_per_wg, unsigned* counters, float* out) {
     __shared__ float red[256 * 8];
     const int t = threadIdx.x;
     const int cg = t % CG, rs = t / CG;
@@ -241,6 +243,37 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const unsigned sho
         const long col = (long)blockIdx.x * CG * 8 + i;
         if (col < cols) part[(long)blockIdx.y * cols + col] = s;
     }
+    if (!counters) return;
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {      // cdna_hip_programming.md Guideline 16: drain, agent-scope release, ticket; the last arrival acquires for the workgroup
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (prev == gridDim.y - 1) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int n = (int)gridDim.y;
+    const int c = t & 31, cl = t >> 5;
+    float* fin = red;                       // [8][32]
+    for (int cb = 0; cb < CG * 8; cb += 32) {
+        const long col = (long)blockIdx.x * CG * 8 + cb + c;
+        float s = 0.f;
+        if (col < cols)
+            for (int i = cl; i < n; i += 8) s += part[(long)i * cols + col];
+        __syncthreads();
+        fin[cl * 32 + c] = s;
+        __syncthreads();
+        if (cl == 0 && col < cols)
+            out[col] = ((fin[c] + fin[32 + c]) + (fin[64 + c] + fin[96 + c])) + ((fin[128 + c] + fin[160 + c]) + (fin[192 + c] + fin[224 + c]));
+    }
+    if (t == 0) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[c] = sum_i part[i][c], i ascending inside each of 8 interleaved lanes, lanes folded in a fixed order.  Columns < split go to out0, the rest to out1
@@ -553,7 +586,7 @@ extern "C" int64_t rga3_colsum_ws_floats(int64_t rows, int64_t cols) {
 }
 
 // out[c] = sum_r x[r, c], written (not accumulated), deterministic; cols % 8 == 0, ld % 8 == 0, x 16-byte aligned; ws: rga3_colsum_ws_floats() f32 elements
-extern "C" int rga3_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, float* ws, int64_t ws_floats, void* stream) {
+extern "C" int rga3_colsum(const void* x, float* out, int64_t rows, int64_t cols, int64_t ld, float* ws, int64_t ws_floats, void* counters, void* stream) {
     RGA3_CHECK_ARG(x && out && ws && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");
     RGA3_CHECK_ARG(cols % 8 == 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0, "colsum: cols / ld multiples of 8 and 16-byte aligned rows (use rga3_colsum_accum otherwise)");
     int CG, RS, nchunk;
@@ -561,8 +594,14 @@ extern "C" int rga3_colsum(const void* x, float* out, int64_t rows, int64_t cols
     colsum_plan(rows, cols, CG, RS, nchunk, rpw);
     RGA3_CHECK_ARG(ws_floats >= (int64_t)nchunk * cols, "colsum: workspace of rga3_colsum_ws_floats() f32 elements needed");
     hipStream_t st = (hipStream_t)stream;
+    if (counters && cdiv(cols / 8, CG) <= 128) {     // both stages in one launch (the last workgroup of a column block finishes it; same order of additions)
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)cdiv(cols / 8, CG), (unsigned)nchunk), dim3(256), 0, st, (cus)x, ws, (long)rows, (int)cols, (long)ld, CG,
+                           RS, rpw, (unsigned*)counters, out);
+        RGA3_CHECK_LAUNCH("colsum_partials<fused finish>");
+        return 0;
+    }
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)cdiv(cols / 8, CG), (unsigned)nchunk), dim3(256), 0, st, (cus)x, ws, (long)rows, (int)cols, (long)ld, CG, RS,
-                       rpw);
+                       rpw, (unsigned*)nullptr, (float*)nullptr);
     RGA3_CHECK_LAUNCH("colsum_partials");
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(cols, 32)), dim3(256), 0, st, (const float*)ws, nchunk, (int)cols, out, out, (int)cols);
     RGA3_CHECK_LAUNCH("colsum_finish");

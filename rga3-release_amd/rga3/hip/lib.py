@@ -80,7 +80,7 @@ SIGNATURES = {
     "rga3_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _p, _i64, _p],
     "rga3_colsum_accum": [_p, _p, _i64, _i64, _i64, _p],
     "rga3_colsum_ws_floats": [_i64, _i64],
-    "rga3_colsum": [_p, _p, _i64, _i64, _i64, _p, _i64, _p],
+    "rga3_colsum": [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _p],
     "rga3_act": [_p, _p, _p, _i64, _i, _p],
     "rga3_bilinear_bwd": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "rga3_mask_product": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],

@@ -181,7 +181,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles < 128 and K >= 1024:      # few output tiles over many tokens: give the kernel room to split K (<= 64 f32 slabs)
         ws = torch.empty((min(64, 256 // tiles, max(2, K // 256)) * M * N,), dtype=torch.float32, device=a.device)
-        cnt = _tn_counters(a.device)   # the slab sum then runs inside the same launch (last workgroup per tile, fixed order)
+        cnt = _tn_counters(a.device)[:128]   # the slab sum then runs inside the same launch (last workgroup per tile, fixed order)
     _lib.check(_lib.load().rga3_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                                              BF16 if out_dtype == torch.bfloat16 else F32, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _ptr(cnt), _stream()),
                "gemm_tn_bf16")
@@ -196,7 +196,7 @@ def _tn_counters(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     t = _tn_cnt.get(key)
     if t is None:
-        t = _tn_cnt[key] = torch.zeros(128, dtype=torch.int32, device=device)
+        t = _tn_cnt[key] = torch.zeros(256, dtype=torch.int32, device=device)     # [0, 128): gemm_tn tiles; [128, 256): colsum column blocks
     return t
 
 
@@ -840,7 +840,7 @@ def colsum(x):
         nws = int(L.rga3_colsum_ws_floats(rows, cols))
         out = torch.empty(cols, dtype=torch.float32, device=x.device)
         ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-        _lib.check(L.rga3_colsum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), ws.data_ptr(), nws, _stream()), "colsum")
+        _lib.check(L.rga3_colsum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), ws.data_ptr(), nws, _tn_counters(x.device)[128:].data_ptr(), _stream()), "colsum")
         return out
     out = torch.zeros(cols, dtype=torch.float32, device=x.device)
     _lib.check(L.rga3_colsum_accum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), _stream()), "colsum_accum")
