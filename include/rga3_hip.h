@@ -201,6 +201,11 @@ int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
                          void* dk, void* dv, float* delta_ws, const int32_t* cu_q, const int32_t* cu_k, int nseg, int max_q,
                          int max_k, int64_t total_q, int Hq, int Hkv, int D, const int64_t* strides16, float scale, int causal,
                          float* dkv_ws, int64_t total_k, void* stream);
+/* Fused MLP of a Hiera stage-1 block, frozen trunk (csrc/hiera_mlp.hip): y [M, 144] = x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 in one launch -- reference
+ * model/sam2.py:1113-1117 (x = x + drop_path(mlp(norm2(x)))), MLP :2305-2329, dims 144 -> 576 -> 144, nn.GELU (erf).  w1f / c1 / d1 are the LayerNorm-folded operands
+ * rga3_gemm_ln_bf16 takes (W1 diag(gamma) in bf16, its row sums in f32, beta W1^T + b1 in bf16); the hidden activation and the row statistics never reach HBM.
+ * x, y contiguous bf16, x != y. */
+int rga3_hiera_mlp144(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, float eps, void* stream);
 /* Token-side tail of the SAM2 mask decoder at inference (csrc/dechead.hip).
  * rga3_mlp3_rows: n (<= 8) three-layer MLPs (Linear+ReLU, Linear+ReLU, Linear [+ sigmoid]) on ONE row per frame, B frames, one launch -- replaces the per-layer calls of
  * reference model/sam2.py:2142-2155 (output_hypernetworks_mlps, iou_prediction_head, pred_obj_score_head; MLP.forward :2319-2329).  HOST arrays:

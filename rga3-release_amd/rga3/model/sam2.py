@@ -34,6 +34,7 @@ from .qwen2_5_vl import Linear
 _DEBUG = None   # set to a dict by tools/grad_locate.py (diagnostic)
 
 
+_MLP_FUSE = True  # stage-1 MLP of the frozen Hiera trunk as one launch (csrc/hiera_mlp.hip); tools/ flip it for A/B runs
 _LN_FOLD = True   # LayerNorm of the frozen Hiera trunk folded into the consuming product (tools/ flip this module attribute for A/B runs; no environment switch)
 
 
@@ -233,7 +234,12 @@ class MultiScaleBlock(nn.Module):
         x = self.attn.proj(att.view(att.shape[0], do), residual=shortcut)
         if self.pool_q:
             H, W, layout_w = H // 2, W // 2, ws // 2
-        if fold and self.dim_out % 8 == 0:
+        l0, l1 = self.mlp.layers[0], self.mlp.layers[1]
+        if (fold and _MLP_FUSE and self.dim_out == 144 and l0.out_features == 576 and self.mlp.num_layers == 2 and self.mlp.act == "gelu" and l0.bias is not None
+                and l1.bias is not None and x.is_contiguous()):
+            # stage-1 MLP (144 -> 576 -> 144 over 65 536 tokens per frame) in one launch: the hidden activation and the LayerNorm statistics never reach HBM
+            x = ops.hiera_mlp144(x, *self._folded("fc1"), l1.weight, l1.bias, self.norm2.eps)
+        elif fold and self.dim_out % 8 == 0:
             hmid = ops.gemm_ln(x, ops.layernorm_stats(x, self.norm2.eps), *self._folded("fc1"), act="gelu")
             x = self.mlp.layers[1](hmid, residual=x)
         else:

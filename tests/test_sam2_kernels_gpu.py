@@ -294,3 +294,30 @@ def test_fused_decoder_heads_and_selection(dev):
     ref = torch.where(obj.float() > 0, x, no_obj.float()[None])
     assert rel(ptr, ref) < 6e-3
     assert torch.equal(ptr[1].cpu(), no_obj) and torch.equal(ptr[2].cpu(), no_obj)
+
+
+@pytest.mark.parametrize("M", [65536, 1000, 256 * 3 + 17])
+def test_hiera_stage1_mlp_fused(dev, M):
+    """csrc/hiera_mlp.hip: x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 (144 -> 576 -> 144) in one launch against fp32 torch (LayerNorm eps 1e-6, exact-erf GELU) on the same
+    bf16 operands, and against the unfused pair it replaces (rga3_layernorm_stats + rga3_gemm_ln_bf16 + rga3_gemm_bf16) -- a full frame's 65 536 tokens and ragged row
+    counts (a partial last 256-token workgroup, a partial last 32-token wave)."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, 144, generator=g) * 1.5 + 0.3 * torch.randn(M, 1, generator=g)).to(torch.bfloat16)
+    w1 = (torch.randn(576, 144, generator=g) * 0.08).to(torch.bfloat16)
+    b1 = (torch.randn(576, generator=g) * 0.1).to(torch.bfloat16)
+    w2 = (torch.randn(144, 576, generator=g) * 0.05).to(torch.bfloat16)
+    b2 = (torch.randn(144, generator=g) * 0.1).to(torch.bfloat16)
+    gamma = (1 + 0.2 * torch.randn(144, generator=g)).to(torch.bfloat16)
+    beta = (0.1 * torch.randn(144, generator=g)).to(torch.bfloat16)
+    xd = x.to(dev)
+    wf, colc, biasf = ops.fold_layernorm(w1.to(dev), b1.to(dev), gamma.to(dev), beta.to(dev))
+    y = ops.hiera_mlp144(xd, wf, colc, biasf, w2.to(dev), b2.to(dev), 1e-6)
+    xf = x.float()
+    ref = xf + F.linear(F.gelu(F.linear(F.layer_norm(xf, (144,), gamma.float(), beta.float(), 1e-6), w1.float(), b1.float())), w2.float(), b2.float())
+    assert rel(y, ref) < 1e-2, rel(y, ref)
+    hmid = ops.gemm_ln(xd, ops.layernorm_stats(xd, 1e-6), wf, colc, biasf, act="gelu")
+    y2 = ops.gemm(hmid, w2.to(dev), b2.to(dev), residual=xd)
+    assert rel(y, y2) < 4e-3, rel(y, y2)
+    assert torch.equal(y, ops.hiera_mlp144(xd, wf, colc, biasf, w2.to(dev), b2.to(dev), 1e-6))
