@@ -178,7 +178,7 @@ def gemm_ln(a, stats, wf, colc, biasf, act: str = "none", out=None, tile: int = 
     return out
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None) -> torch.Tensor:
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None, fused_sum: bool = False) -> torch.Tensor:
     """out [M, N] = a^T @ b for a [K, M], b [K, N] bf16 (row stride free): dW = dY^T X without transposing either operand."""
     _need_cuda(a, b, out)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0]
@@ -194,7 +194,10 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles < 128 and K >= 1024:      # few output tiles over many tokens: give the kernel room to split K (<= 64 f32 slabs)
         ws = torch.empty((min(64, 256 // tiles, max(2, K // 256)) * M * N,), dtype=torch.float32, device=a.device)
-        cnt = _tn_counters(a.device)[:128]   # the slab sum then runs inside the same launch (last workgroup per tile, fixed order)
+        if fused_sum:
+            cnt = _tn_counters(a.device)[:128]
+        # (cnt stays None by default: the in-launch slab sum -- last workgroup per tile, rga3_gemm_tn_bf16's `counters` -- was measured 3x SLOWER than the second launch it saves:
+        #  one workgroup per tile adds Z x 64 KiB behind two agent-scope fences while the chip idles; DESIGN.md 4, rejected list)
     _lib.check(_lib.load().rga3_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                                              BF16 if out_dtype == torch.bfloat16 else F32, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _ptr(cnt), _stream()),
                "gemm_tn_bf16")
@@ -843,7 +846,7 @@ def layernorm_bwd(x, weight, dy, eps: float, want_param_grads=True):
     return dx, dw, db
 
 
-def colsum(x):
+def colsum(x, fused_finish: bool = False):
     """f32 column sums of a bf16 [rows, cols] tensor (row stride free)."""
     _need_cuda(x)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
@@ -853,7 +856,8 @@ def colsum(x):
         nws = int(L.rga3_colsum_ws_floats(rows, cols))
         out = torch.empty(cols, dtype=torch.float32, device=x.device)
         ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-        _lib.check(L.rga3_colsum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), ws.data_ptr(), nws, _tn_counters(x.device)[128:].data_ptr(), _stream()), "colsum")
+        _lib.check(L.rga3_colsum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), ws.data_ptr(), nws,
+                                 _tn_counters(x.device)[128:].data_ptr() if fused_finish else None, _stream()), "colsum")   # default two launches: the fused finish lost
         return out
     out = torch.zeros(cols, dtype=torch.float32, device=x.device)
     _lib.check(L.rga3_colsum_accum(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0), _stream()), "colsum_accum")

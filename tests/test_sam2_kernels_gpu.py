@@ -321,3 +321,21 @@ def test_hiera_stage1_mlp_fused(dev, M):
     y2 = ops.gemm(hmid, w2.to(dev), b2.to(dev), residual=xd)
     assert rel(y, y2) < 4e-3, rel(y, y2)
     assert torch.equal(y, ops.hiera_mlp144(xd, wf, colc, biasf, w2.to(dev), b2.to(dev), 1e-6))
+
+
+def test_in_launch_reductions_equal_two_launch_forms(dev):
+    """The optional `counters` forms of rga3_gemm_tn_bf16 (K-slice sum by the last workgroup of a tile) and rga3_colsum (second stage by the last workgroup of a column
+    block) add in the same order as their second launches: bit-identical results, run after run.  (They are NOT the default: measured slower)"""
+    from rga3.hip import ops
+
+    for (K, M, N) in ((65536, 128, 256), (2112, 128, 3584), (4160, 512, 128)):
+        a, b = rnd((K, M), dev, 0.5, K), rnd((K, N), dev, 0.5, K + 1)
+        ref = ops.gemm_tn(a, b)
+        for _ in range(3):
+            assert torch.equal(ops.gemm_tn(a, b, fused_sum=True), ref), (K, M, N)
+        assert torch.equal(ops.gemm_tn(a, b, out_dtype=torch.float32, fused_sum=True), ops.gemm_tn(a, b, out_dtype=torch.float32))
+    for (rows, cols) in ((65536, 256), (144, 256), (1048576, 32), (4096, 2048)):
+        x = rnd((rows, cols), dev, 1.0, rows)
+        ref = ops.colsum(x)
+        for _ in range(3):
+            assert torch.equal(ops.colsum(x, fused_finish=True), ref), (rows, cols)
