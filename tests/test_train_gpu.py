@@ -572,3 +572,30 @@ def test_bucket_layout_optimizer_equals_per_tensor(dev):
     for a, b in zip(res[0][0] + res[0][1] + res[0][2], res[1][0] + res[1][1] + res[1][2]):
         assert torch.equal(a, b)
     assert abs(res[0][3] - res[1][3]) <= 1e-5 * res[0][3]
+
+
+def test_gemm_health_watch_polls_without_sync_and_reports_a_give_up(dev):
+    """rga3.hip.ops.GemmHealthWatch (polled by FusedAdamW.step): the give-up counter of every GEMM workspace is fetched by a non-blocking copy and examined one round later
+    -- no synchronising call in poll() -- and a non-zero counter raises (and re-arms the flag words)."""
+    from rga3.hip import lib, ops
+
+    a, w = rnd((2112, 3584), dev, 0.1, 1), rnd((3584, 3584), dev, 0.1, 2)
+    ops.gemm(a, w, tile=22)                      # a stream-K launch: the workspace of this stream exists
+    watch = ops.GemmHealthWatch(every=1)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        watch.poll()
+        ops.gemm(a, w, tile=22)
+        watch.poll()                             # examines the first fetch (zero), issues the second
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    ws = ops.gemm_workspace(a.device)
+    off = int(lib.load().rga3_gemm_timeout_counter_offset())
+    assert off > 0 and ops.gemm_stream_k_timeouts(a.device) == 0
+    ws[off:off + 4].view(torch.int32).fill_(3)   # what a hand-off that gave up three times leaves behind
+    watch.poll()                                 # examines the second fetch (still zero), fetches the 3
+    with pytest.raises(lib.Rga3Error, match="timed out 3"):
+        watch.poll()
+    ws[off:off + 4].view(torch.int32).zero_()
+    assert ops.gemm_stream_k_timeouts(a.device) == 0
