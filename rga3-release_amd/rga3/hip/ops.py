@@ -235,6 +235,8 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
     # few query blocks x heads over a long key range (SAM2 memory attention: one head, 4096 queries, <= 28 736 keys): hand the kernel a
     # workspace so it can split the keys over up to 8 workgroups per query block
     bq, bk = (int(block[0]), int(block[1])) if block else (0, 0)   # block-diagonal visibility inside a segment: (query block, key block), powers of two
+    if not max_k and cu_k is cu_q:      # self-attention over the same packing: the longest key segment is the longest query segment (no read-back)
+        max_k = int(max_q)
     split_ws = None
     if not causal and ((int(max_q) + 63) // 64) * Hq * nseg < 128 and k.shape[0] >= 1024 and D % 4 == 0:
         if not max_k:    # longest key segment: known to most callers (max_k); reading it back from cu_k is a device -> host sync
