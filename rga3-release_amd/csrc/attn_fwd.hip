@@ -16,7 +16,6 @@
 //  * K/V tiles are register-staged (global_load 16 B -> ds_write_b128) one tile ahead, into rows padded by
 //    32 B so that both the b128 K reads and the transposed V reads are bank-conflict-free.
 #include "common.h"
-#include "attn32.h"
 #include <type_traits>
 
 namespace rga3 {
@@ -786,15 +785,6 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
         // (4 waves x 32 rows per 256-token window -- half the fragment reads per row, one wave fewer per SIMD -- measured slower: 129 vs 112 us)
         if (max_q <= 64) return (D <= 64) ? launch_win<64, 4, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 4, 1>(a, nseg, max_q, max_k, st);
         return (D <= 64) ? launch_win<64, 8, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 8, 1>(a, nseg, max_q, max_k, st);
-    }
-    // long non-causal rows at head dims 33 .. 96 (Hiera-L global attention, the ViT's full-attention blocks): 32 query rows per wave on 32x32x16 MFMAs (attn32.hip)
-    if (impl == 0 && g_attn_variant == 0 && a.nsplit == 1 && block_q == 0 && attn32_applies(D, causal, max_q, max_k) &&
-        (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0) {
-        Attn32Args b;
-        b.q = a.q; b.k = a.k; b.v = a.v; b.o = a.o; b.lse = a.lse; b.cu_q = a.cu_q; b.cu_k = a.cu_k;
-        b.q_st = q_st; b.q_sh = q_sh; b.k_st = k_st; b.k_sh = k_sh; b.v_st = v_st; b.v_sh = v_sh; b.o_st = o_st; b.o_sh = o_sh;
-        b.total_q = total_q; b.Hq = Hq; b.Hkv = Hkv; b.D = D; b.scale_log2 = a.scale_log2; b.gx = 1;
-        return attn32_launch(b, nseg, max_q, st);
     }
     if (impl == 0) return launch_any<true>(a, nseg, max_q, st);
     return launch_any<false>(a, nseg, max_q, st);

@@ -165,11 +165,11 @@ ATTN_CASES = [
     ([1024], [7000], 1, 1, 256, False),           # memory attention over a grown bank: key range split over workgroups
     ([100, 700], [3000, 1200], 2, 2, 64, False),  # split-KV with ragged segments (second segment shorter than a slice set)
     ([640, 129, 1000], None, 6, 2, 128, True),    # paired causal q-blocks, ragged tails, GQA
-    ([4096], None, 8, 8, 72, False),              # Hiera-L global attention: the 32-row kernel (attn32.hip), head dim padded 72 -> 80 / 96 in LDS only
-    ([1024, 1024, 700, 300], None, 4, 2, 80, False),   # attn32: ragged segments (a partial 256-row block, a partial last key tile), GQA
-    ([512, 256], None, 2, 2, 96, False),          # attn32: D = 96 (6 k-steps, no padding)
-    ([600], None, 2, 2, 40, False),               # attn32: D = 40 (3 k-steps, 2 output row blocks)
-    ([2048], None, 2, 1, 64, False),              # attn32: D = 64, two query heads on one kv head
+    ([4096], None, 8, 8, 72, False),              # Hiera-L global attention at full length
+    ([1024, 1024, 700, 300], None, 4, 2, 80, False),   # long ragged segments, GQA, head dim 80
+    ([512, 256], None, 2, 2, 96, False),          # head dim 96
+    ([600], None, 2, 2, 40, False),               # head dim 40
+    ([2048], None, 2, 1, 64, False),              # head dim 64, two query heads on one kv head
     ([200], [457], 3, 3, 64, True),               # ... causal with Lk > Lq, one unpaired block pair
     ([333, 128], None, 2, 2, 96, False),          # ... head dim 96, non-causal, ragged
     ([130], [64], 2, 1, 32, False),               # ... a single key tile, D = 32 (padded to 64)

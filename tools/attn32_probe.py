@@ -24,4 +24,7 @@ for name, nseg, L, H, D in (("hiera global x8 frames", 8, 4096, 8, 72), ("vit fu
     err = ((a.float() - c.float()).norm() / c.float().norm()).item()
     t_new = t(lambda: ops.attn_varlen(q, k, v, cu, cu, L, D ** -0.5, max_k=L))
     t_old = t(lambda: ops.attn_varlen(q, k, v, cu, cu, L, D ** -0.5, impl=2, max_k=L))
+    cu2 = cu.clone()        # distinct cu objects and no max_k: the dispatcher cannot know the key range -> the round-2 production route (8 waves x 2 x 16 rows)
+    t_prod = t(lambda: ops.attn_varlen(q, k, v, cu, cu2, L, D ** -0.5))
+    print(f"   round-2 production route: {t_prod:.3f} ms = {fl / t_prod / 1e9:.0f} TFLOP/s")
     print(f"{name}: attn32 {t_new:.3f} ms = {fl / t_new / 1e9:.0f} TFLOP/s   16-row {t_old:.3f} ms = {fl / t_old / 1e9:.0f} TFLOP/s   rel diff {err:.2e}", flush=True)
