@@ -152,16 +152,20 @@ __global__ __launch_bounds__(512) void hiera_mlp144_kernel(HmArgs p) {
         const char* w1s = smem + buf * HM_STAGE;
         const char* w2s = w1s + HM_W1B;
         const float* cs = (const float*)(w2s + HM_W2B);      // [64] c, then [64] d
-        // ---- H^T chunk = W1' X^T, LayerNorm fold, GELU, bf16: the B operand of the second product
-        bf16x8 gb[2][2];
+        // ---- H^T chunk = W1' X^T for both 32-hidden blocks first (18 MFMAs back to back), then per block: LayerNorm fold + GELU + bf16 (vector ALU) followed by its
+        //      share of Y^T += W2 chunk . G^T (10 MFMAs) -- block 1's GELU has no dependence on block 0's MFMAs, so the two pipes can overlap
+        f32x16 acc[2];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-            f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[hb][i] = 0.f;
             const char* a0 = w1s + (hb * 32 + r) * HM_W1STR + h * 16;
 #pragma unroll
-            for (int ks = 0; ks < HM_KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(a0 + ks * 32), xf[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < HM_KS; ++ks) acc[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(a0 + ks * 32), xf[ks], acc[hb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            bf16x8 gb[2];
             float g[16];
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
@@ -169,9 +173,8 @@ __global__ __launch_bounds__(512) void hiera_mlp144_kernel(HmArgs p) {
                 const f32x4 dd = *(const f32x4*)(cs + HM_HC + hb * 32 + 8 * i4 + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = rinv * (acc[4 * i4 + e] - mean * cc[e]) + dd[e];
-                    v = hm_gelu_erf(bf2f(f2bf(v)));      // bf16 rounding of the linear output before the activation, as the unfused pair does
-                    g[4 * i4 + e] = v;
+                    float v = rinv * (acc[hb][4 * i4 + e] - mean * cc[e]) + dd[e];
+                    g[4 * i4 + e] = hm_gelu_erf(bf2f(f2bf(v)));      // bf16 rounding of the linear output before the activation, as the unfused pair does
                 }
             }
 #pragma unroll
@@ -181,22 +184,20 @@ __global__ __launch_bounds__(512) void hiera_mlp144_kernel(HmArgs p) {
                 pk[1] = pack_bf2(g[8 * ss + 2], g[8 * ss + 3]);
                 pk[2] = pack_bf2(g[8 * ss + 4], g[8 * ss + 5]);
                 pk[3] = pack_bf2(g[8 * ss + 6], g[8 * ss + 7]);
-                gb[hb][ss] = __builtin_bit_cast(bf16x8, pk);
+                gb[ss] = __builtin_bit_cast(bf16x8, pk);
             }
-        }
-        // ---- Y^T += W2 chunk . G^T: fragment element j of half h is hidden 16 ss + 8 (j >> 2) + 4 h + (j & 3) of block hb
+            // Y^T += W2 chunk . G^T: fragment element j of half h is hidden 16 ss + 8 (j >> 2) + 4 h + (j & 3) of block hb
 #pragma unroll
-        for (int cb = 0; cb < HM_CB; ++cb) {
-            const char* a0 = w2s + (cb * 32 + r) * HM_W2STR + 8 * h;
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
+            for (int cb = 0; cb < HM_CB; ++cb) {
+                const char* a0 = w2s + (cb * 32 + r) * HM_W2STR + 8 * h + hb * 64;
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {
-                    const char* a = a0 + (hb * 32 + 16 * ss) * 2;
+                    const char* a = a0 + 32 * ss;
                     const u32x2 lo = *(const u32x2*)a, hi = *(const u32x2*)(a + 16);
                     const u32x4 af = {lo[0], lo[1], hi[0], hi[1]};
-                    y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), gb[hb][ss], y[cb], 0, 0, 0);
+                    y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), gb[ss], y[cb], 0, 0, 0);
                 }
+            }
         }
         if (ch + 1 < NCH) store_chunk(buf ^ 1);
         __syncthreads();
