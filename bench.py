@@ -125,6 +125,11 @@ class BatchFeed:
                     n_video, grid = (first["input_ids"].shape[1] - 64, tuple(int(v) for v in first["video_grid_thw"][0]))
                     self.pool.append(dict(first, pixel_values_videos=make_inputs(cfg, dev, seed=rank + 7919 * i, n_video=n_video, grid=grid)["pixel_values_videos"]))
 
+    def peek_pixels(self):
+        """Pixel tensors of the sample the NEXT call of next() will return (for model.prefetch_vision)."""
+        big = self.pool[self.j % len(self.pool)] if self.mode == "fresh" else self.first
+        return {k: big[k] for k in ("pixel_values_videos", "video_grid_thw") if k in big}
+
     def next(self):
         j, self.j = self.j, self.j + 1
         if self.mode != "fresh":
@@ -691,6 +696,7 @@ def main():
     ap.add_argument("--refine", action="store_true", help="training modes, 1 GPU: run the in-situ tile refinement before the warmup")
     ap.add_argument("--dense-embed-grad", action="store_true", help="exchange embed_tokens' gradient as a dense bucket (A/B of the sparse row exchange)")
     ap.add_argument("--sam-frames", type=int, default=16)
+    ap.add_argument("--no-prefetch", action="store_true", help="training modes: do not run the frozen vision tower of the next sample one step ahead on a side stream (A/B)")
     ap.add_argument("--batches", choices=["fresh", "repeat"], default="fresh",
                     help="training modes: fresh = a new sample (new tensor objects, new token ids, [SEG] position, pixel tensors from a resident pool of 4) every step, as a "
                          "training loop feeds it; repeat = the same tensor objects every step with the host plan reused (round 2's measurement)")
@@ -790,14 +796,21 @@ def main():
         set_fp8_frozen_gemms(True)
     losses = []
     feed = BatchFeed(args.batches, cfg, dev, rank, inputs, "full" if full else "llm", sam_frames=args.sam_frames)
+    prefetch = not args.no_prefetch and args.batches == "fresh"
     model.reuse_host_plan(args.batches == "repeat")
 
     def step(sync=True):
         reducer.begin_step()
         for mi in range(accum):   # gradient accumulation: gradients are exchanged once per optimizer step (DDP no_sync)
             reducer.begin_micro_step()
-            out = model(**feed.next())
+            cur = feed.next()
+            pf = prefetch and feed.mode == "fresh"
+            if pf and full:      # the next sample's pixels are announced; the model launches its frozen ViT on a side stream where this step's mask path begins
+                model.prefetch_next(**feed.peek_pixels())
+            out = model(**cur)
             loss = out["loss"] if isinstance(out, dict) else out.loss
+            if pf and not full:  # no mask path in this mode: behind the forward, beside the backward / optimizer
+                model.prefetch_vision(**feed.peek_pixels())
             if mi + 1 < accum or not sync:
                 with reducer.no_sync():
                     (loss / accum).backward()
@@ -892,6 +905,10 @@ def main():
             return round((time.perf_counter() - t0) / nv * 1e3, 3)
 
         variants = {"steps_each": nv}
+        if prefetch:      # the same fresh-batch step with the next sample's frozen ViT computed inside its own forward instead of one step ahead on a side stream
+            prefetch = False
+            variants["fresh_batch_no_vision_prefetch_ms"] = timed()
+            prefetch = True
         if args.batches == "fresh":
             feed.mode = "repeat"
             model.reuse_host_plan(True)
@@ -945,7 +962,7 @@ def main():
                                        "AdamW -- are not streamed), bucketed RCCL all-reduce (embed_tokens rows exchanged sparsely); 16 frames 448x448, S=2112, 1 sample/GPU" +
                                        (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)" if full else ""),
                            "per_gpu_batch": 1, "seq_len": 2112, "parallelism": f"dp{world}", "trainable_params": n_train, "flops_per_sample": fl,
-                           "batches": args.batches, "adamw_embed_rows_updated": rows_updated, "variants": variants},
+                           "batches": args.batches, "vision_prefetch": bool(prefetch), "adamw_embed_rows_updated": rows_updated, "variants": variants},
                 "roofline": fwd_roof if fwd_roof is not None else rfb, "roofline_fwd_bwd": rfb,
                 "verify": dict(fwd_verify or {}, loss_first_last=[round(float(lv[0]), 5), round(float(lv[-1]), 5)]),
                 "comm": comm, "cpu_baseline": cpu}

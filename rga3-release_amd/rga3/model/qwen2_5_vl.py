@@ -593,8 +593,10 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
             # a frozen tower with constant pixels needs no graph: under no_grad the windowed blocks take the attention kernel that rotates q / k while loading
             # (no stand-alone rope pass) -- the reference freezes the vision tower during RGA3 training (train_joint.py:193-251 trains LoRA, heads, mask decoder)
             frozen = not px.requires_grad and not any(p_.requires_grad for p_ in self.visual.parameters())
-            with torch.no_grad() if frozen else contextlib.nullcontext():
-                emb = self.visual(px, _np(grid))
+            emb = self._prefetched_vision(px, grid) if frozen else None
+            if emb is None:
+                with torch.no_grad() if frozen else contextlib.nullcontext():
+                    emb = self.visual(px, _np(grid))
             key = ("where", tok)
             if key not in pl:
                 where = np.flatnonzero(ids_packed_np == tok)
@@ -604,6 +606,43 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
                 raise ValueError(f"vision features and placeholder tokens do not match: tokens {n_where}, features {emb.shape[0]}")
             ops.scatter_rows_(x, where_dev, emb)
         return x
+
+    # -- frozen vision tower, one step ahead ------------------------------------------------------------------------------
+    def prefetch_vision(self, pixel_values=None, image_grid_thw=None, pixel_values_videos=None, video_grid_thw=None, **_):
+        """Run the FROZEN vision tower on the NEXT batch's pixels now, on a side stream, and keep the result for the forward that receives these same tensors.
+        The tower does not depend on anything the optimizer updates (the reference freezes it, train_joint.py:190-191), so a trainer that already holds the next
+        batch (DataLoader prefetch) can enqueue it behind the current forward: it then fills the CUs that the launch-bound mask-path backward and the HBM-bound
+        optimizer leave idle.  Optional: a forward without a matching prefetch computes the features itself; results are bit-identical either way (same kernels)."""
+        if any(p_.requires_grad for p_ in self.visual.parameters()):
+            return
+        st = self.__dict__.get("_pf_stream")
+        if st is None:
+            st = self.__dict__["_pf_stream"] = torch.cuda.Stream(device=self.device)
+        cache = self.__dict__.setdefault("_pf_cache", {})
+        cache.clear()
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                     # the pixels (and everything queued so far) come first
+        for px, grid in ((pixel_values, image_grid_thw), (pixel_values_videos, video_grid_thw)):
+            if px is None or px.requires_grad:
+                continue
+            with torch.cuda.stream(st), torch.no_grad():
+                st.wait_event(ready)
+                emb = self.visual(px, _np(grid))
+                done = torch.cuda.Event()
+                done.record(st)
+            cache[px.data_ptr()] = ((px._version, tuple(px.shape), px.dtype), px, emb, done)     # holds px: its address cannot be recycled while the entry lives
+
+    def _prefetched_vision(self, px, grid):
+        cache = self.__dict__.get("_pf_cache")
+        hit = cache.pop(px.data_ptr(), None) if cache else None
+        if hit is None or hit[0] != (px._version, tuple(px.shape), px.dtype):
+            return None
+        _, _, emb, done = hit
+        cur = torch.cuda.current_stream(px.device)
+        cur.wait_event(done)
+        emb.record_stream(cur)                # allocated on the side stream, consumed (and later freed) on this one
+        return emb
 
     def reuse_host_plan(self, on: bool = True):
         """Opt in to keeping the host plan of the last forward for as long as the SAME unmodified tensor objects come back (an evaluation loop over a fixed

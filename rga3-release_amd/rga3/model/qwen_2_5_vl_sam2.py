@@ -131,6 +131,17 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
             return super().forward(**kwargs)
         return self.model_forward(**kwargs)
 
+    def prefetch_next(self, **next_batch):
+        """Tell the model which batch comes NEXT (its pixel tensors: `pixel_values_videos` / `video_grid_thw`, `pixel_values` / `image_grid_thw`).  The training
+        forward then launches the frozen vision tower for it on a side stream right after this step's SAM2 image encoder -- where the launch-bound mask path begins and
+        most CUs fall idle (Qwen2_5_VLForConditionalGeneration.prefetch_vision).  Optional; a forward without it computes the features itself, bit-identically."""
+        self.__dict__["_next_pixels"] = {k: next_batch.get(k) for k in ("pixel_values", "image_grid_thw", "pixel_values_videos", "video_grid_thw")}
+
+    def _launch_prefetch(self):
+        nxt = self.__dict__.pop("_next_pixels", None)
+        if nxt is not None:
+            self.prefetch_vision(**nxt)
+
     # ---- helpers ------------------------------------------------------------------------------------------
     def _seg_embeddings(self, hidden_last: torch.Tensor, seg_token_mask_np: np.ndarray, pl=None):
         """text_hidden_fcs on the gathered rows (value-identical to MLP-then-gather, reference :215-218)."""
@@ -207,6 +218,7 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
             e = sample_embedding(i)
             assert e.shape[0] == 1, "one [SEG] per sample on the training path (reference sam2.py:3356 assert)"
             st = gm.get_sam2_embeddings_train(images_sam[i])
+            self._launch_prefetch()      # next batch's frozen ViT (if the trainer announced it) goes out beside the mask decoder / its backward
             _, high = gm.inject_language_embd_train(st, e[None].expand(num_frames_sam, -1, -1))
             grad = torch.is_grad_enabled()
             pred = AG.BilinearFn.apply(high[:, 0].contiguous(), tuple(label_list[i].shape), None) if grad else ops.bilinear(high[:, 0].contiguous(), tuple(label_list[i].shape))
@@ -219,6 +231,7 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
                 mask_bce_loss = mask_bce_loss + sigmoid_ce_loss(pred, gt_mask.to(device), num_masks=n) * n
                 mask_dice_loss = mask_dice_loss + dice_loss(pred, gt_mask.to(device), num_masks=n) * n
             num_masks += n
+        self._launch_prefetch()          # (a batch without [SEG]: no SAM2 pass happened above)
         mask_bce_loss = self.config.bce_loss_weight * mask_bce_loss / (num_masks + 1e-8)
         mask_dice_loss = self.config.dice_loss_weight * mask_dice_loss / (num_masks + 1e-8)
         mask_loss = mask_bce_loss + mask_dice_loss

@@ -393,3 +393,33 @@ def test_two_optimizer_steps_h1(dev, G):
             cos = float((d * ref).sum() / (np.linalg.norm(d) * np.linalg.norm(ref) + 1e-30))
             assert cos > (0.9 if step == 0 else 0.8), (n, step, cos)
     red.remove()
+
+
+def test_vision_prefetch_is_bit_identical_and_optional(model, dev, G):
+    """UniGRModel.prefetch_next / Qwen2_5_VLForConditionalGeneration.prefetch_vision: the frozen vision tower of a batch computed AHEAD on a side stream gives the same
+    bits as computing it inside the forward; an entry is used once, only for the very tensor it was computed from (a different tensor, or the same tensor after a write,
+    misses and the forward computes the features itself)."""
+    b = to_dev(make_batch(CASES["10"], seed=3), dev)
+    for p in model.visual.parameters():      # the prefetch is for the FROZEN tower (reference train_joint.py:190-191)
+        p.requires_grad_(False)
+    with torch.no_grad():
+        ref = model(**b, inference=False)
+        model.prefetch_vision(pixel_values_videos=b["pixel_values_videos"], video_grid_thw=b["video_grid_thw"])
+        assert len(model.__dict__["_pf_cache"]) == 1
+        out = model(**b, inference=False)
+        assert len(model.__dict__["_pf_cache"]) == 0                      # consumed
+        for k in ref:
+            assert torch.equal(ref[k], out[k]), k
+        # announced through prefetch_next: launched inside the training forward, consumed by the NEXT forward of the same tensors
+        model.prefetch_next(pixel_values_videos=b["pixel_values_videos"], video_grid_thw=b["video_grid_thw"])
+        out1 = model(**b, inference=False)
+        assert len(model.__dict__["_pf_cache"]) == 1 and "_next_pixels" not in model.__dict__
+        out2 = model(**b, inference=False)
+        for k in ref:
+            assert torch.equal(ref[k], out1[k]) and torch.equal(ref[k], out2[k]), k
+        # a stale entry (the tensor was written after the prefetch) is not used
+        model.prefetch_vision(pixel_values_videos=b["pixel_values_videos"], video_grid_thw=b["video_grid_thw"])
+        b["pixel_values_videos"].mul_(1.0)
+        out3 = model(**b, inference=False)
+        for k in ref:
+            assert torch.equal(ref[k], out3[k]), k
