@@ -875,10 +875,12 @@ def main():
     # ---- GEMM-family instrumented pass over the same step (rank 0)
     roof_tr = None
     if rank == 0 and world == 1 and not timed_only:
+        pf_saved, prefetch = prefetch, False      # the per-launch GEMM timings are taken without the side-stream ViT running beside them (events would time the overlap)
         with GemmTimer(ops) as gt:
             for _ in range(max(2, args.steps // 2)):
                 step()
             tot_ms = gt.total_ms()
+        prefetch = pf_saved
         nst = max(2, args.steps // 2)
         g_ms = tot_ms / nst
         roof_tr = {"launches_per_step": len(gt.ev) // nst, "gemm_ms_per_step": round(g_ms, 3), "gemm_flops_per_step": gt.flops / nst,
