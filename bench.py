@@ -470,8 +470,11 @@ def sam2_stream(args, dev, rank, world, dist):
     prompt on frame 0 only, then propagate (memory attention over the growing bank, mask decoder, memory encoder per frame).
     `value` counts the stream with the per-frame image features already computed ("memory-attention mask-decoder only"); the
     encoder-inclusive rate is reported beside it."""
+    from rga3.model import sam2 as sam2_mod
     from rga3.model.sam2 import SAM2, VideoSession
 
+    if args.no_rowchain:
+        sam2_mod._ROWCHAIN = False      # A/B: the row-wise steps of the memory-attention layers as separate launches
     T = args.stream_frames
     torch.manual_seed(1)
     m = SAM2().to(torch.bfloat16).to(dev).eval()
@@ -536,10 +539,10 @@ def sam2_stream(args, dev, rank, world, dist):
         from rga3.hip import ops as _ops
         real, evs, acc = _ops.memattn_cross, [], [0.0, 0.0]
 
-        def timed(q, k, mm, scale, nsplit=0):
+        def timed(q, k, mm, scale, nsplit=0, **kw):
             s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s_.record()
-            r_ = real(q, k, mm, scale, nsplit)
+            r_ = real(q, k, mm, scale, nsplit, **kw)
             e_.record()
             evs.append((s_, e_))
             acc[0] += 2.0 * q.shape[0] * k.shape[0] * (256 + 64)                               # QK^T over 256 + PM over 64
@@ -555,7 +558,8 @@ def sam2_stream(args, dev, rank, world, dist):
         tot = sum(a.elapsed_time(b) for a, b in evs)
         n = len(evs)
         tr, src = _traffic("sam2_stream", "memattn")
-        dom = {"bound": "mfma", "kernel": "memattn_cross_kernel + memattn_combine_kernel (csrc/memattn.hip: 32x32x16 bf16 MFMA, values kept in the 64-wide memory space)",
+        dom = {"bound": "mfma", "kernel": ("memattn_cross_kernel + memattn_combine_kernel" if args.no_rowchain else "memattn_cross_kernel (its key slices are merged by the consumer, memlayer_rows_kernel)")
+               + " (csrc/memattn.hip: 32x32x16 bf16 MFMA, values kept in the 64-wide memory space)",
                "launches_per_stream": n, "avg_launch_ms": round(tot / max(n, 1), 5), "achieved": round(acc[0] / (tot * 1e-3) / 1e12, 1), "peak": PEAK_BF16 / 1e12,
                "unit": "TFLOP/s", "frac": round(acc[0] / (tot * 1e-3) / PEAK_BF16, 4), "algorithmic_flops_per_launch": acc[0] / max(n, 1),
                "algorithmic_bytes_per_launch": acc[1] / max(n, 1), "traffic": tr, "traffic_source": src,
@@ -691,6 +695,7 @@ def main():
     ap.add_argument("--stream-frames", type=int, default=32)
     ap.add_argument("--grad-accum", type=int, default=4)
     ap.add_argument("--no-fp8", action="store_true", help="lora_fp8 mode with bf16 GEMMs (A/B)")
+    ap.add_argument("--no-rowchain", action="store_true", help="sam2_stream mode: A/B of csrc/memlayer.hip (the row-wise steps between the attention kernels as separate launches)")
     ap.add_argument("--no-graph", action="store_true", help="sam2_stream mode: run every frame eagerly (A/B of the hipGraph replay)")
     ap.add_argument("--no-refine", action="store_true", help="skip the in-situ tile refinement of the forward leg (A/B)")
     ap.add_argument("--refine", action="store_true", help="training modes, 1 GPU: run the in-situ tile refinement before the warmup")

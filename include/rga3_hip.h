@@ -47,8 +47,9 @@ int rga3_last_error(char* buf, size_t n);
  * :1383 (lm_head); reference model/qwen_2_5_vl_sam2.py:131-137 (text_hidden_fcs), model/sam2.py:986-1117
  * (Hiera qkv/proj/mlp), :857-889 (FPN 1x1), :1417-1481 (decoder attention projections).
  * colscale [N_out] is the ConvNeXt layer scale of reference model/sam2.py:690-703.
- * K, lda, ldw must be multiples of 8 (16-byte rows); tile = -1 lets the library choose (M <= 4 rows: the weight-stream kernel, 40).
- * Explicit tilings (all give the same bits except 22 / 32 / 25 / 14 / 40, whose K splits / lane-strided sums change the f32 summation order,
+ * K, lda, ldw must be multiples of 8 (16-byte rows); tile = -1 lets the library choose (M <= 4 rows: the weight-stream kernel, 40; 5 - 16 rows: the token-row
+ * kernel, 41).
+ * Explicit tilings (all give the same bits except 22 / 32 / 25 / 14 / 40 / 41, whose K splits / lane-strided sums change the f32 summation order,
  * reproducibly):
  *   20 = 256x256 ping-pong, one tile per workgroup;  21 = the same, persistent (one workgroup per CU);
  *   22 = persistent + stream-K tail (needs the caller workspace below);  31 / 32 = 21 / 22 with 192x256 tiles (M = 2112 = 11 x 192);
@@ -56,7 +57,9 @@ int rga3_last_error(char* buf, size_t n);
  *   11, 12 / 3 / 4 / 5 / 13 = single-phase 128x128 / 128x256 / 128x320 / 128x192 / 64x64;  10 = single-phase 256x256 (first generation, A/B);
  *   14 = 64x64 with K cut into up to 32 slices (skinny plain products such as LoRA's x A^T: N = 128 over K = 3584; same workspace; runs as 13
  *        when there is a bias / activation / residual);
- *   40 = skinny weight-stream kernel for M <= 4 (the decode step of generate(), reference app.py:308-317): no column scale. */
+ *   40 = skinny weight-stream kernel for M <= 4 (the decode step of generate(), reference app.py:308-317): no column scale;
+ *   41 = token rows, M <= 16 (the 9 decoder tokens of reference model/sam2.py:1926-2100 TwoWayTransformer: a workgroup per 16 output columns, K split over its
+ *        8 waves): bf16 output, no column scale, no SwiGLU. */
 int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, int out_dtype, int tile,
                    void* workspace, int64_t workspace_bytes, void* stream);
@@ -221,10 +224,25 @@ int rga3_sam_select_objptr(const void* iou, const void* obj, const void* toks, i
  * q [Nq, 256], k [Nk, 256] (projected + rotated), m [Nk, 64] the un-projected memory rows; the caller applies the value projection to the 64-wide result
  * (softmax rows sum to one: softmax(S) (m Wv^T + bv) = (softmax(S) m) Wv^T + bv).  Replaces, for reference model/sam2.py:1519-1548 (RoPEAttention.forward of
  * cross_attn_image, kv_in_dim 64), v_proj over the whole bank + F.scaled_dot_product_attention.  Strides in elements; nsplit key slices (1..32);
- * ws = rga3_memattn_cross_ws_floats(Nq, nsplit) floats of caller workspace (< 0 = bad arguments).  Deterministic (no atomics). */
+ * ws = rga3_memattn_cross_ws_floats(Nq, nsplit) floats of caller workspace (< 0 = bad arguments).  Deterministic (no atomics).
+ * out = NULL leaves only the per-slice partial results in ws ([nsplit, Nq, 64] f32 unnormalised sums, then [nsplit, Nq, 2] f32 (maximum in the log2 domain,
+ * row sum)) for rga3_memlayer_rows to merge. */
 int64_t rga3_memattn_cross_ws_floats(int64_t Nq, int nsplit);
 int rga3_memattn_cross(const void* q, const void* k, const void* m, void* out, int64_t Nq, int64_t Nk, int64_t q_stride, int64_t k_stride, int64_t m_stride,
                        int64_t out_stride, float scale, int nsplit, float* ws, void* stream);
+/* The row-wise chain between the attention kernels of a memory-attention layer in ONE launch (csrc/memlayer.hip; model width 256), for reference
+ * model/sam2.py:448-530 (MemoryAttentionLayer._forward_sa / _forward_ca / forward: out_proj + residual, norm, the next q / qkv projection) and :1901-1923
+ * (apply_rotary_enc).  Every stage but the LayerNorm is optional:
+ *   product 1: operand rows a [M, K1] (K1 = 64 or 256) or the partial results of rga3_memattn_cross(out = NULL) (part_o, part_ml, nsplit; K1 = 64),
+ *              x' = bf16(bf16(a w1^T + b1) + res) with w1 [256, K1]; written to x_out if given.  w1 = NULL: x' = res.
+ *   t = LayerNorm(x'; ln_w, ln_b, eps); written to t_out if given.
+ *   product 2: y = bf16(t w2^T + b2), w2 [N2, 256], N2 = 256 or 768; columns < rope_cols get the axial rotation (cos / sin [nq, 128] f32, row = token % nq,
+ *              pair index = (column % 256) / 2); written to y_out.
+ * Row strides in elements (multiples of 4; a: of 8). */
+int rga3_memlayer_rows(const void* a, int64_t a_stride, int K1, const float* part_o, const float* part_ml, int nsplit, const void* w1, const void* b1,
+                       const void* res, int64_t res_stride, void* x_out, int64_t x_stride, const void* ln_w, const void* ln_b, float eps, void* t_out,
+                       int64_t t_stride, const void* w2, const void* b2, int N2, void* y_out, int64_t y_stride, const float* cos, const float* sin,
+                       int rope_cols, int nq, int64_t M, void* stream);
 /* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up in launches that used this workspace (expected 0;
  * < 0 = error); synchronises the device */
 int rga3_gemm_stream_k_timeouts(const void* workspace);

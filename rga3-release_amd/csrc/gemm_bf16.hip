@@ -1452,6 +1452,73 @@ static int launch_gemv(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Token-row products, 5 <= M <= 16 (tile 41): the token side of SAM2's two-way transformer (reference model/sam2.py:1926-2100: 9 output / prompt tokens per
+// frame through q / k / v / out projections and a 256 -> 2048 -> 256 MLP, 22 products per frame).  The tiled kernels pad those rows to a 128-row tile and walk K
+// inside ONE or two workgroups: 6 - 9 us per product, 24 us at K = 2048, all latency (profiles/r03_stream_frame_timeline_fused_tail.txt).  Here a workgroup owns 16
+// output columns and its 8 waves split K between them (k-step ks goes to wave ks % 8): the M rows are the MFMA's B operand (tokens on the N side), the 16 weight rows
+// the A operand, both read straight from L2 with every load of a wave in flight at once; the 8 partial tiles meet in LDS and wave 0 adds them in wave order (fixed
+// order: reproducible) and runs gemm_epilogue's arithmetic (bias, bf16 rounding before GELU, ReLU, the linear output rounded before the residual is added).
+constexpr int R16_NW = 8, R16_U = 8;
+template <int ACT>
+__global__ __launch_bounds__(64 * R16_NW) void gemm_rows16_kernel(GemmArgs p) {
+    __shared__ f32x4 red[R16_NW][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const unsigned short* arow = p.W + (long)min(n0 + c, p.N - 1) * p.ldw + g * 8;
+    const unsigned short* brow = p.A + (long)min(c, p.M - 1) * p.lda + g * 8;
+    const int nks = (p.K + 31) >> 5;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks0 = w; ks0 < nks; ks0 += R16_NW * R16_U) {
+        bf16x8 af[R16_U], bf[R16_U];
+#pragma unroll
+        for (int u = 0; u < R16_U; ++u) {
+            const int k = (ks0 + u * R16_NW) * 32 + g * 8;
+            u32x4 za = {0u, 0u, 0u, 0u}, zb = {0u, 0u, 0u, 0u};
+            if (k < p.K) {          // K % 8 == 0: a 16-byte chunk lies inside K or outside, never across
+                za = *(const u32x4*)(arow + (ks0 + u * R16_NW) * 32);
+                zb = *(const u32x4*)(brow + (ks0 + u * R16_NW) * 32);
+            }
+            af[u] = __builtin_bit_cast(bf16x8, za);
+            bf[u] = __builtin_bit_cast(bf16x8, zb);
+        }
+#pragma unroll
+        for (int u = 0; u < R16_U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], bf[u], acc, 0, 0, 0);
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w != 0) return;
+    f32x4 v = red[0][lane];
+#pragma unroll
+    for (int i = 1; i < R16_NW; ++i) v += red[i][lane];
+    // lane (c, g): row c, columns n0 + 4 g .. + 3
+    const int col = n0 + 4 * g;
+    if (c >= p.M || col >= p.N) return;
+    unsigned short* dst = (unsigned short*)p.C + (long)c * p.ldc + col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (col + r >= p.N) break;
+        float x = v[r];
+        if (p.bias) x += bf2f(p.bias[col + r]);
+        if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
+        if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
+        if (p.res) x = bf2f(f2bf(x)) + bf2f(p.res[(long)c * p.ldr + col + r]);
+        dst[r] = f2bf(x);
+    }
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_rows16(const GemmArgs& a, hipStream_t st) {
+    if constexpr (OUT_F32 || ACT == ACT_SWIGLU) {
+        return fail(-1, "gemm: tile 41 (token rows) writes bf16 and has no SwiGLU form");
+    } else {
+        hipLaunchKernelGGL(gemm_rows16_kernel<ACT>, dim3((unsigned)cdiv(a.N, 16)), dim3(64 * R16_NW), 0, st, a);
+        RGA3_CHECK_LAUNCH("gemm_rows16_kernel");
+        return 0;
+    }
+}
+
 // tile choice: fill the 256 CUs.  score = useful fraction of the last wave of tiles x a per-config prior.
 static int pick_tile(int M, int N, int K, bool plain, int forced) {
     if (forced >= 0) return forced;
@@ -1497,6 +1564,7 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 32: return launch_sk<ACT, OUT_F32, 3>(a, true, st);    // ... + stream-K tail
         case 25: return launch_splitk<ACT, OUT_F32>(a, st);
         case 40: return launch_gemv<ACT, OUT_F32>(a, st);   // M <= 4: weight stream (decode step)
+        case 41: return launch_rows16<ACT, OUT_F32>(a, st);  // 5 <= M <= 16 token rows
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);
     }
 }
@@ -1540,7 +1608,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || tile == 5 || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || tile == 5 || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;
@@ -1554,7 +1622,9 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.ws = workspace; a.ws_bytes = workspace_bytes; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
     hipStream_t st = (hipStream_t)stream;
     RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
-    int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
+    const bool rows16_ok = M <= 16 && !colscale && out_dtype == RGA3_BF16 && act != ACT_SWIGLU;
+    RGA3_CHECK_ARG(tile != 41 || rows16_ok, "gemm: the token-row kernel (tile 41) takes M <= 16 rows, bf16 output, no column scale, no SwiGLU");
+    int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : (tile == -1 && rows16_ok) ? 41 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
     if (out_dtype == RGA3_F32) return launch_act<ACT_NONE, true>(a, tl, st);
     switch (act) {
         case ACT_NONE: return launch_act<ACT_NONE, false>(a, tl, st);

@@ -31,27 +31,37 @@ namespace rga3 {
 
 constexpr int MA_KT = 64;                                      // keys per tile
 constexpr int MA_D = 256;                                      // q / k width
-constexpr int MA_DM = 64;                                      // memory width (value source)
+constexpr int MA_DM = 64;                                      // memory width (value source of the cross-attention)
 constexpr int MA_KSTR = MA_D * 2 + 16;                         // 528 B per K row in LDS
-constexpr int MA_MSTR = MA_DM * 2 + 64;                        // 192 B per M row in LDS
-constexpr int MA_TILE_BYTES = MA_KT * (MA_KSTR + MA_MSTR);     // 46 080
-constexpr int MA_LDS = 2 * MA_TILE_BYTES;                      // 92 160
-constexpr int MA_QB = 256;                                     // query rows per workgroup
 constexpr int MA_MAX_SPLIT = 32;
+// value rows in LDS: DM * 2 + 64 B (192 B for the 64-wide memory rows, 576 B for 256-wide values): the 4 rows x 64 B a 32-lane half of a transposed read touches
+// start 16 banks apart
+template <int DM> struct MaGeom {
+    static constexpr int MSTR = DM * 2 + 64;
+    static constexpr int TILE_BYTES = MA_KT * (MA_KSTR + MSTR);   // 46 080 (DM 64) / 70 656 (DM 256)
+    static constexpr int LDS = 2 * TILE_BYTES;                    // 92 160 / 141 312
+};
 
 struct MemAttnArgs {
     const unsigned short* q;   // [Nq, 256] bf16 (projected, rotated)
     const unsigned short* k;   // [Nk, 256] bf16 (projected, rotated)
-    const unsigned short* m;   // [Nk, 64] bf16 memory rows (value source)
-    unsigned short* out;       // [Nq, 64] bf16 = softmax(q k^T scale) m
-    float* part_o;             // [nsplit, Nq, 64] f32 unnormalised partial sums
+    const unsigned short* m;   // [Nk, DM] bf16 value rows (DM 64: the un-projected memory rows; DM 256: the self-attention's values)
+    unsigned short* out;       // [Nq, DM] bf16 = softmax(q k^T scale) m
+    float* part_o;             // [nsplit, Nq, DM] f32 unnormalised partial sums
     float* part_ml;            // [nsplit, Nq, 2] f32 (running maximum in the log2 domain, row sum)
     long q_st, k_st, m_st, out_st;
     int Nq, Nk, nsplit;
     float scale_log2;
 };
 
-__global__ __launch_bounds__(512) void memattn_cross_kernel(MemAttnArgs p) {
+// DM: value width, NW: waves per workgroup.  The product uses DM 64 (values kept in memory space) with 8 waves x 32 queries (216 VGPRs, two waves per SIMD).
+// Round 3 also ran the layer's SELF-attention through this loop (DM 256: 8 output blocks = 128 accumulator registers, so 4 waves, one per SIMD, on the 512-register
+// budget): correct, 43.8 us against 47.6 us for the general attention kernel on 4096 x 4096 (tools/memlayer_probe.py), but merging its 256-wide f32 partials costs
+// what it saves -- the 32-frame stream ran at 619.9 vs 619.6 and 604.9 vs 610.0 frames/s with and without it -- so that instantiation is not shipped.
+template <int DM, int NW>
+__global__ __launch_bounds__(64 * NW) void memattn_cross_kernel(MemAttnArgs p) {
+    constexpr int NT = 64 * NW, MA_QB = 32 * NW, NB = DM / 32, MA_MSTR = MaGeom<DM>::MSTR, MA_TILE_BYTES = MaGeom<DM>::TILE_BYTES;
+    constexpr int KJ = MA_KT * (MA_D / 8) / NT, MJ = MA_KT * (DM / 8) / NT, MCH = DM / 8;   // 16-byte chunks per thread and tile: keys, values; chunks per value row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -72,37 +82,42 @@ __global__ __launch_bounds__(512) void memattn_cross_kernel(MemAttnArgs p) {
         for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
     }
 
-    u32x4 kreg[4], mreg;
+    u32x4 kreg[KJ], mreg[MJ];
     auto load_tile = [&](int t) {
         const int k0 = t * MA_KT;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = tid + j * 512, row = idx >> 5, ch = idx & 31;
+        for (int j = 0; j < KJ; ++j) {
+            const int idx = tid + j * NT, row = idx >> 5, ch = idx & 31;
             u32x4 z = {0u, 0u, 0u, 0u};
             if (k0 + row < p.Nk) z = *(const u32x4*)(p.k + (long)(k0 + row) * p.k_st + ch * 8);
             kreg[j] = z;
         }
-        {
-            const int row = tid >> 3, ch = tid & 7;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int idx = tid + j * NT, row = idx / MCH, ch = idx % MCH;
             u32x4 z = {0u, 0u, 0u, 0u};
             if (k0 + row < p.Nk) z = *(const u32x4*)(p.m + (long)(k0 + row) * p.m_st + ch * 8);
-            mreg = z;
+            mreg[j] = z;
         }
     };
     auto store_tile = [&](int buf) {
         char* Kb = smem + buf * MA_TILE_BYTES;
         char* Mb = Kb + MA_KT * MA_KSTR;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = tid + j * 512, row = idx >> 5, ch = idx & 31;
+        for (int j = 0; j < KJ; ++j) {
+            const int idx = tid + j * NT, row = idx >> 5, ch = idx & 31;
             *(u32x4*)(Kb + row * MA_KSTR + ch * 16) = kreg[j];
         }
-        *(u32x4*)(Mb + (tid >> 3) * MA_MSTR + (tid & 7) * 16) = mreg;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int idx = tid + j * NT, row = idx / MCH, ch = idx % MCH;
+            *(u32x4*)(Mb + row * MA_MSTR + ch * 16) = mreg[j];
+        }
     };
 
-    f32x16 o[2];
+    f32x16 o[NB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
@@ -122,18 +137,20 @@ __global__ __launch_bounds__(512) void memattn_cross_kernel(MemAttnArgs p) {
         const char* Kb = smem + buf * MA_TILE_BYTES;
         const char* Mb = Kb + MA_KT * MA_KSTR;
         // ---- S^T = K Q^T: two blocks of 32 keys x 32 queries, 16 k-steps each
+        // (the two key blocks advance together: two independent accumulator chains, so a wave that is alone on its SIMD -- DM 256 -- does not wait out the
+        // latency of every product; the same for the output blocks below)
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-            const char* ka = Kb + (kb * 32 + r) * MA_KSTR + h * 16;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const bf16x8 a = *(const bf16x8*)(ka + ks * 32);
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 a = *(const bf16x8*)(Kb + (kb * 32 + r) * MA_KSTR + h * 16 + ks * 32);
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
             }
-        }
         if ((t + 1) * MA_KT > p.Nk) {   // ragged last tile: keys past the end see nothing (wave-uniform branch)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(512) void memattn_cross_kernel(MemAttnArgs p) {
         m_run = m_new;
         if (__any(alpha != 1.0f)) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[b][i] *= alpha;
         }
@@ -184,11 +201,11 @@ __global__ __launch_bounds__(512) void memattn_cross_kernel(MemAttnArgs p) {
                 pb[kb][ss] = __builtin_bit_cast(bf16x8, pk);
             }
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
+                for (int b = 0; b < NB; ++b) {
                     const char* a0 = Mb + (kb * 32 + 16 * ss) * MA_MSTR + b * 64 + tr_off;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * MA_MSTR));
@@ -204,9 +221,9 @@ __global__ __launch_bounds__(512) void memattn_cross_kernel(MemAttnArgs p) {
     l_run += __shfl_xor(l_run, 32, 64);
     const int qi = q0 + r;
     if (qi < p.Nq) {
-        float* po = p.part_o + ((long)split * p.Nq + qi) * MA_DM;
+        float* po = p.part_o + ((long)split * p.Nq + qi) * DM;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 f32x4 v = {o[b][4 * i4], o[b][4 * i4 + 1], o[b][4 * i4 + 2], o[b][4 * i4 + 3]};
@@ -220,27 +237,65 @@ __global__ __launch_bounds__(512) void memattn_cross_kernel(MemAttnArgs p) {
     }
 }
 
-// out[q] = sum_s w_s PM_s[q] / sum_s w_s l_s[q],  w_s = 2^(m_s - max_s m_s): one wave per query row (lane = memory column), slices added in slice order
+// out[q] = sum_s w_s PM_s[q] / sum_s w_s l_s[q],  w_s = 2^(m_s - max_s m_s): one wave per query row (lane = DM / 64 consecutive columns), slices added in slice order
+template <int DM>
 __global__ __launch_bounds__(256) void memattn_combine_kernel(MemAttnArgs p) {
+    constexpr int CPL = DM / 64;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= p.Nq) return;
     float m = -INFINITY;
     for (int s = 0; s < p.nsplit; ++s) m = fmaxf(m, p.part_ml[((long)s * p.Nq + row) * 2]);
-    float acc = 0.f, l = 0.f;
+    float acc[CPL], l = 0.f;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) acc[e] = 0.f;
     for (int s = 0; s < p.nsplit; ++s) {
         const float ms = p.part_ml[((long)s * p.Nq + row) * 2];
         const float w = (ms == -INFINITY) ? 0.f : exp2f(ms - m);
         l += w * p.part_ml[((long)s * p.Nq + row) * 2 + 1];
-        acc += w * p.part_o[((long)s * p.Nq + row) * MA_DM + lane];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) acc[e] += w * p.part_o[((long)s * p.Nq + row) * DM + lane * CPL + e];
     }
-    const float v = l > 0.f ? acc / l : 0.f;
-    p.out[row * p.out_st + lane] = f2bf(v);
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) p.out[row * p.out_st + lane * CPL + e] = f2bf(l > 0.f ? acc[e] / l : 0.f);
 }
 
 }  // namespace rga3
 
 using namespace rga3;
+
+template <int DM, int NW>
+static int memattn_launch(const void* q, const void* k, const void* m, void* out, int64_t Nq, int64_t Nk, int64_t q_stride, int64_t k_stride, int64_t m_stride,
+                          int64_t out_stride, float scale, int nsplit, float* ws, void* stream, const char* name) {
+    RGA3_CHECK_ARG(q && k && m && ws, "%s: null pointer", name);
+    RGA3_CHECK_ARG(Nq > 0 && Nk > 0 && Nq < (1 << 24) && Nk < (1 << 24), "%s: Nq %ld Nk %ld", name, (long)Nq, (long)Nk);
+    RGA3_CHECK_ARG(nsplit >= 1 && nsplit <= MA_MAX_SPLIT, "%s: nsplit %d", name, nsplit);
+    RGA3_CHECK_ARG(q_stride % 8 == 0 && k_stride % 8 == 0 && m_stride % 8 == 0 && q_stride >= MA_D && k_stride >= MA_D && m_stride >= DM && (!out || out_stride >= DM),
+                   "%s: strides", name);
+    RGA3_CHECK_ARG(scale > 0.f, "%s: scale must be positive", name);
+    RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)m | (uintptr_t)ws) & 15) == 0, "%s: 16-byte alignment", name);
+    auto kern = memattn_cross_kernel<DM, NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MaGeom<DM>::LDS);
+        if (e != hipSuccess) return fail(-(int)e, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+        attr_done = true;
+    }
+    MemAttnArgs a;
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.m = (const unsigned short*)m; a.out = (unsigned short*)out;
+    a.part_o = ws; a.part_ml = ws + (int64_t)nsplit * Nq * DM;
+    a.q_st = q_stride; a.k_st = k_stride; a.m_st = m_stride; a.out_st = out_stride;
+    a.Nq = (int)Nq; a.Nk = (int)Nk; a.nsplit = nsplit;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nqb = (unsigned)cdiv(Nq, 32 * NW);
+    hipLaunchKernelGGL(kern, dim3(nqb * (unsigned)nsplit), dim3(64 * NW), MaGeom<DM>::LDS, st, a);
+    RGA3_CHECK_LAUNCH(name);
+    if (!out) return 0;
+    hipLaunchKernelGGL(memattn_combine_kernel<DM>, dim3((unsigned)cdiv(Nq, 4)), dim3(256), 0, st, a);
+    RGA3_CHECK_LAUNCH(name);
+    return 0;
+}
 
 // floats of caller workspace for nsplit key slices over Nq query rows (partial sums + (max, sum) pairs)
 extern "C" int64_t rga3_memattn_cross_ws_floats(int64_t Nq, int nsplit) {
@@ -250,32 +305,9 @@ extern "C" int64_t rga3_memattn_cross_ws_floats(int64_t Nq, int nsplit) {
 
 // out [Nq, 64] bf16 = softmax(scale * q k^T) m  with q [Nq, 256], k [Nk, 256], m [Nk, 64] bf16 (row strides in elements, 16-byte aligned rows).
 // nsplit key slices (1 .. 32; the caller sizes it so that ceil(Nq / 256) * nsplit covers the CUs), ws = rga3_memattn_cross_ws_floats(Nq, nsplit) floats.
+// out = NULL: only the partial results are left in ws ([nsplit, Nq, 64] unnormalised sums, then [nsplit, Nq, 2] (maximum in the log2 domain, row sum)); the consumer
+// merges them (rga3_memlayer_rows does, in the same slice order).
 extern "C" int rga3_memattn_cross(const void* q, const void* k, const void* m, void* out, int64_t Nq, int64_t Nk, int64_t q_stride, int64_t k_stride,
                                   int64_t m_stride, int64_t out_stride, float scale, int nsplit, float* ws, void* stream) {
-    RGA3_CHECK_ARG(q && k && m && out && ws, "memattn_cross: null pointer");
-    RGA3_CHECK_ARG(Nq > 0 && Nk > 0 && Nq < (1 << 24) && Nk < (1 << 24), "memattn_cross: Nq %ld Nk %ld", (long)Nq, (long)Nk);
-    RGA3_CHECK_ARG(nsplit >= 1 && nsplit <= MA_MAX_SPLIT, "memattn_cross: nsplit %d", nsplit);
-    RGA3_CHECK_ARG(q_stride % 8 == 0 && k_stride % 8 == 0 && m_stride % 8 == 0 && q_stride >= MA_D && k_stride >= MA_D && m_stride >= MA_DM && out_stride >= MA_DM,
-                   "memattn_cross: strides");
-    RGA3_CHECK_ARG(scale > 0.f, "memattn_cross: scale must be positive");
-    RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)m | (uintptr_t)ws) & 15) == 0, "memattn_cross: 16-byte alignment");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)memattn_cross_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_LDS);
-        if (e != hipSuccess) return fail(-(int)e, "memattn_cross: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
-    MemAttnArgs a;
-    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.m = (const unsigned short*)m; a.out = (unsigned short*)out;
-    a.part_o = ws; a.part_ml = ws + (int64_t)nsplit * Nq * MA_DM;
-    a.q_st = q_stride; a.k_st = k_stride; a.m_st = m_stride; a.out_st = out_stride;
-    a.Nq = (int)Nq; a.Nk = (int)Nk; a.nsplit = nsplit;
-    a.scale_log2 = scale * 1.4426950408889634f;
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned nqb = (unsigned)cdiv(Nq, MA_QB);
-    hipLaunchKernelGGL(memattn_cross_kernel, dim3(nqb * (unsigned)nsplit), dim3(512), MA_LDS, st, a);
-    RGA3_CHECK_LAUNCH("memattn_cross_kernel");
-    hipLaunchKernelGGL(memattn_combine_kernel, dim3((unsigned)cdiv(Nq, 4)), dim3(256), 0, st, a);
-    RGA3_CHECK_LAUNCH("memattn_combine_kernel");
-    return 0;
+    return memattn_launch<MA_DM, 8>(q, k, m, out, Nq, Nk, q_stride, k_stride, m_stride, out_stride, scale, nsplit, ws, stream, "memattn_cross");
 }

@@ -109,6 +109,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
         extra = (25,) if (M * N <= (1 << 20) and K >= 4096 and plain) else ()
         if plain and bias is None and N % 8 == 0 and M * N <= (1 << 19) and K >= 512:   # skinny products (LoRA x A^T, dY B): 64 x 64 tiles with a K split
             extra = extra + (14,)
+        if M <= 16 and colscale is None and out_dtype == torch.bfloat16 and act != "swiglu":   # token rows (smaller products take tile 41 without asking)
+            extra = extra + (41,)
         tile = _tuner.pick(_tuner.key_of(M, N, K, act, odt, bias is not None, residual is not None), run, extra)
     run(tile)
     return out
@@ -526,7 +528,7 @@ def sam_select_objptr(iou, obj, toks, proj, no_obj_ptr):
 _memattn_ws = {}
 
 
-def memattn_cross(q, k, m, scale: float, nsplit: int = 0):
+def memattn_cross(q, k, m, scale: float, nsplit: int = 0, partials: bool = False):
     """SAM2 memory cross-attention with the values kept in memory space (csrc/memattn.hip): softmax(scale q k^T) m -> [Nq, 64] bf16.
     q [Nq, 256], k [Nk, 256] bf16 (projected and rotated; row strides free), m [Nk, 64] bf16 the un-projected memory rows.  The caller applies the value
     projection to the result.  nsplit = 0 picks the number of key slices that fills the chip (one 256-row query block x slice per CU)."""
@@ -546,10 +548,55 @@ def memattn_cross(q, k, m, scale: float, nsplit: int = 0):
     ws = _memattn_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = _memattn_ws[key] = torch.empty(n, dtype=torch.float32, device=q.device)
+    if partials:     # leave the per-slice partial results in the workspace: (sums [nsplit, Nq, 64], (max, sum) [nsplit, Nq, 2], nsplit) for memlayer_rows
+        _lib.check(L.rga3_memattn_cross(q.data_ptr(), k.data_ptr(), m.data_ptr(), None, Nq, Nk, q.stride(0), k.stride(0), m.stride(0), 0,
+                                        float(scale), int(nsplit), ws.data_ptr(), _stream()), "memattn_cross")
+        return ws[:nsplit * Nq * 64], ws[nsplit * Nq * 64:nsplit * Nq * 66], nsplit
     out = torch.empty((Nq, 64), dtype=torch.bfloat16, device=q.device)
     _lib.check(L.rga3_memattn_cross(q.data_ptr(), k.data_ptr(), m.data_ptr(), out.data_ptr(), Nq, Nk, q.stride(0), k.stride(0), m.stride(0), out.stride(0),
                                     float(scale), int(nsplit), ws.data_ptr(), _stream()), "memattn_cross")
     return out
+
+
+def memlayer_rows(res, ln, eps: float, a=None, partials=None, w1=None, b1=None, want_x=True, want_t=False, w2=None, b2=None, rope=None, rope_cols: int = 0):
+    """The row-wise chain between the attention kernels of a SAM2 memory-attention layer in one launch (csrc/memlayer.hip), model width 256:
+         x' = bf16(bf16(a w1^T + b1) + res)   (a [M, 64 | 256] rows, or partials = memattn_cross(..., partials=True); without w1: x' = res)
+         t  = LayerNorm(x'; ln = (weight, bias), eps)
+         y  = bf16(t w2^T + b2), columns < rope_cols rotated by rope = (cos, sin) [nq, 128] f32 (row = token % nq)
+    -> (x' or None, t or None, y or None)."""
+    wln, bln = ln
+    _need_cuda(res, wln, bln, a, w1, b1, w2, b2)
+    assert res.dtype == torch.bfloat16 and res.dim() == 2 and res.shape[1] == 256 and res.stride(1) == 1
+    M, dev = res.shape[0], res.device
+    x = t = y = None
+    K1, po, pml, ns = 0, None, None, 0
+    if w1 is not None:
+        assert w1.dtype == torch.bfloat16 and w1.is_contiguous() and w1.shape[0] == 256
+        K1 = w1.shape[1]
+        if partials is not None:
+            po, pml, ns = partials
+            assert a is None and K1 == 64 and po.numel() == ns * M * 64 and pml.numel() == ns * M * 2
+        else:
+            assert a is not None and a.dtype == torch.bfloat16 and tuple(a.shape) == (M, K1) and a.stride(1) == 1
+        if want_x:
+            x = torch.empty((M, 256), dtype=torch.bfloat16, device=dev)
+    else:
+        assert a is None and partials is None
+    if want_t or w2 is None:
+        t = torch.empty((M, 256), dtype=torch.bfloat16, device=dev)
+    N2, cos, sin, nq = 0, None, None, 0
+    if w2 is not None:
+        assert w2.dtype == torch.bfloat16 and w2.is_contiguous() and w2.shape[1] == 256 and w2.shape[0] in (256, 768)
+        N2 = w2.shape[0]
+        y = torch.empty((M, N2), dtype=torch.bfloat16, device=dev)
+        if rope_cols:
+            cos, sin = rope
+            assert cos.dtype == sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape[1] == 128 and cos.shape == sin.shape
+            nq = cos.shape[0]
+    _lib.check(_lib.load().rga3_memlayer_rows(_ptr(a), a.stride(0) if a is not None else 0, K1, _ptr(po), _ptr(pml), ns, _ptr(w1), _ptr(b1), res.data_ptr(), res.stride(0),
+                                              _ptr(x), 256, wln.data_ptr(), _ptr(bln), float(eps), _ptr(t), 256, _ptr(w2), _ptr(b2), N2, _ptr(y), N2 if N2 else 0,
+                                              _ptr(cos), _ptr(sin), int(rope_cols), nq, M, _stream()), "memlayer_rows")
+    return x, t, y
 
 
 def pixel_shuffle2x(g, bias, add, F: int, H: int, W: int, act: str = "none"):

@@ -34,6 +34,7 @@ from .qwen2_5_vl import Linear
 _DEBUG = None   # set to a dict by tools/grad_locate.py (diagnostic)
 
 
+_ROWCHAIN = True  # memory attention at inference: the row-wise steps between the attention kernels in one launch each (csrc/memlayer.hip)
 _MLP_FUSE = True  # stage-1 MLP of the frozen Hiera trunk as one launch (csrc/hiera_mlp.hip); tools/ flip it for A/B runs
 _LN_FOLD = True   # LayerNorm of the frozen Hiera trunk folded into the consuming product (tools/ flip this module attribute for A/B runs; no environment switch)
 
@@ -689,13 +690,33 @@ class MemoryAttention(nn.Module):
             return self.norm(x)
         pk = self._packs()
         L, D = len(self.layers), self.d_model
-        k_all = ops.gemm(mem_k, pk["wk_all"], pk["bk_all"])                           # keys of every layer: [nk, L * 256]
         cosL, sinL = self._tables(nq, L, x.device)
+        k_all = ops.gemm(mem_k, pk["wk_all"], pk["bk_all"])                           # keys of every layer: [nk, L * 256]
         ops.rope_axial_(k_all, cosL, sinL, nk - num_obj_ptr_tokens)
         cos2, sin2 = self._tables(nq, 2, x.device)
         cos1, sin1 = self.layers[0].self_attn.table(nq, x.device)
         cu = _cu(1, nq, x.device)
         memory = memory.contiguous()
+        if _ROWCHAIN:
+            # the row-wise steps between the attention kernels as ONE launch each (csrc/memlayer.hip): [norm1 -> qkv -> RoPE], [out_proj + residual -> norm2 -> q_proj ->
+            # RoPE], [merge of the cross-attention slices -> Wo Wv + residual -> norm3]
+            rope = (cos1, sin1)
+            l0 = self.layers[0]
+            qkv = ops.memlayer_rows(x, (l0.norm1.weight, l0.norm1.bias), l0.norm1.eps, w2=pk["layers"][0]["wqkv"], b2=pk["layers"][0]["bqkv"], rope=rope, rope_cols=2 * D)[2]
+            for li, layer in enumerate(self.layers):
+                lp, sa, ca = pk["layers"][li], layer.self_attn, layer.cross_attn_image
+                q3, k3, v3 = (qkv[:, i * D:(i + 1) * D].unflatten(1, (1, D)) for i in range(3))
+                o = ops.attn_varlen(q3, k3, v3, cu, cu, nq, D ** -0.5)
+                x, _, qp = ops.memlayer_rows(x, (layer.norm2.weight, layer.norm2.bias), layer.norm2.eps, a=o.view(nq, D), w1=sa.out_proj.weight, b1=sa.out_proj.bias,
+                                             w2=ca.q_proj.weight, b2=ca.q_proj.bias, rope=rope, rope_cols=D)
+                parts = ops.memattn_cross(qp, k_all[:, li * D:(li + 1) * D], memory, D ** -0.5, partials=True)
+                x, t, _ = ops.memlayer_rows(x, (layer.norm3.weight, layer.norm3.bias), layer.norm3.eps, partials=parts, w1=lp["wov"], b1=lp["bov"], want_t=True)
+                x = layer.linear2(layer.linear1(t, act="relu"), residual=x)
+                if li + 1 < L:
+                    nx = self.layers[li + 1]
+                    qkv = ops.memlayer_rows(x, (nx.norm1.weight, nx.norm1.bias), nx.norm1.eps, w2=pk["layers"][li + 1]["wqkv"], b2=pk["layers"][li + 1]["bqkv"], rope=rope,
+                                            rope_cols=2 * D)[2]
+            return self.norm(x)
         for li, layer in enumerate(self.layers):
             lp = pk["layers"][li]
             t = layer.norm1(x)

@@ -538,3 +538,28 @@ def test_attention_block_diagonal_packing(dev, seg_q, seg_k, nwin, H, D):
     ck2 = (torch.arange(nwin // g + 1, dtype=torch.int32) * seg_k * g).to(dev)
     got = ops.attn_varlen(q, k, v, cq2, ck2, seg_q * g, D ** -0.5, block=(seg_q, seg_k))
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(9, 256, 256), (9, 2048, 256), (9, 256, 2048), (16, 128, 256), (5, 24, 40), (13, 3584, 3584), (7, 250, 1176)])
+@pytest.mark.parametrize("act", ["none", "gelu", "relu"])
+def test_gemm_token_rows(dev, M, N, K, act):
+    """Tile 41 (5 - 16 token rows, K split over the 8 waves of a workgroup): the mask decoder's token-side products (9 x 256 x 256, the 256 -> 2048 -> 256 MLP), ragged
+    N / K (a last k-step of 8 columns, a last 16-column block of 8 / 10), a [SEG]-row sized product; bias, activation and residual with gemm_epilogue's rounding
+    points -- against fp32, against the tiled kernel, reproducible, and picked automatically for these shapes."""
+    from rga3.hip import ops
+
+    a, w = _rand((M, K), dev, seed=M + N), _rand((N, K), dev, 0.05, seed=K)
+    bias, res = _rand((N,), dev, 0.5, seed=5), _rand((M, N), dev, seed=6)
+    out = ops.gemm(a, w, bias=bias, residual=res, act=act, tile=41)
+    ref = R.linear_ref(a.cpu(), w.cpu(), bias.cpu(), res.cpu(), act)
+    assert _rel_l2(out, ref) < 8e-3
+    tiled = ops.gemm(a, w, bias=bias, residual=res, act=act, tile=12)
+    assert _rel_l2(out, tiled) < 2e-3
+    assert torch.equal(out, ops.gemm(a, w, bias=bias, residual=res, act=act, tile=41))
+    if M * N * K < (1 << 24):
+        assert torch.equal(out, ops.gemm(a, w, bias=bias, residual=res, act=act))          # tile = -1 routes here
+    plain = ops.gemm(a, w, tile=41)
+    assert _rel_l2(plain, R.linear_ref(a.cpu(), w.cpu())) < 6e-3
+    buf = torch.zeros((M, N + 8), dtype=torch.bfloat16, device=dev)                        # strided output view
+    ops.gemm(a, w, bias=bias, out=buf[:, :N], tile=41)
+    assert torch.equal(buf[:, :N], ops.gemm(a, w, bias=bias, tile=41)) and float(buf[:, N:].abs().max()) == 0.0

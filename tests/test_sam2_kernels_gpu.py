@@ -339,3 +339,66 @@ def test_in_launch_reductions_equal_two_launch_forms(dev):
         ref = ops.colsum(x)
         for _ in range(3):
             assert torch.equal(ops.colsum(x, fused_finish=True), ref), (rows, cols)
+
+
+@pytest.mark.parametrize("M,nq", [(4096, 4096), (1000, 256), (16 * 3 + 5, 64)])
+def test_memory_layer_row_chain(dev, M, nq):
+    """csrc/memlayer.hip: the three one-launch chains of a memory-attention layer against the launches they replace (same library: GEMM with residual epilogue,
+    LayerNorm, axial RoPE, the cross-attention merge) and against fp32 torch on the same bf16 operands -- a whole 64 x 64 frame, ragged row counts (partial last
+    16-row workgroup), table rows wrapping (token % nq)."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(M + nq)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16).to(dev)
+    x = (torch.randn(M, 256, generator=g) * 1.2 + 0.4 * torch.randn(M, 1, generator=g)).to(torch.bfloat16).to(dev)
+    gam, bet = (1 + 0.2 * torch.randn(256, generator=g)).to(torch.bfloat16).to(dev), r(256, sc=0.1)
+    ang = torch.rand(nq, 128, generator=g) * 6.28
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+
+    def rope_ref(y, cols):       # fp32 complex rotation of consecutive pairs, table row = token % nq, pair = (column % 256) / 2
+        y = y.clone()
+        t = torch.arange(M) % nq
+        for c0 in range(0, cols, 256):
+            blk = y[:, c0:c0 + 256].reshape(M, 128, 2)
+            c, s = cos.cpu()[t], sin.cpu()[t]
+            y[:, c0:c0 + 256] = torch.stack([blk[..., 0] * c - blk[..., 1] * s, blk[..., 0] * s + blk[..., 1] * c], -1).reshape(M, 256)
+        return y
+
+    # (1) norm -> qkv (256 -> 768) -> RoPE on q | k
+    wqkv, bqkv = r(768, 256, sc=0.06), r(768, sc=0.1)
+    _, _, y = ops.memlayer_rows(x, (gam, bet), 1e-5, w2=wqkv, b2=bqkv, rope=(cos, sin), rope_cols=512)
+    y_un = ops.gemm(ops.layernorm(x, gam, bet, 1e-5), wqkv, bqkv)
+    ops.rope_axial_(y_un[:, :512], cos.repeat(1, 2).contiguous(), sin.repeat(1, 2).contiguous(), M)
+    ref = rope_ref(F.linear(F.layer_norm(x.float().cpu(), (256,), gam.float().cpu(), bet.float().cpu(), 1e-5), wqkv.float().cpu(), bqkv.float().cpu()), 512)
+    assert rel(y, ref) < 1e-2, rel(y, ref)
+    assert rel(y, y_un) < 3e-3, rel(y, y_un)
+
+    # (2) out-projection + residual -> norm -> q projection -> RoPE
+    a, wo, bo, wq, bq = r(M, 256), r(256, 256, sc=0.06), r(256, sc=0.1), r(256, 256, sc=0.06), r(256, sc=0.1)
+    x2, t2, q2 = ops.memlayer_rows(x, (gam, bet), 1e-5, a=a, w1=wo, b1=bo, want_t=True, w2=wq, b2=bq, rope=(cos, sin), rope_cols=256)
+    x_un = ops.gemm(a, wo, bo, residual=x)
+    t_un = ops.layernorm(x_un, gam, bet, 1e-5)
+    q_un = ops.gemm(t_un, wq, bq)
+    ops.rope_axial_(q_un, cos, sin, M)
+    assert rel(x2, x_un) < 2e-3, rel(x2, x_un)                     # same rounding points; the library GEMM may cut K differently (stream-K)
+    assert rel(t2, t_un) < 3e-3 and rel(q2, q_un) < 3e-3, (rel(t2, t_un), rel(q2, q_un))
+    xr = F.linear(a.float().cpu(), wo.float().cpu(), bo.float().cpu()) + x.float().cpu()
+    qr = rope_ref(F.linear(F.layer_norm(xr, (256,), gam.float().cpu(), bet.float().cpu(), 1e-5), wq.float().cpu(), bq.float().cpu()), 256)
+    assert rel(x2, xr) < 1e-2 and rel(q2, qr) < 1.5e-2, (rel(x2, xr), rel(q2, qr))
+
+    # (3) merge of the cross-attention slices -> (Wo Wv) + residual -> norm
+    Nk = 1500
+    qq, kk, mm = r(M, 256), (torch.randn(Nk, 256, generator=g) * (0.5 + 1.5 * torch.linspace(0, 1, Nk)[:, None])).to(torch.bfloat16).to(dev), r(Nk, 64)
+    wov, bov = r(256, 64, sc=0.1), r(256, sc=0.1)
+    for nsplit in (0, 1, 5):
+        pm = ops.memattn_cross(qq, kk, mm, 256 ** -0.5, nsplit=nsplit)
+        x_un = ops.gemm(pm, wov, bov, residual=x)
+        t_un = ops.layernorm(x_un, gam, bet, 1e-5)
+        parts = ops.memattn_cross(qq, kk, mm, 256 ** -0.5, nsplit=nsplit, partials=True)
+        x3, t3, _ = ops.memlayer_rows(x, (gam, bet), 1e-5, partials=parts, w1=wov, b1=bov, want_t=True)
+        assert rel(x3, x_un) < 2e-3, (nsplit, rel(x3, x_un))
+        assert rel(t3, t_un) < 3e-3, rel(t3, t_un)
+    # plain 64-wide rows as the operand of product 1, nothing but the normalised rows written
+    _, t4, _ = ops.memlayer_rows(x, (gam, bet), 1e-5, a=pm, w1=wov, b1=bov, want_x=False)
+    assert torch.equal(t4, t3)
+    assert torch.equal(q2, ops.memlayer_rows(x, (gam, bet), 1e-5, a=a, w1=wo, b1=bo, w2=wq, b2=bq, rope=(cos, sin), rope_cols=256)[2])
