@@ -176,6 +176,14 @@ int rga3_bilinear(const void* in, int in_dtype, float* out, const int32_t* plane
  * (model/sam2.py:3017-3022 + MaskDownSampler :611-643) */
 int rga3_conv3x3s2(const void* x, int x_dtype, const void* w, const void* bias, void* y, int64_t F, int H, int W, int Cin, int Cout,
                    float sig_scale, float sig_bias, void* stream);
+/* n (<= 24) device-to-device copies in one launch (dst[i] <- src[i], bytes[i] bytes: multiples of 16, 16-byte aligned pointers, no overlap; the three arrays are HOST
+ * arrays).  The copies a video-session frame makes around its captured graph (reference model/sam2.py:2829-2989 builds the bank with torch.cat / index ops per frame). */
+int rga3_copy_many(void* const* dst, const void* const* src, const int64_t* bytes, int n, void* stream);
+/* The same convolution with the LayerNorm2d over its output channels and the exact GELU that follow it in reference model/sam2.py:611-643 (MaskDownSampler stages)
+ * in ONE launch, for the two narrow stages: (Cin, Cout) = (1, 4) from an f32 plane (with the sigmoid affine on load) or (4, 16) from bf16.  The arithmetic and
+ * rounding points of rga3_conv3x3s2 followed by rga3_layernorm_fwd(act = 1). */
+int rga3_conv3x3s2_ln_gelu(const void* x, int x_dtype, const void* w, const void* bias, const void* ln_w, const void* ln_b, float eps, void* y, int64_t F, int H, int W,
+                           int Cin, int Cout, float sig_scale, float sig_bias, void* stream);
 /* cols [F*(H/2)*(W/2), 9*C] (K index (kh*3+kw)*C + c, zero padded) of x [F,H,W,C] for Conv2d(k3,s2,p1) through rga3_gemm_bf16 with the weight
  * repacked [Cout, (kh,kw,ci)]: the wide stages of the memory encoder's mask downsampler (reference model/sam2.py:611-643) */
 int rga3_im2col3x3s2(const void* x, void* cols, int64_t F, int H, int W, int C, void* stream);

@@ -180,6 +180,130 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const void* __restrict__
     }
 }
 
+// ---- The first two stages of the memory encoder's mask down-sampler in one launch each (reference model/sam2.py:611-643 MaskDownSampler: Conv2d(k=3, s=2, p=1) ->
+//      LayerNorm2d -> GELU, 1 -> 4 channels at 1024 x 1024 and 4 -> 16 at 512 x 512).  A thread owns one OUTPUT PIXEL with all its channels, so the channel
+//      LayerNorm and the GELU are in-thread arithmetic on the convolution's result; filter, bias, gamma and beta sit in LDS as f32 and are read as broadcasts.
+//      The one-thread-per-output-element kernel above issued a 2-byte load per multiply and re-evaluated the input sigmoid once per output channel: 16 + 40 us for
+//      the two stages, + 5.6 + 11.2 us for their LayerNorm launches (profiles/r03_stream_frame_timeline_fused_tail.txt).  Same taps in the same order, the same
+//      bf16 rounding of the convolution's output before the statistics, LayerNorm sums associated as the stand-alone kernels associate them (4 channels: in sequence;
+//      16: two runs of 8, then their sum): equal to conv3x3s2 + layernorm(act = gelu) except for the last bf16 bit of a few elements per million (the compiler
+//      contracts the two forms differently).
+template <int CIN, int COUT, bool IN_F32>
+__global__ __launch_bounds__(256) void conv3x3s2_ln_gelu_kernel(const void* __restrict__ x, const unsigned short* __restrict__ w, const unsigned short* __restrict__ bias,
+                                                                const unsigned short* __restrict__ ln_w, const unsigned short* __restrict__ ln_b, float eps,
+                                                                unsigned short* __restrict__ y, long F, int H, int W, float ascale, float abias) {
+    __shared__ float wf[COUT * CIN * 9], bf[COUT], gf[COUT], hf[COUT];
+    for (int i = threadIdx.x; i < COUT * CIN * 9; i += 256) wf[i] = bf2f(w[i]);
+    if (threadIdx.x < COUT) {
+        bf[threadIdx.x] = bias ? bf2f(bias[threadIdx.x]) : 0.f;
+        gf[threadIdx.x] = bf2f(ln_w[threadIdx.x]);
+        hf[threadIdx.x] = ln_b ? bf2f(ln_b[threadIdx.x]) : 0.f;
+    }
+    __syncthreads();
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = F * Ho * Wo;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int ox = (int)(t % Wo), oy = (int)((t / Wo) % Ho);
+        const long f = t / ((long)Wo * Ho);
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = bf[co];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int sy = oy * 2 - 1 + kh;
+            if (sy < 0 || sy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int sx = ox * 2 - 1 + kw;
+                if (sx < 0 || sx >= W) continue;
+                const long pix = (f * H + sy) * (long)W + sx;
+                float xv[CIN];
+                if constexpr (IN_F32) {
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        float v = ((const float*)x)[pix * CIN + ci];
+                        if (ascale != 0.f) v = bf2f(f2bf(ascale / (1.f + __expf(-v)) + abias));
+                        xv[ci] = v;
+                    }
+                } else if constexpr (CIN == 4) {
+                    const u32x2 pk = *(const u32x2*)((const unsigned short*)x + pix * 4);
+                    xv[0] = __uint_as_float(pk[0] << 16); xv[1] = __uint_as_float(pk[0] & 0xffff0000u);
+                    xv[2] = __uint_as_float(pk[1] << 16); xv[3] = __uint_as_float(pk[1] & 0xffff0000u);
+                } else {
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) xv[ci] = bf2f(((const unsigned short*)x)[pix * CIN + ci]);
+                }
+#pragma unroll
+                for (int co = 0; co < COUT; ++co)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc[co] += xv[ci] * wf[((co * CIN + ci) * 3 + kh) * 3 + kw];
+            }
+        }
+        // LayerNorm over the channels of this pixel on the bf16-rounded convolution output, then the exact-erf GELU of the bf16-rounded normalised value
+        float v[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) v[co] = bf2f(f2bf(acc[co]));
+        float s1 = 0.f, s2 = 0.f;
+        if constexpr (COUT == 16) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a += v[e]; b += v[8 + e]; }
+            s1 = a + b;
+        } else {
+#pragma unroll
+            for (int e = 0; e < COUT; ++e) s1 += v[e];
+        }
+        const float mean = s1 / (float)COUT;
+        if constexpr (COUT == 16) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d0 = v[e] - mean, d1 = v[8 + e] - mean; a += d0 * d0; b += d1 * d1; }
+            s2 = a + b;
+        } else {
+#pragma unroll
+            for (int e = 0; e < COUT; ++e) { const float d = v[e] - mean; s2 += d * d; }
+        }
+        const float rinv = rsqrtf(s2 / (float)COUT + eps);
+        unsigned short o[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float n = bf2f(f2bf((v[co] - mean) * rinv * gf[co] + hf[co]));
+            o[co] = f2bf(0.5f * n * (1.0f + erff(n * 0.70710678118654752f)));
+        }
+        unsigned short* dst = y + t * COUT;
+        if constexpr (COUT % 8 == 0) {
+#pragma unroll
+            for (int c8 = 0; c8 < COUT / 8; ++c8) {
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (unsigned)o[c8 * 8 + 2 * e] | ((unsigned)o[c8 * 8 + 2 * e + 1] << 16);
+                *(u32x4*)(dst + c8 * 8) = pk;
+            }
+        } else {
+            static_assert(COUT == 4, "4 or a multiple of 8 output channels");
+            u32x2 pk = {(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+            *(u32x2*)dst = pk;
+        }
+    }
+}
+
+// ---- Several device-to-device copies in ONE launch (<= 24 segments of 16-byte chunks): what a video-session frame moves around its captured graph -- the frame's
+//      tokens and two feature maps and up to 6 memories + 15 pointers into the graph's static inputs, 4 results out -- was 9 - 13 copy launches of ~5 us each between
+//      two graph replays (profiles/r03_stream_frame_timeline_fused_tail.txt: __amd_rocclr_copyBuffer x 7 + the torch.cat / clone kernels).
+constexpr int CM_MAX = 24;
+struct CopyMany {
+    const u32x4* src[CM_MAX];
+    u32x4* dst[CM_MAX];
+    long chunks[CM_MAX];
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyMany p) {
+    const int sgm = blockIdx.y;
+    const u32x4* __restrict__ s = p.src[sgm];
+    u32x4* __restrict__ d = p.dst[sgm];
+    const long n = p.chunks[sgm];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) d[i] = s[i];
+}
+
 // ---- im2col for Conv2d(k=3, s=2, p=1) on token-major maps: x [F, H, W, C] -> cols [F*(H/2)*(W/2), 9*C], K index = (kh*3 + kw)*C + c,
 //      zero padding.  Feeds the NT GEMM with the weight repacked [Cout, (kh, kw, ci)]: the direct kernel above issues one 2-byte load per
 //      multiply and took 0.8 ms for the memory encoder's 64 -> 256 channel stage (0.3 GFLOP).
@@ -401,6 +525,45 @@ extern "C" int rga3_conv3x3s2(const void* x, int x_dtype, const void* w, const v
     else
         hipLaunchKernelGGL(conv3x3s2_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, x, (cus)w, (cus)bias, (us)y, (long)F, H, W, Cin, Cout, 0.f, 0.f);
     RGA3_CHECK_LAUNCH("conv3x3s2");
+    return 0;
+}
+
+// Conv2d(k=3, s=2, p=1) + LayerNorm over the output channels + exact GELU in one launch, for the two narrow stages of the mask down-sampler: (Cin, Cout) = (1, 4) with
+// an f32 input plane (optionally sigmoid(x) * sig_scale + sig_bias on load) or (4, 16) with a bf16 token-major input.  y [F, H/2, W/2, Cout] bf16.
+extern "C" int rga3_conv3x3s2_ln_gelu(const void* x, int x_dtype, const void* w, const void* bias, const void* ln_w, const void* ln_b, float eps, void* y, int64_t F, int H,
+                                      int W, int Cin, int Cout, float sig_scale, float sig_bias, void* stream) {
+    RGA3_CHECK_ARG(x && w && ln_w && y && F > 0 && H % 2 == 0 && W % 2 == 0, "conv3x3s2_ln_gelu: bad args");
+    RGA3_CHECK_ARG((x_dtype == RGA3_F32 && Cin == 1 && Cout == 4) || (x_dtype == RGA3_BF16 && Cin == 4 && Cout == 16),
+                   "conv3x3s2_ln_gelu: (Cin, Cout) = (%d, %d): (1, 4) from an f32 plane or (4, 16) from bf16", Cin, Cout);
+    RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "conv3x3s2_ln_gelu: 16-byte alignment");
+    dim3 g(grid1(F * (H / 2) * (W / 2)));
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 1)
+        hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<1, 4, true>), g, dim3(256), 0, st, x, (cus)w, (cus)bias, (cus)ln_w, (cus)ln_b, eps, (us)y, (long)F, H, W, sig_scale, sig_bias);
+    else
+        hipLaunchKernelGGL((conv3x3s2_ln_gelu_kernel<4, 16, false>), g, dim3(256), 0, st, x, (cus)w, (cus)bias, (cus)ln_w, (cus)ln_b, eps, (us)y, (long)F, H, W, 0.f, 0.f);
+    RGA3_CHECK_LAUNCH("conv3x3s2_ln_gelu");
+    return 0;
+}
+
+// n (<= 24) device-to-device copies in one launch: dst[i] <- src[i], bytes[i] bytes each (multiples of 16, 16-byte aligned, no overlap).  HOST arrays.
+extern "C" int rga3_copy_many(void* const* dst, const void* const* src, const int64_t* bytes, int n, void* stream) {
+    RGA3_CHECK_ARG(dst && src && bytes && n >= 1 && n <= CM_MAX, "copy_many: n %d (1..%d)", n, CM_MAX);
+    CopyMany p;
+    long most = 0;
+    for (int i = 0; i < n; ++i) {
+        RGA3_CHECK_ARG(dst[i] && src[i] && bytes[i] > 0 && bytes[i] % 16 == 0 && ((((uintptr_t)dst[i]) | ((uintptr_t)src[i])) & 15) == 0,
+                       "copy_many: segment %d: %ld bytes (multiple of 16, 16-byte aligned pointers)", i, (long)bytes[i]);
+        p.src[i] = (const u32x4*)src[i];
+        p.dst[i] = (u32x4*)dst[i];
+        p.chunks[i] = bytes[i] / 16;
+        if (p.chunks[i] > most) most = p.chunks[i];
+    }
+    unsigned gx = (unsigned)cdiv(most, 256 * 4);     // ~4 chunks per thread for the largest segment; smaller segments leave their extra workgroups idle
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(copy_many_kernel, dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, p);
+    RGA3_CHECK_LAUNCH("copy_many");
     return 0;
 }
 

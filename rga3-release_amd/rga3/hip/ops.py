@@ -443,6 +443,43 @@ def bilinear(x, size, plane_idx=None):
 _conv_pack = {}
 
 
+def copy_many(pairs):
+    """[(dst, src), ...] dense tensors of equal byte size -> dst[i] <- src[i], 24 copies per launch (csrc/sam2ops.hip copy_many); pairs that are not 16-byte
+    shaped / aligned go through Tensor.copy_."""
+    import ctypes
+    todo = []
+    for d, s in pairs:
+        nb = d.numel() * d.element_size()
+        if (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype and d.numel() == s.numel() and nb > 0 and nb % 16 == 0
+                and d.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0):
+            todo.append((d.data_ptr(), s.data_ptr(), nb))
+        else:
+            d.copy_(s)
+    for i0 in range(0, len(todo), 24):
+        part = todo[i0:i0 + 24]
+        n = len(part)
+        dp, sp, nb = (ctypes.c_void_p * n)(*[p_[0] for p_ in part]), (ctypes.c_void_p * n)(*[p_[1] for p_ in part]), (ctypes.c_int64 * n)(*[p_[2] for p_ in part])
+        _lib.check(_lib.load().rga3_copy_many(ctypes.cast(dp, ctypes.c_void_p), ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p), n, _stream()),
+                   "copy_many")
+
+
+def conv3x3s2_ln_gelu_ok(x, weight) -> bool:
+    """The fused narrow stages: 1 -> 4 channels from an f32 plane, 4 -> 16 from bf16."""
+    co, ci = weight.shape[0], weight.shape[1]
+    return (x.dtype == torch.float32 and (ci, co) == (1, 4)) or (x.dtype == torch.bfloat16 and (ci, co) == (4, 16))
+
+
+def conv3x3s2_ln_gelu(x, weight, bias, ln_w, ln_b, eps: float, F: int, H: int, W: int, sig_scale: float = 0.0, sig_bias: float = 0.0):
+    """conv3x3s2 + LayerNorm over the output channels + exact GELU in one launch (csrc/sam2ops.hip); the arithmetic of conv3x3s2 followed by layernorm(act="gelu")."""
+    _need_cuda(x, weight, bias, ln_w, ln_b)
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    assert conv3x3s2_ln_gelu_ok(x, weight) and weight.dtype == torch.bfloat16 and weight.is_contiguous() and x.is_contiguous() and x.numel() == F * H * W * Cin
+    y = torch.empty((F * (H // 2) * (W // 2), Cout), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().rga3_conv3x3s2_ln_gelu(x.data_ptr(), F32 if x.dtype == torch.float32 else BF16, weight.data_ptr(), _ptr(bias), ln_w.data_ptr(), _ptr(ln_b),
+                                                  float(eps), y.data_ptr(), F, H, W, Cin, Cout, float(sig_scale), float(sig_bias), _stream()), "conv3x3s2_ln_gelu")
+    return y
+
+
 def conv3x3s2(x, weight, bias, F: int, H: int, W: int, sig_scale: float = 0.0, sig_bias: float = 0.0):
     """token-major x [F*H*W, Cin] (bf16, or f32 single plane with the sigmoid affine) -> [F*(H/2)*(W/2), Cout]."""
     _need_cuda(x, weight, bias)

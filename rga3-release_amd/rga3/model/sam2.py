@@ -792,10 +792,12 @@ class MemoryEncoder(nn.Module):
         x, H = mask_f32.contiguous(), S
         for i in range(self.mask_downsampler.n_down):
             conv, norm = enc[3 * i], enc[3 * i + 1]
-            if i == 0:
-                x = ops.conv3x3s2(x, conv.weight, conv.bias, Fn, H, H, sig_scale, sig_bias)
-            else:
-                x = ops.conv3x3s2(x, conv.weight, conv.bias, Fn, H, H)
+            ss, sb = (sig_scale, sig_bias) if i == 0 else (0.0, 0.0)
+            if not _ag() and ops.conv3x3s2_ln_gelu_ok(x, conv.weight):   # the two narrow stages: convolution + LayerNorm2d + GELU in one launch
+                x = ops.conv3x3s2_ln_gelu(x, conv.weight, conv.bias, norm.weight, norm.bias, norm.eps, Fn, H, H, ss, sb)
+                H //= 2
+                continue
+            x = ops.conv3x3s2(x, conv.weight, conv.bias, Fn, H, H, ss, sb)
             H //= 2
             x = norm(x, act="gelu")   # incl. the 4-channel stage (narrow-row LayerNorm kernel)
         last = enc[3 * self.mask_downsampler.n_down]
@@ -1175,13 +1177,11 @@ class VideoSession:
             mask = ops.bilinear(pm.reshape(1, *pm.shape[-2:]).float().contiguous(), (S, S)).unsqueeze(0)
             return pm, o["obj_ptr"], mf, mask
 
-        G["tok"].copy_(f["feat"][t * hw:(t + 1) * hw])
-        G["s0"].copy_(f["feat_s0"][t * 16 * hw:(t + 1) * 16 * hw])
-        G["s1"].copy_(f["feat_s1"][t * 4 * hw:(t + 1) * 4 * hw])
-        if n_nc:
-            torch.cat([self.non_cond[t - n_nc + i]["maskmem_features"] for i in range(n_nc)], dim=0, out=G["mem"][hw:p0])
-        if n_pp:
-            torch.cat([self.non_cond[t - dd]["obj_ptr"].reshape(-1, m.mem_dim) for dd in range(1, n_pp + 1)], dim=0, out=G["mem"][p0 + k:])
+        # the frame's inputs and the moving part of the bank into the graph's static buffers: one launch for all of them
+        moves = [(G["tok"], f["feat"][t * hw:(t + 1) * hw]), (G["s0"], f["feat_s0"][t * 16 * hw:(t + 1) * 16 * hw]), (G["s1"], f["feat_s1"][t * 4 * hw:(t + 1) * 4 * hw])]
+        moves += [(G["mem"][(1 + i) * hw:(2 + i) * hw], self.non_cond[t - n_nc + i]["maskmem_features"]) for i in range(n_nc)]
+        moves += [(G["mem"][p0 + dd * k:p0 + (dd + 1) * k], self.non_cond[t - dd]["obj_ptr"].reshape(-1, m.mem_dim)) for dd in range(1, n_pp + 1)]
+        ops.copy_many(moves)
         if fresh:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -1192,8 +1192,9 @@ class VideoSession:
             with torch.cuda.graph(ent["graph"], pool=cache["pool"]):
                 ent["outs"] = body()
         ent["graph"].replay()
-        pm, ptr, mf, mask = ent["outs"]
-        return pm.clone(), ptr.clone(), mf.clone(), mask.clone()
+        outs = [torch.empty_like(o_) for o_ in ent["outs"]]      # the graph's result buffers are overwritten by the next replay
+        ops.copy_many(list(zip(outs, ent["outs"])))
+        return tuple(outs)
 
     def propagate(self, use_graph: bool = False, start_frame_idx=None, max_frame_num_to_track=None, reverse: bool = False):
         """reference propagate_in_video (sam2.py:4049-4132): (frame_idx, masks [1, 1, S, S] f32) in processing order -- by default every frame from the first

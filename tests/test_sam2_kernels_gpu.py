@@ -402,3 +402,54 @@ def test_memory_layer_row_chain(dev, M, nq):
     _, t4, _ = ops.memlayer_rows(x, (gam, bet), 1e-5, a=pm, w1=wov, b1=bov, want_x=False)
     assert torch.equal(t4, t3)
     assert torch.equal(q2, ops.memlayer_rows(x, (gam, bet), 1e-5, a=a, w1=wo, b1=bo, w2=wq, b2=bq, rope=(cos, sin), rope_cols=256)[2])
+
+
+@pytest.mark.parametrize("Fn,S", [(1, 1024), (2, 64), (1, 8)])
+def test_mask_downsampler_narrow_stages_fused(dev, Fn, S):
+    """csrc/sam2ops.hip conv3x3s2_ln_gelu: Conv2d(k 3, s 2, p 1) + LayerNorm2d + GELU of the two narrow mask-down-sampler stages in one launch each -- the same numbers as
+    the three launches they replace (conv3x3s2, then layernorm with the fused GELU), and fp32 torch on the same bf16 operands; a whole 1024 x 1024 mask, two frames, and a
+    8 x 8 map where many taps fall on the zero padding."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(S)
+    mask = (torch.randn(Fn, S, S, generator=g) * 4).to(dev)
+    w1, b1 = rnd((4, 1, 3, 3), dev, 0.3, seed=1), rnd((4,), dev, 0.1, seed=2)
+    g1, h1 = (1 + 0.2 * torch.randn(4, generator=g)).to(torch.bfloat16).to(dev), rnd((4,), dev, 0.1, seed=3)
+    w2, b2 = rnd((16, 4, 3, 3), dev, 0.2, seed=4), rnd((16,), dev, 0.1, seed=5)
+    g2, h2 = (1 + 0.2 * torch.randn(16, generator=g)).to(torch.bfloat16).to(dev), rnd((16,), dev, 0.1, seed=6)
+    y1 = ops.conv3x3s2_ln_gelu(mask, w1, b1, g1, h1, 1e-6, Fn, S, S, 20.0, -10.0)
+    u1 = ops.layernorm(ops.conv3x3s2(mask, w1, b1, Fn, S, S, 20.0, -10.0), g1, h1, 1e-6, act="gelu")
+
+    def same(a, b):     # the same arithmetic at the same rounding points; the compilers' contraction choices differ in a few elements per million, by one bf16 ulp
+        d = (a.float() - b.float()).abs()
+        return float((d > 0).float().mean()) < 2e-5 and bool((d <= b.float().abs() * 2 ** -7 + 1e-30).all())
+
+    assert same(y1, u1)
+    y2 = ops.conv3x3s2_ln_gelu(y1, w2, b2, g2, h2, 1e-6, Fn, S // 2, S // 2)
+    u2 = ops.layernorm(ops.conv3x3s2(y1, w2, b2, Fn, S // 2, S // 2), g2, h2, 1e-6, act="gelu")
+    assert same(y2, u2)
+    mm = (torch.sigmoid(mask.cpu()) * 20 - 10).to(torch.bfloat16).float()
+    r1 = F.conv2d(mm[:, None], w1.float().cpu(), b1.float().cpu(), stride=2, padding=1).permute(0, 2, 3, 1)
+    r1 = F.gelu(F.layer_norm(r1, (4,), g1.float().cpu(), h1.float().cpu(), 1e-6))
+    assert rel(y1, r1.reshape(-1, 4)) < 2e-2
+    r2 = F.conv2d(y1.float().cpu().view(Fn, S // 2, S // 2, 4).permute(0, 3, 1, 2), w2.float().cpu(), b2.float().cpu(), stride=2, padding=1).permute(0, 2, 3, 1)
+    r2 = F.gelu(F.layer_norm(r2, (16,), g2.float().cpu(), h2.float().cpu(), 1e-6))
+    assert rel(y2, r2.reshape(-1, 16)) < 2e-2
+
+
+def test_copy_many(dev):
+    """csrc/sam2ops.hip copy_many: up to 24 device-to-device copies per launch (more are chunked), sizes from 16 B to a few MB; odd-sized / strided pairs fall back to
+    Tensor.copy_."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(3)
+    sizes = [8, 256, 4096 * 64, 1000 * 8, 16 * 4096 * 32, 24] + [256] * 25
+    srcs = [torch.randn(n, generator=g).to(torch.bfloat16).to(dev) for n in sizes]
+    dsts = [torch.zeros_like(s_) for s_ in srcs]
+    odd_s, odd_d = torch.randn(7, generator=g).to(torch.bfloat16).to(dev), torch.zeros(7, dtype=torch.bfloat16, device=dev)        # 14 bytes
+    big = torch.randn(64, 64, generator=g).to(dev)
+    view_d = torch.zeros(64, 64, device=dev)
+    ops.copy_many(list(zip(dsts, srcs)) + [(odd_d, odd_s), (view_d[:, :32], big[:, :32])])
+    for d_, s_ in zip(dsts, srcs):
+        assert torch.equal(d_, s_)
+    assert torch.equal(odd_d, odd_s) and torch.equal(view_d[:, :32], big[:, :32]) and float(view_d[:, 32:].abs().max()) == 0.0
