@@ -251,12 +251,6 @@ int rga3_memlayer_rows(const void* a, int64_t a_stride, int K1, const float* par
                        const void* res, int64_t res_stride, void* x_out, int64_t x_stride, const void* ln_w, const void* ln_b, float eps, void* t_out,
                        int64_t t_stride, const void* w2, const void* b2, int N2, void* y_out, int64_t y_stride, const float* cos, const float* sin,
                        int rope_cols, int nq, int64_t M, void* stream);
-/* Activation-stationary product for the K = 576 shapes of the frozen Hiera trunk (reference model/sam2.py:986-1117: attn.qkv, attn.proj, mlp fc1 of a stage-3
- * MultiScaleBlock): a workgroup keeps 256 token rows x K in registers and the weight matrix streams past them (csrc/gemm_xstat.hip).  C [M, N] bf16 =
- * act(A W^T + bias) (+ residual); with rowstat [M][2] / colc [N] the LayerNorm-folded form of rga3_gemm_ln_bf16.  K == 576, N % 32 == 0, act none (0) / gelu (1) /
- * relu (3); strides in elements (multiples of 8).  Epilogue arithmetic and rounding points of rga3_gemm_bf16. */
-int rga3_gemm_xstat_bf16(const void* A, const void* W, const void* bias, const void* residual, const float* rowstat, const float* colc, void* C, int64_t M, int64_t N,
-                         int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, void* stream);
 /* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up in launches that used this workspace (expected 0;
  * < 0 = error); synchronises the device */
 int rga3_gemm_stream_k_timeouts(const void* workspace);

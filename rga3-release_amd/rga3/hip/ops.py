@@ -116,30 +116,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     return out
 
 
-def gemm_xstat_ok(a, w) -> bool:
-    """Shapes the activation-stationary kernel takes: K = 576, N a multiple of 32."""
-    return a.shape[1] == 576 and w.shape[1] == 576 and w.shape[0] % 32 == 0 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
-
-
-def gemm_xstat(a, w, bias=None, residual=None, act: str = "none", stats=None, colc=None, out=None):
-    """act(a @ w.T + bias) (+ residual) by the activation-stationary kernel (csrc/gemm_xstat.hip; K = 576); with stats / colc the LayerNorm-folded form of gemm_ln."""
-    _need_cuda(a, w, bias, residual, stats, colc, out)
-    assert a.dtype == w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and gemm_xstat_ok(a, w)
-    assert act in ("none", "gelu", "relu") and (stats is None) == (colc is None)
-    M, K = a.shape
-    N = w.shape[0]
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.bfloat16 and out.stride(0) % 8 == 0
-    if residual is not None:
-        assert residual.dtype == torch.bfloat16 and residual.shape == (M, N) and residual.stride(1) == 1
-    if stats is not None:
-        assert stats.dtype == colc.dtype == torch.float32 and tuple(stats.shape) == (M, 2) and stats.is_contiguous() and colc.numel() == N
-    _lib.check(_lib.load().rga3_gemm_xstat_bf16(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(stats), _ptr(colc), out.data_ptr(), M, N, K, a.stride(0),
-                                                w.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0, ACT[act], _stream()), "gemm_xstat_bf16")
-    return out
-
-
 def layernorm_stats(x, eps: float):
     """[rows, 2] f32 = (mean, 1/sqrt(var + eps)) of the rows of x [rows, dim] bf16 (row stride free): the input of gemm_ln."""
     _need_cuda(x)
