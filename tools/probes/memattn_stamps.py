@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """s_memtime stamps of workgroup 0 of the (measurement-build) staggered memory cross-attention kernel: per half-step start / after the phase / after the LDS store /
-(next start = after the barrier).  make -C rga3-release_amd/csrc AB=1 first."""
+(next start = after the barrier).  The variant is not in the tree: git apply tools/probes/memattn_staggered_variant.patch && make -C rga3-release_amd/csrc, run this,
+then git checkout rga3-release_amd/csrc/memattn.hip && make again."""
 import os
 import sys
 
