@@ -323,44 +323,72 @@ __global__ __launch_bounds__(256) void im2col3x3s2_kernel(const unsigned short* 
     }
 }
 
-// ---- depthwise Conv2d(k=7, p=3) on token-major maps [F, H, W, C]; w [C, 1, 7, 7]; 8 channels per thread.
-// The 49 x C filter taps are staged ONCE per workgroup as f32 [tap][C] in LDS (the first form fetched every tap of every channel with a scalar 2-byte global load:
-// 392 dependent loads per thread, 60 us for one 64 x 64 x 256 map); a thread then reads its 8 channels of a tap with two ds_read_b128.  Same taps, same order,
-// same f32 sums: bit-identical results.
-__global__ __launch_bounds__(256) void dwconv7_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+// ---- depthwise Conv2d(k=7, p=3) on token-major maps [F, H, W, C]; w [C, 1, 7, 7] (reference model/sam2.py:690-703 CXBlock.dwconv).
+// A workgroup takes an 8 x 8 pixel tile x 64 channels: the 14 x 14 x 64 input halo (25 KB) and the 49 x 64 taps go to LDS once -- every global load of the workgroup in
+// flight together -- and each of the 512 threads (pixel, 8 channels) walks its 49 taps out of LDS.  History of this kernel on one 64 x 64 x 256 map (4 MB in + out):
+// 60 us with a scalar 2-byte global load per tap and channel; 23 us with the taps in LDS but the input read tap by tap from global memory (49 dependent-latency
+// rounds at two waves per SIMD), of which ~10 us were a badly staged tap table; 18 us with row-batched loads.  Same taps in the same order, f32 sums: the same bits.
+constexpr int DW_T = 8, DW_HALO = DW_T + 6, DW_CB = 64;
+__global__ __launch_bounds__(512) void dwconv7_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                                       const unsigned short* __restrict__ bias, unsigned short* __restrict__ y, long F, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float dw_taps[];   // [49][C]
-    for (int i = threadIdx.x; i < 49 * C; i += 256) dw_taps[(i % 49) * C + i / 49] = bf2f(w[i]);
-    __syncthreads();
-    const int nch = C / 8;
-    const long total = F * H * W * nch;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ch = (int)(i % nch);
-        const long t = i / nch;
-        const int px = (int)(t % W), py = (int)((t / W) % H);
-        const long f = t / ((long)W * H);
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = bias ? bf2f(bias[ch * 8 + e]) : 0.f;
-        for (int kh = 0; kh < 7; ++kh) {
-            const int sy = py - 3 + kh;
-            if (sy < 0 || sy >= H) continue;
-            for (int kw = 0; kw < 7; ++kw) {
-                const int sx = px - 3 + kw;
-                if (sx < 0 || sx >= W) continue;
-                float fx[8];
-                up8(*(const u32x4*)(x + ((f * H + sy) * (long)W + sx) * C + ch * 8), fx);
-                const float* wk = dw_taps + (kh * 7 + kw) * C + ch * 8;
-                const f32x4 w0 = *(const f32x4*)wk, w1 = *(const f32x4*)(wk + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[e] += fx[e] * w0[e];
-                    acc[4 + e] += fx[4 + e] * w1[e];
-                }
-            }
-        }
-        *(u32x4*)(y + t * C + ch * 8) = pk8(acc);
+    __shared__ __attribute__((aligned(16))) unsigned short xin[DW_HALO * DW_HALO * DW_CB];   // [14][14][64]
+    __shared__ __attribute__((aligned(16))) unsigned short raw[DW_CB * 49 + 8];              // this channel block's taps as in memory: [64][49]
+    __shared__ __attribute__((aligned(16))) unsigned short taps[49 * DW_CB];                 // [49][64]
+    const int tid = threadIdx.x;
+    const int tilesx = (W + DW_T - 1) / DW_T, tilesy = (H + DW_T - 1) / DW_T;
+    const int tx = blockIdx.x % tilesx, ty = (blockIdx.x / tilesx) % tilesy;
+    const long f = blockIdx.x / ((long)tilesx * tilesy);
+    const int c0 = blockIdx.y * DW_CB;
+    const int cb = min(DW_CB, C - c0);             // channels of this block (multiple of 8)
+    const int x0 = tx * DW_T - 3, y0 = ty * DW_T - 3;
+    // halo: 196 pixels x 8 chunks of 16 bytes; out-of-map pixels are zeros (adding 0 * w leaves a sum as it was: the same bits as skipping the tap)
+    for (int i = tid; i < DW_HALO * DW_HALO * (DW_CB / 8); i += 512) {
+        const int ch = i & 7, pix = i >> 3;
+        const int hy = pix / DW_HALO, hx = pix - hy * DW_HALO;
+        const int sy = y0 + hy, sx = x0 + hx;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W && ch * 8 < cb) v = *(const u32x4*)(x + ((f * H + sy) * (long)W + sx) * C + c0 + ch * 8);
+        *(u32x4*)(xin + pix * DW_CB + ch * 8) = v;
     }
+    // taps of channels c0 .. c0 + cb - 1: contiguous cb x 49 values, copied as they are, then transposed inside LDS
+    {
+        const unsigned short* wsrc = w + (long)c0 * 49;
+        const int n = cb * 49;
+        const int head = (int)(((16 - ((uintptr_t)wsrc & 15)) & 15) / 2);     // elements before the first 16-byte boundary
+        for (int i = tid; i < min(head, n); i += 512) raw[i] = wsrc[i];
+        const int nchunk = (n - min(head, n)) / 8;
+        for (int i = tid; i < nchunk; i += 512) {
+            const u32x4 v = *(const u32x4*)(wsrc + head + i * 8);
+            unsigned short* d = raw + head + i * 8;     // raw + head is only 2-byte aligned in general: element stores
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d[2 * e] = (unsigned short)(v[e] & 0xffffu); d[2 * e + 1] = (unsigned short)(v[e] >> 16); }
+        }
+        for (int i = min(head, n) + nchunk * 8 + tid; i < n; i += 512) raw[i] = wsrc[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < 49 * DW_CB; i += 512) {
+        const int k = i / DW_CB, ch1 = i - k * DW_CB;
+        taps[i] = ch1 < cb ? raw[ch1 * 49 + k] : (unsigned short)0;
+    }
+    __syncthreads();
+    const int cg = tid & 7, pp = tid >> 3;            // 8 channels, pixel of the tile
+    const int ly = pp >> 3, lx = pp & 7;
+    const int py = ty * DW_T + ly, px = tx * DW_T + lx;
+    if (py >= H || px >= W || cg * 8 >= cb) return;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bf2f(bias[c0 + cg * 8 + e]) : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+            float fx[8], fw[8];
+            up8(*(const u32x4*)(xin + ((ly + kh) * DW_HALO + lx + kw) * DW_CB + cg * 8), fx);
+            up8(*(const u32x4*)(taps + (kh * 7 + kw) * DW_CB + cg * 8), fw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += fx[e] * fw[e];
+        }
+    *(u32x4*)(y + ((f * H + py) * (long)W + px) * C + c0 + cg * 8) = pk8(acc);
 }
 
 // ---- axial complex RoPE in place (reference sam2.py:1901-1923): consecutive (even, odd) pairs, token t < n_rope uses
@@ -575,17 +603,11 @@ extern "C" int rga3_im2col3x3s2(const void* x, void* cols, int64_t F, int H, int
 }
 
 extern "C" int rga3_dwconv7x7(const void* x, const void* w, const void* bias, void* y, int64_t F, int H, int W, int C, void* stream) {
-    RGA3_CHECK_ARG(x && w && y && F > 0 && C % 8 == 0 && C <= 512, "dwconv7x7: bad args (C %d: multiple of 8, <= 512)", C);
-    const int lds = 49 * C * 4;
-    static int lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwconv7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(-(int)e, "dwconv7x7: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        lds_set = lds;
-    }
-    unsigned gx = (unsigned)cdiv(F * H * W * (C / 8), 256);
-    if (gx > 1024) gx = 1024;     // every workgroup stages the taps once, then strides over the pixels
-    hipLaunchKernelGGL(dwconv7_kernel, dim3(gx), dim3(256), lds, (hipStream_t)stream, (cus)x, (cus)w, (cus)bias, (us)y, (long)F, H, W, C);
+    RGA3_CHECK_ARG(x && w && y && F > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "dwconv7x7: bad args (C %d: a multiple of 8)", C);
+    RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "dwconv7x7: 16-byte alignment of the maps");
+    const long tiles = (long)cdiv(W, DW_T) * cdiv(H, DW_T) * F;
+    RGA3_CHECK_ARG(tiles < (1L << 31) && cdiv(C, DW_CB) <= 65535, "dwconv7x7: grid");
+    hipLaunchKernelGGL(dwconv7_kernel, dim3((unsigned)tiles, (unsigned)cdiv(C, DW_CB)), dim3(512), 0, (hipStream_t)stream, (cus)x, (cus)w, (cus)bias, (us)y, (long)F, H, W, C);
     RGA3_CHECK_LAUNCH("dwconv7x7");
     return 0;
 }

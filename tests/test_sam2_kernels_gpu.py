@@ -453,3 +453,19 @@ def test_copy_many(dev):
     for d_, s_ in zip(dsts, srcs):
         assert torch.equal(d_, s_)
     assert torch.equal(odd_d, odd_s) and torch.equal(view_d[:, :32], big[:, :32]) and float(view_d[:, 32:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Fn,H,W,C", [(1, 64, 64, 256), (2, 20, 12, 72), (1, 7, 9, 8)])
+def test_dwconv7x7_tiled(dev, Fn, H, W, C):
+    """csrc/sam2ops.hip dwconv7_kernel (8 x 8 pixel tile x 64 channels per workgroup, halo and taps in LDS): the memory encoder's map, maps that are not multiples of
+    the tile with a partial channel block, a map smaller than the filter -- against F.conv2d(groups = C) on the same bf16 operands."""
+    from rga3.hip import ops
+
+    x, w, b = rnd((Fn * H * W, C), dev, seed=H), rnd((C, 1, 7, 7), dev, 0.1, seed=W), rnd((C,), dev, 0.1, seed=C)
+    ref = F.conv2d(x.float().cpu().view(Fn, H, W, C).permute(0, 3, 1, 2), w.float().cpu(), b.float().cpu(), padding=3, groups=C).permute(0, 2, 3, 1).reshape(-1, C)
+    out = ops.dwconv7x7(x, w, b, Fn, H, W)
+    assert rel(out, ref) < 6e-3
+    assert torch.equal(out, ops.dwconv7x7(x, w, b, Fn, H, W))
+    off = torch.zeros(8 + C * 49, dtype=torch.bfloat16, device=dev)      # a filter that does not start on a 16-byte boundary
+    off[3:3 + C * 49] = w.reshape(-1)
+    assert torch.equal(out, ops.dwconv7x7(x, off[3:3 + C * 49].view(C, 1, 7, 7), b, Fn, H, W))
