@@ -4,9 +4,9 @@
 // Every one of these is a 3-layer MLP on ONE 256-wide row per frame.  As GEMV launches they were 21 launches + ~25 elementwise / index launches of the host framework
 // per frame, each at the ~4.5 us launch floor: 0.2 ms of the 2.2 ms steady-state frame of the configs[3] stream (profiles/r03_stream_frame_timeline_memattn.txt).
 // Two launches replace them:
-//   mlp3_rows_kernel   grid (MLP, frame): the 3 layers of one MLP for one frame's token row; the row lives in LDS as f32, a thread owns an output column and walks its
-//                      weight row in 16-byte steps (the six weight sets together are 1.5 MB: L2-resident), bias + bf16 rounding + ReLU as the GEMM epilogue does,
-//                      optional sigmoid on the last layer (IoU head);
+//   mlp3_rows_kernel   grid (MLP, frame): the 3 layers of one MLP for one frame's token row; the row lives in LDS as bf16 and is the B operand of 16x16x32 MFMAs over 16
+//                      weight rows at a time (see mlp_layer; the six weight sets together are 1.5 MB: L2-resident), bias + bf16 rounding + ReLU as the GEMM
+//                      epilogue does, optional sigmoid on the last layer (IoU head);
 //   sam_select_kernel  grid (frame): argmax over the 3 multimask IoUs (first maximum, on the bf16 values the IoU head wrote), the chosen mask token through obj_ptr_proj,
 //                      hard gating against no_obj_ptr by the sign of the object score, and the plane index the bilinear / mask selection kernels take.
 // Latency-bound byte work (nothing here belongs on MFMA).
@@ -28,39 +28,75 @@ struct Mlp3Batch { Mlp3 m[MLP3_MAX]; };
 
 __device__ __forceinline__ float bf16_round(float v) { return bf2f(f2bf(v)); }
 
-// yout[j] = act(bf16(sum_i W[j][i] xin[i] + bias[j])) for j < n_out; xin / yout f32 in LDS
-__device__ __forceinline__ void mlp_layer(const float* xin, int n_in, const unsigned short* W, const unsigned short* bias, int n_out, float* yout, bool relu) {
-    for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
-        const unsigned short* row = W + (long)j * n_in;
-        float acc = 0.f;
-        for (int i = 0; i < n_in; i += 8) {
-            const u32x4 wv = *(const u32x4*)(row + i);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc = fmaf(__uint_as_float(wv[e] << 16), xin[i + 2 * e], acc);
-                acc = fmaf(__uint_as_float(wv[e] & 0xffff0000u), xin[i + 2 * e + 1], acc);
+// yout[j] = act(bf16(sum_i W[j][i] xin[i] + bias[j])) for j < n_out; xin / yout bf16 rows in LDS (a layer's output IS bf16: nothing is lost between layers).
+// The row is the B operand of 16x16x32 MFMAs (every column of the tile carries the same row; column 0 is kept), 16 weight rows the A operand, read straight from L2:
+// a wave instruction touches 16 rows x 64 contiguous bytes and a wave keeps all 8 k-steps of a 16-row tile in flight.  History: a lane per output column walking
+// its own weight row (64 cache lines per load instruction, one load in flight: ~5 us per 256 x 256 layer); rows read by 32 lanes and reduced by shuffles (five
+// dependent ds_bpermute per row: 12 us per layer).
+__device__ __forceinline__ void mlp_layer(const unsigned short* xin, int n_in, const unsigned short* W, const unsigned short* bias, int n_out, unsigned short* yout, bool relu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int nks = (n_in + 31) >> 5;                 // <= 16 (n_in <= 512)
+    for (int n0 = wave * 16; n0 < n_out; n0 += nwave * 16) {
+        const unsigned short* wrow = W + (long)min(n0 + c, n_out - 1) * n_in + 8 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the 4 biases of this lane's outputs travel with the weight fragments (fetched after the products, one 2-byte load at a time, they were 16 dependent L2
+        // round trips per layer -- most of the kernel)
+        u32x2 bb = {0u, 0u};
+        if (bias) {
+            const int b0 = n0 + 4 * g;
+            if (b0 + 3 < n_out && ((((uintptr_t)(bias + b0)) & 7) == 0)) {
+                bb = *(const u32x2*)(bias + b0);
+            } else {
+                unsigned short t4[4] = {0, 0, 0, 0};
+                for (int r = 0; r < 4; ++r) if (b0 + r < n_out) t4[r] = bias[b0 + r];
+                bb = u32x2{(unsigned)t4[0] | ((unsigned)t4[1] << 16), (unsigned)t4[2] | ((unsigned)t4[3] << 16)};
             }
         }
-        float v = bf16_round(acc + (bias ? bf2f(bias[j]) : 0.f));
-        if (relu) v = fmaxf(v, 0.f);
-        yout[j] = v;
+        for (int ks0 = 0; ks0 < nks; ks0 += 8) {
+            bf16x8 af[8], bf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = (ks0 + u) * 32 + 8 * g;
+                u32x4 za = {0u, 0u, 0u, 0u}, zb = {0u, 0u, 0u, 0u};
+                if (k < n_in) {          // n_in % 8 == 0: a chunk lies inside the row or outside
+                    za = *(const u32x4*)(wrow + (ks0 + u) * 32);
+                    zb = *(const u32x4*)(xin + k);
+                }
+                af[u] = __builtin_bit_cast(bf16x8, za);
+                bf[u] = __builtin_bit_cast(bf16x8, zb);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], bf[u], acc, 0, 0, 0);
+        }
+        if (c == 0) {                    // lane (0, g) holds outputs n0 + 4 g .. + 3
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = n0 + 4 * g + r;
+                if (row < n_out) {
+                    float v = bf16_round(acc[r] + __uint_as_float((r & 1) ? (bb[r >> 1] & 0xffff0000u) : (bb[r >> 1] << 16)));
+                    if (relu) v = fmaxf(v, 0.f);
+                    yout[row] = f2bf(v);
+                }
+            }
+        }
     }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void mlp3_rows_kernel(Mlp3Batch P) {
-    __shared__ float bufa[MLP3_MAXDIM], bufb[MLP3_MAXDIM];
+    __shared__ __attribute__((aligned(16))) unsigned short bufa[MLP3_MAXDIM], bufb[MLP3_MAXDIM];
     const Mlp3& m = P.m[blockIdx.x];
     const long b = blockIdx.y;
     const unsigned short* x = m.x + b * m.x_bstride;
-    for (int i = threadIdx.x; i < m.in; i += blockDim.x) bufa[i] = bf2f(x[i]);
+    for (int i = threadIdx.x; i < m.in; i += blockDim.x) bufa[i] = x[i];
     __syncthreads();
     mlp_layer(bufa, m.in, m.w0, m.b0, m.hid, bufb, true);
     mlp_layer(bufb, m.hid, m.w1, m.b1, m.hid, bufa, true);
     mlp_layer(bufa, m.hid, m.w2, m.b2, m.out, bufb, false);
     unsigned short* y = m.y + b * m.y_bstride;
     for (int j = threadIdx.x; j < m.out; j += blockDim.x) {
-        float v = bufb[j];
+        float v = bf2f(bufb[j]);
         if (m.final_act == 1) v = 1.f / (1.f + __expf(-v));
         y[j] = f2bf(v);
     }
@@ -80,7 +116,7 @@ struct SamSelectArgs {
 };
 
 __global__ __launch_bounds__(256) void sam_select_kernel(SamSelectArgs p) {
-    __shared__ float bufa[MLP3_MAXDIM], bufb[MLP3_MAXDIM];
+    __shared__ __attribute__((aligned(16))) unsigned short bufa[MLP3_MAXDIM], bufb[MLP3_MAXDIM];
     const long b = blockIdx.x;
     // first maximum of the three multimask IoUs (torch.argmax returns the first index on ties)
     int best = 0;
@@ -95,13 +131,13 @@ __global__ __launch_bounds__(256) void sam_select_kernel(SamSelectArgs p) {
         p.sel[b] = (int)(b * 4 + 1 + best);
     }
     const unsigned short* tok = p.toks + b * p.tok_bstride + (long)(1 + best) * p.C;      // multimask token 1 + best
-    for (int i = threadIdx.x; i < p.C; i += blockDim.x) bufa[i] = bf2f(tok[i]);
+    for (int i = threadIdx.x; i < p.C; i += blockDim.x) bufa[i] = tok[i];
     __syncthreads();
     mlp_layer(bufa, p.C, p.w0, p.b0, p.C, bufb, true);
     mlp_layer(bufb, p.C, p.w1, p.b1, p.C, bufa, true);
     mlp_layer(bufa, p.C, p.w2, p.b2, p.C, bufb, false);
     const bool is_obj = bf2f(p.obj[b]) > 0.f;
-    for (int j = threadIdx.x; j < p.C; j += blockDim.x) p.obj_ptr[b * p.C + j] = is_obj ? f2bf(bufb[j]) : p.no_obj_ptr[j];
+    for (int j = threadIdx.x; j < p.C; j += blockDim.x) p.obj_ptr[b * p.C + j] = is_obj ? bufb[j] : p.no_obj_ptr[j];
 }
 
 }  // namespace rga3

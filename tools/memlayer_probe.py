@@ -73,6 +73,9 @@ def main():
     for (m_, n_, k_) in ((9, 256, 256), (9, 2048, 256), (9, 256, 2048)):
         ta, tw, tb = r(m_, k_), r(n_, k_, sc=0.05), r(n_)
         print(f"token rows {m_} x {n_} x {k_}: tile 41 {t_us(lambda: ops.gemm(ta, tw, tb, tile=41)):6.1f} us   128 x 128 tiles {t_us(lambda: ops.gemm(ta, tw, tb, tile=12)):6.1f} us")
+    mw = [(r(256, 256, sc=0.06), r(256, sc=0.1), r(256, 256, sc=0.06), r(256, sc=0.1), r(32, 256, sc=0.06), r(32, sc=0.1)) for _ in range(6)]
+    toks = r(1, 9, 256)
+    print(f"six 3-layer MLPs on token rows (mlp3_rows): {t_us(lambda: ops.mlp3_rows([(toks[0, i], 9 * 256, mw[i], False) for i in range(6)], 1)):7.1f} us")
     dx, dw_, db = r(4096, 256), r(256, 1, 7, 7, sc=0.1), r(256, sc=0.1)
     print(f"dwconv 7x7, 64 x 64 x 256   : {t_us(lambda: ops.dwconv7x7(dx, dw_, db, 1, 64, 64)):7.1f} us")
     print(f"cross attention             : partials only {t_us(lambda: ops.memattn_cross(qq, kk, mm, 256 ** -0.5, partials=True)):7.1f} us   with merge {t_us(lambda: ops.memattn_cross(qq, kk, mm, 256 ** -0.5)):7.1f} us")
