@@ -176,6 +176,14 @@ int rga3_bilinear(const void* in, int in_dtype, float* out, const int32_t* plane
  * (model/sam2.py:3017-3022 + MaskDownSampler :611-643) */
 int rga3_conv3x3s2(const void* x, int x_dtype, const void* w, const void* bias, void* y, int64_t F, int H, int W, int Cin, int Cout,
                    float sig_scale, float sig_bias, void* stream);
+/* The image side of a two-way-transformer block boundary of the mask decoder in ONE launch (csrc/decimg.hip), for reference model/sam2.py:1926-2100
+ * (TwoWayAttentionBlock.forward: cross_attn_image_to_token + norm4, then the next cross_attn_token_to_image's k / v projections, Attention :1417-1481):
+ *   keys' [M, 256] = LayerNorm(bf16(bf16(attn((keys + pe) Wq^T + bq; kt, vt) Wo^T + bo) + keys)),   k2 = (keys' + pe) Wk2^T + bk2,  v2 = keys' Wv2^T + bv2  [M, 128]
+ * with attn = 8 heads x 16 over the nk (<= 16) tokens of the row's frame (frame = row / hw, hw >= 16), kt / vt [frames * nk, 128] the token-side keys / values already
+ * projected, pe [hw, 256] broadcast over frames.  wk2 = wv2 = NULL: only keys'.  Strides in elements. */
+int rga3_decimg_rows(const void* keys, int64_t keys_stride, const void* pe, int64_t pe_stride, int hw, const void* kt, const void* vt, int nk, const void* wq, const void* bq,
+                     const void* wo, const void* bo, const void* ln_w, const void* ln_b, float eps, const void* wk2, const void* bk2, const void* wv2, const void* bv2,
+                     void* keys_out, int64_t keys_out_stride, void* k2, void* v2, int64_t kv_stride, float scale, int64_t M, void* stream);
 /* n (<= 24) device-to-device copies in one launch (dst[i] <- src[i], bytes[i] bytes: multiples of 16, 16-byte aligned pointers, no overlap; the three arrays are HOST
  * arrays).  The copies a video-session frame makes around its captured graph (reference model/sam2.py:2829-2989 builds the bank with torch.cat / index ops per frame). */
 int rga3_copy_many(void* const* dst, const void* const* src, const int64_t* bytes, int n, void* stream);

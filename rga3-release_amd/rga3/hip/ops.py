@@ -443,6 +443,30 @@ def bilinear(x, size, plane_idx=None):
 _conv_pack = {}
 
 
+def decimg_rows(keys, pe, kt, vt, nk: int, q_proj, out_proj, norm, eps: float, k_next=None, v_next=None, scale: float = 0.25):
+    """The image side of a mask-decoder block boundary in one launch (csrc/decimg.hip): keys [M, 256], pe [hw, 256] (broadcast over frames), kt / vt [frames * nk, 128]
+    token-side keys / values (projected), q_proj / out_proj / k_next / v_next = (weight, bias) pairs, norm = (weight, bias).  -> (keys', k2, v2) (k2 = v2 = None
+    without k_next / v_next)."""
+    _need_cuda(keys, pe, kt, vt, *q_proj, *out_proj, *norm)
+    assert keys.dtype == torch.bfloat16 and keys.dim() == 2 and keys.shape[1] == 256 and keys.stride(1) == 1 and pe.shape[1] == 256 and pe.stride(1) == 1
+    M, hw = keys.shape[0], pe.shape[0]
+    assert M % hw == 0 and hw >= 16 and 1 <= nk <= 16 and kt.is_contiguous() and vt.is_contiguous() and tuple(kt.shape) == tuple(vt.shape) == (M // hw * nk, 128)
+    (wq, bq), (wo, bo), (gw, gb) = q_proj, out_proj, norm
+    assert tuple(wq.shape) == (128, 256) and tuple(wo.shape) == (256, 128) and wq.is_contiguous() and wo.is_contiguous()
+    out = torch.empty((M, 256), dtype=torch.bfloat16, device=keys.device)
+    k2 = v2 = None
+    wk2 = bk2 = wv2 = bv2 = None
+    if k_next is not None:
+        (wk2, bk2), (wv2, bv2) = k_next, v_next
+        assert tuple(wk2.shape) == tuple(wv2.shape) == (128, 256) and wk2.is_contiguous() and wv2.is_contiguous()
+        k2 = torch.empty((M, 128), dtype=torch.bfloat16, device=keys.device)
+        v2 = torch.empty((M, 128), dtype=torch.bfloat16, device=keys.device)
+    _lib.check(_lib.load().rga3_decimg_rows(keys.data_ptr(), keys.stride(0), pe.data_ptr(), pe.stride(0), hw, kt.data_ptr(), vt.data_ptr(), int(nk), wq.data_ptr(), _ptr(bq),
+                                            wo.data_ptr(), _ptr(bo), gw.data_ptr(), _ptr(gb), float(eps), _ptr(wk2), _ptr(bk2), _ptr(wv2), _ptr(bv2), out.data_ptr(), 256,
+                                            _ptr(k2), _ptr(v2), 128, float(scale), M, _stream()), "decimg_rows")
+    return out, k2, v2
+
+
 def copy_many(pairs):
     """[(dst, src), ...] dense tensors of equal byte size -> dst[i] <- src[i], 24 copies per launch (csrc/sam2ops.hip copy_many); pairs that are not 16-byte
     shaped / aligned go through Tensor.copy_."""

@@ -469,3 +469,67 @@ def test_dwconv7x7_tiled(dev, Fn, H, W, C):
     off = torch.zeros(8 + C * 49, dtype=torch.bfloat16, device=dev)      # a filter that does not start on a 16-byte boundary
     off[3:3 + C * 49] = w.reshape(-1)
     assert torch.equal(out, ops.dwconv7x7(x, off[3:3 + C * 49].view(C, 1, 7, 7), b, Fn, H, W))
+
+
+@pytest.mark.parametrize("B,hw,nk", [(1, 4096, 9), (3, 24, 9), (2, 40, 16), (1, 16, 1)])
+def test_decoder_image_side_block_boundary(dev, B, hw, nk):
+    """csrc/decimg.hip: image-to-token attention + norm4 + the next token-to-image k / v projections in one launch, against the eight launches it replaces (add_bcast,
+    q_proj, the attention kernel, out_proj + residual, LayerNorm, add_bcast, k_proj, v_proj) and against fp32 torch on the same bf16 operands -- a whole 64 x 64 frame,
+    several small frames whose 16-row blocks straddle a frame boundary, the maximum token count, a single token."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(B * 100 + hw + nk)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16).to(dev)
+    M = B * hw
+    keys, pe = (torch.randn(M, 256, generator=g) * 1.2 + 0.3 * torch.randn(M, 1, generator=g)).to(torch.bfloat16).to(dev), r(hw, 256, sc=0.5)
+    kt, vt = r(B * nk, 128), r(B * nk, 128)
+    wq, bq, wo, bo = r(128, 256, sc=0.06), r(128, sc=0.1), r(256, 128, sc=0.09), r(256, sc=0.1)
+    gam, bet = (1 + 0.2 * torch.randn(256, generator=g)).to(torch.bfloat16).to(dev), r(256, sc=0.1)
+    wk, bk, wv, bv = r(128, 256, sc=0.06), r(128, sc=0.1), r(128, 256, sc=0.06), r(128, sc=0.1)
+    out, k2, v2 = ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, (wk, bk), (wv, bv), scale=0.25)
+    # the launches replaced
+    kin = ops.add_bcast(keys, pe)
+    qp = ops.gemm(kin, wq, bq)
+    cuq = torch.arange(0, M + 1, hw, dtype=torch.int32, device=dev)
+    cuk = torch.arange(0, B * nk + 1, nk, dtype=torch.int32, device=dev)
+    o = ops.attn_varlen(qp.view(-1, 8, 16), kt.view(-1, 8, 16), vt.view(-1, 8, 16), cuq, cuk, hw, 0.25, max_k=nk)
+    x_un = ops.layernorm(ops.gemm(o.reshape(-1, 128), wo, bo, residual=keys), gam, bet, 1e-5)
+    k_un, v_un = ops.gemm(ops.add_bcast(x_un, pe), wk, bk), ops.gemm(x_un, wv, bv)
+    assert rel(out, x_un) < 4e-3 and rel(k2, k_un) < 6e-3 and rel(v2, v_un) < 6e-3, (rel(out, x_un), rel(k2, k_un), rel(v2, v_un))
+    # fp32
+    f = lambda t: t.float().cpu()
+    pe_rows = f(pe).repeat(B, 1)
+    qf_ = (F.linear(f(keys) + pe_rows, f(wq), f(bq))).view(B, hw, 8, 16).permute(0, 2, 1, 3)
+    kf_, vf_ = f(kt).view(B, nk, 8, 16).permute(0, 2, 1, 3), f(vt).view(B, nk, 8, 16).permute(0, 2, 1, 3)
+    of_ = torch.softmax(qf_ @ kf_.transpose(-1, -2) * 0.25, dim=-1) @ vf_
+    xr = F.layer_norm(F.linear(of_.permute(0, 2, 1, 3).reshape(M, 128), f(wo), f(bo)) + f(keys), (256,), f(gam), f(bet), 1e-5)
+    assert rel(out, xr) < 1.5e-2, rel(out, xr)
+    assert rel(k2, F.linear(xr + pe_rows, f(wk), f(bk))) < 2e-2 and rel(v2, F.linear(xr, f(wv), f(bv))) < 2e-2
+    only, n1, n2 = ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, scale=0.25)
+    assert n1 is None and n2 is None and torch.equal(only, out)
+    assert torch.equal(out, ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, (wk, bk), (wv, bv), scale=0.25)[0])
+
+
+def test_two_way_transformer_fused_image_side_matches_separate_launches(dev):
+    """The mask decoder's two-way transformer at SAM2-L dims (4096 image tokens, 9 tokens): the path with the one-launch image side against the per-launch path."""
+    from rga3.model import sam2 as S2
+
+    torch.manual_seed(5)
+    tr = S2.TwoWayTransformer(2, 256, 8, 2048).to(torch.bfloat16).to(dev).eval()
+    with torch.no_grad():
+        for p_ in tr.parameters():
+            if p_.dim() >= 2:
+                p_.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(6)
+    keys = torch.randn(4096, 256, generator=g).to(torch.bfloat16).to(dev)
+    pe = (torch.randn(4096, 256, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    toks = torch.randn(9, 256, generator=g).to(torch.bfloat16).to(dev)
+    with torch.no_grad():
+        assert tr._fusable(keys, pe, 9)
+        q1, k1 = tr(keys, pe, toks, 1, 9, 4096)
+        S2._DECIMG = False
+        try:
+            q0, k0 = tr(keys, pe, toks, 1, 9, 4096)
+        finally:
+            S2._DECIMG = True
+    assert rel(q1, q0) < 1e-2 and rel(k1, k0) < 1e-2, (rel(q1, q0), rel(k1, k0))
