@@ -84,7 +84,7 @@ __device__ __forceinline__ void mlp_layer(const unsigned short* xin, int n_in, c
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void mlp3_rows_kernel(Mlp3Batch P) {
+__global__ __launch_bounds__(1024) void mlp3_rows_kernel(Mlp3Batch P) {
     __shared__ __attribute__((aligned(16))) unsigned short bufa[MLP3_MAXDIM], bufb[MLP3_MAXDIM];
     const Mlp3& m = P.m[blockIdx.x];
     const long b = blockIdx.y;
@@ -115,7 +115,7 @@ struct SamSelectArgs {
     int C;
 };
 
-__global__ __launch_bounds__(256) void sam_select_kernel(SamSelectArgs p) {
+__global__ __launch_bounds__(1024) void sam_select_kernel(SamSelectArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short bufa[MLP3_MAXDIM], bufb[MLP3_MAXDIM];
     const long b = blockIdx.x;
     // first maximum of the three multimask IoUs (torch.argmax returns the first index on ties)
@@ -165,7 +165,8 @@ extern "C" int rga3_mlp3_rows(const void* const* ptrs, const int64_t* dims, int 
                        "mlp3_rows: dims %d -> %d -> %d (inputs multiples of 8, all <= 512)", m.in, m.hid, m.out);
         RGA3_CHECK_ARG((((uintptr_t)m.w0 | (uintptr_t)m.w1 | (uintptr_t)m.w2) & 15) == 0, "mlp3_rows: weights must be 16-byte aligned");
     }
-    hipLaunchKernelGGL(mlp3_rows_kernel, dim3((unsigned)n, (unsigned)B), dim3(256), 0, (hipStream_t)stream, P);
+    // 16 waves: a 256-wide layer is one 16-row tile per wave, so a layer costs one L2 round trip instead of four in a row
+    hipLaunchKernelGGL(mlp3_rows_kernel, dim3((unsigned)n, (unsigned)B), dim3(1024), 0, (hipStream_t)stream, P);
     RGA3_CHECK_LAUNCH("mlp3_rows_kernel");
     return 0;
 }
@@ -180,7 +181,7 @@ extern "C" int rga3_sam_select_objptr(const void* iou, const void* obj, const vo
     a.w0 = (const unsigned short*)w0; a.b0 = (const unsigned short*)b0; a.w1 = (const unsigned short*)w1; a.b1 = (const unsigned short*)b1;
     a.w2 = (const unsigned short*)w2; a.b2 = (const unsigned short*)b2; a.no_obj_ptr = (const unsigned short*)no_obj_ptr;
     a.best = (long long*)best; a.sel = sel; a.obj_ptr = (unsigned short*)obj_ptr; a.tok_bstride = tok_bstride; a.C = C;
-    hipLaunchKernelGGL(sam_select_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sam_select_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, a);
     RGA3_CHECK_LAUNCH("sam_select_kernel");
     return 0;
 }
