@@ -259,6 +259,11 @@ int rga3_memlayer_rows(const void* a, int64_t a_stride, int K1, const float* par
                        const void* res, int64_t res_stride, void* x_out, int64_t x_stride, const void* ln_w, const void* ln_b, float eps, void* t_out,
                        int64_t t_stride, const void* w2, const void* b2, int N2, void* y_out, int64_t y_stride, const float* cos, const float* sin,
                        int rope_cols, int nq, int64_t M, void* stream);
+/* n (<= 4) token-row products (M <= 16 rows each, as tile 41) in ONE launch, each optionally on the SUM of two row operands: the token side of reference
+ * model/sam2.py:1926-2100 (TwoWayAttentionBlock.forward: q = queries + query_pe, then q_proj(q) / k_proj(q) / v_proj(queries) of the same attention are independent
+ * nn.Linear calls).  ptrs: n x 6 {A, A2 or NULL, W, bias or NULL, residual or NULL, C}; dims: n x 9 {M, N, K, act (0 none / 1 gelu / 3 relu), lda, lda2, ldw, ldc, ldr}.
+ * A + A2 is rounded to bf16 before the product.  HOST arrays. */
+int rga3_gemm_rows16_many(const void* const* ptrs, const int64_t* dims, int n, void* stream);
 /* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up in launches that used this workspace (expected 0;
  * < 0 = error); synchronises the device */
 int rga3_gemm_stream_k_timeouts(const void* workspace);

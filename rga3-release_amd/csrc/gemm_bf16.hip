@@ -1508,6 +1508,73 @@ __global__ __launch_bounds__(64 * R16_NW) void gemm_rows16_kernel(GemmArgs p) {
     }
 }
 
+// Several token-row products in ONE launch, each optionally on the SUM of two row operands (rga3_gemm_rows16_many): the token side of a two-way block issues its
+// q / k / v projections of (tokens + positional tokens) and of the tokens as 2 - 3 separate products behind an elementwise add each -- here grid.y picks the product
+// and the add happens while the rows are loaded (rounded to bf16 as the add kernel rounds).
+constexpr int R16_MAXSETS = 4;
+struct Rows16Set {
+    const unsigned short *A, *A2, *W, *bias, *res;
+    unsigned short* C;
+    int M, N, K, act;
+    long lda, lda2, ldw, ldc, ldr;
+};
+struct Rows16Many { Rows16Set s[R16_MAXSETS]; };
+
+__global__ __launch_bounds__(64 * R16_NW) void gemm_rows16_many_kernel(Rows16Many P) {
+    __shared__ f32x4 red[R16_NW][64];
+    const Rows16Set& p = P.s[blockIdx.y];
+    const int n0 = blockIdx.x * 16;
+    if (n0 >= p.N) return;                       // (uniform per workgroup: no barrier is skipped by part of it)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const unsigned short* arow = p.W + (long)min(n0 + c, p.N - 1) * p.ldw + g * 8;
+    const unsigned short* brow = p.A + (long)min(c, p.M - 1) * p.lda + g * 8;
+    const unsigned short* brow2 = p.A2 ? p.A2 + (long)min(c, p.M - 1) * p.lda2 + g * 8 : nullptr;
+    const int nks = (p.K + 31) >> 5;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks0 = w; ks0 < nks; ks0 += R16_NW * R16_U) {
+        bf16x8 af[R16_U], bf[R16_U];
+#pragma unroll
+        for (int u = 0; u < R16_U; ++u) {
+            const int k = (ks0 + u * R16_NW) * 32 + g * 8;
+            u32x4 za = {0u, 0u, 0u, 0u}, zb = {0u, 0u, 0u, 0u};
+            if (k < p.K) {
+                za = *(const u32x4*)(arow + (ks0 + u * R16_NW) * 32);
+                zb = *(const u32x4*)(brow + (ks0 + u * R16_NW) * 32);
+                if (brow2) {
+                    const u32x4 z2 = *(const u32x4*)(brow2 + (ks0 + u * R16_NW) * 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        zb[e] = pack_bf2(__uint_as_float(zb[e] << 16) + __uint_as_float(z2[e] << 16), __uint_as_float(zb[e] & 0xffff0000u) + __uint_as_float(z2[e] & 0xffff0000u));
+                }
+            }
+            af[u] = __builtin_bit_cast(bf16x8, za);
+            bf[u] = __builtin_bit_cast(bf16x8, zb);
+        }
+#pragma unroll
+        for (int u = 0; u < R16_U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u], bf[u], acc, 0, 0, 0);
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w != 0) return;
+    f32x4 v = red[0][lane];
+#pragma unroll
+    for (int i = 1; i < R16_NW; ++i) v += red[i][lane];
+    const int col = n0 + 4 * g;
+    if (c >= p.M || col >= p.N) return;
+    unsigned short* dst = p.C + (long)c * p.ldc + col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (col + r >= p.N) break;
+        float x = v[r];
+        if (p.bias) x += bf2f(p.bias[col + r]);
+        if (p.act == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
+        if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+        if (p.res) x = bf2f(f2bf(x)) + bf2f(p.res[(long)c * p.ldr + col + r]);
+        dst[r] = f2bf(x);
+    }
+}
+
 template <int ACT, bool OUT_F32>
 static int launch_rows16(const GemmArgs& a, hipStream_t st) {
     if constexpr (OUT_F32 || ACT == ACT_SWIGLU) {
@@ -1572,6 +1639,31 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
 }  // namespace rga3
 
 using namespace rga3;
+
+// n (<= 4) token-row products (M <= 16 rows each) in one launch: C_i [M_i, N_i] bf16 = act_i((A_i (+ A2_i)) W_i^T + bias_i) (+ residual_i).  ptrs: n x 6 pointers
+// {A, A2 or NULL, W, bias or NULL, residual or NULL, C}; dims: n x 9 {M, N, K, act, lda, lda2, ldw, ldc, ldr} (elements; K and the A / W strides multiples of 8).
+// A + A2 is rounded to bf16 before the product (what a separate add launch would have written).  HOST arrays.
+extern "C" int rga3_gemm_rows16_many(const void* const* ptrs, const int64_t* dims, int n, void* stream) {
+    RGA3_CHECK_ARG(ptrs && dims && n >= 1 && n <= R16_MAXSETS, "gemm_rows16_many: n %d (1..%d)", n, R16_MAXSETS);
+    Rows16Many P;
+    int64_t maxn = 0;
+    for (int i = 0; i < n; ++i) {
+        Rows16Set& s = P.s[i];
+        const void* const* q = ptrs + 6 * i;
+        const int64_t* d = dims + 9 * i;
+        s.A = (const unsigned short*)q[0]; s.A2 = (const unsigned short*)q[1]; s.W = (const unsigned short*)q[2]; s.bias = (const unsigned short*)q[3];
+        s.res = (const unsigned short*)q[4]; s.C = (unsigned short*)q[5];
+        s.M = (int)d[0]; s.N = (int)d[1]; s.K = (int)d[2]; s.act = (int)d[3]; s.lda = d[4]; s.lda2 = d[5]; s.ldw = d[6]; s.ldc = d[7]; s.ldr = d[8];
+        RGA3_CHECK_ARG(s.A && s.W && s.C && s.M >= 1 && s.M <= 16 && s.N >= 1 && s.K >= 8 && s.K % 8 == 0, "gemm_rows16_many: set %d: M %d (1..16), N %d, K %d", i, s.M, s.N, s.K);
+        RGA3_CHECK_ARG(s.lda % 8 == 0 && s.ldw % 8 == 0 && (!s.A2 || s.lda2 % 8 == 0), "gemm_rows16_many: set %d: strides must be multiples of 8", i);
+        RGA3_CHECK_ARG((((uintptr_t)s.A | (uintptr_t)s.A2 | (uintptr_t)s.W) & 15) == 0, "gemm_rows16_many: set %d: 16-byte alignment", i);
+        RGA3_CHECK_ARG(s.act == ACT_NONE || s.act == ACT_GELU || s.act == ACT_RELU, "gemm_rows16_many: set %d: act %d", i, s.act);
+        if (s.N > maxn) maxn = s.N;
+    }
+    hipLaunchKernelGGL(gemm_rows16_many_kernel, dim3((unsigned)cdiv(maxn, 16), (unsigned)n), dim3(64 * R16_NW), 0, (hipStream_t)stream, P);
+    RGA3_CHECK_LAUNCH("gemm_rows16_many_kernel");
+    return 0;
+}
 
 // Bytes of workspace rga3_gemm_bf16 wants on the current device for tiles 22 / 25 (0 on error).
 extern "C" int64_t rga3_gemm_workspace_bytes(void) {

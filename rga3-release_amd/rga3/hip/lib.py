@@ -58,6 +58,7 @@ SIGNATURES = {
     "rga3_memattn_cross_ws_floats": [_i64, _i],
     "rga3_memattn_cross": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _p, _p],
     "rga3_memlayer_rows": [_p, _i64, _i, _p, _p, _i, _p, _p, _p, _i64, _p, _i64, _p, _p, _f, _p, _i64, _p, _p, _i, _p, _i64, _p, _p, _i, _i, _i64, _p],
+    "rga3_gemm_rows16_many": [_p, _p, _i, _p],
     "rga3_gemm_stream_k_timeouts": [_p],
     "rga3_gemm_timeout_counter_offset": [],
     "rga3_quant_fp8_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],

@@ -116,6 +116,33 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     return out
 
 
+def gemm_rows16_many(sets):
+    """Up to 4 token-row products (M <= 16) in one launch (csrc/gemm_bf16.hip gemm_rows16_many_kernel).  sets: list of (a, a2 or None, weight, bias or None[, residual
+    [, act]]): out_i = act((a + a2) @ weight.T + bias) (+ residual), a + a2 rounded to bf16 first.  -> list of [M, N] bf16."""
+    import ctypes
+    n = len(sets)
+    assert 1 <= n <= 4
+    ptrs, dims, outs = (ctypes.c_void_p * (6 * n))(), (ctypes.c_int64 * (9 * n))(), []
+    for i, st in enumerate(sets):
+        a, a2, w, b = st[:4]
+        res = st[4] if len(st) > 4 else None
+        act = st[5] if len(st) > 5 else "none"
+        _need_cuda(a, a2, w, b, res)
+        assert a.dtype == w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.stride(1) == 1 and w.stride(1) == 1
+        M, K = a.shape
+        N = w.shape[0]
+        assert M <= 16 and K % 8 == 0 and (a2 is None or (a2.shape == a.shape and a2.stride(1) == 1 and a2.dtype == torch.bfloat16))
+        assert b is None or (b.numel() == N and b.is_contiguous()) and (res is None or (tuple(res.shape) == (M, N) and res.stride(1) == 1))
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        outs.append(out)
+        for j, t in enumerate((a, a2, w, b, res, out)):
+            ptrs[6 * i + j] = _ptr(t) or None
+        for j, v in enumerate((M, N, K, ACT[act], a.stride(0), a2.stride(0) if a2 is not None else 0, w.stride(0), N, res.stride(0) if res is not None else 0)):
+            dims[9 * i + j] = int(v)
+    _lib.check(_lib.load().rga3_gemm_rows16_many(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dims, ctypes.c_void_p), n, _stream()), "gemm_rows16_many")
+    return outs
+
+
 def layernorm_stats(x, eps: float):
     """[rows, 2] f32 = (mean, 1/sqrt(var + eps)) of the rows of x [rows, dim] bf16 (row stride free): the input of gemm_ln."""
     _need_cuda(x)

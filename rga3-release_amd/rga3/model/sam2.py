@@ -385,11 +385,10 @@ class Attention(nn.Module):
             o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5, max_k=nk)
         return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
 
-    def forward_projected(self, q, kp, vp, B, nq, nk, residual=None):
-        """forward() with the keys / values already projected (kp, vp [B*nk, internal_dim])."""
+    def attend(self, qp, kp, vp, B, nq, nk, residual=None):
+        """softmax(QK^T)V + out_proj on projections that already exist (qp [B*nq, internal_dim], kp / vp [B*nk, internal_dim])."""
         H, hd = self.num_heads, self.internal_dim // self.num_heads
-        qp = _lin(self.q_proj, q)
-        o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5, max_k=nk)
+        o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, qp.device), _cu(B, nk, qp.device), nq, hd ** -0.5, max_k=nk)
         return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
 
 
@@ -433,22 +432,22 @@ class TwoWayAttentionBlock(nn.Module):
     def forward_fused(self, queries, keys, query_pe, key_pe, B, nq, nk, kp, vp, nxt):
         """Inference form: the token side as above; the image side of the block's end -- image-to-token attention, norm4 and the NEXT token-to-image attention's
         k / v projections -- in one launch (csrc/decimg.hip).  kp / vp: this block's token-to-image keys / values if the previous block already produced them."""
-        if self.skip_first_layer_pe:
-            queries = self.self_attn(queries, queries, queries, B, nq, nq)
-        else:
-            q = _add(queries, query_pe)
-            queries = self.self_attn(q, q, queries, B, nq, nq, residual=queries)
+        # token side: the projections of one attention are independent products of (tokens + positional tokens) / tokens -- one launch per attention, the sum
+        # taken while the rows are loaded (csrc/gemm_bf16.hip gemm_rows16_many_kernel)
+        sa, t2i, i2t = self.self_attn, self.cross_attn_token_to_image, self.cross_attn_image_to_token
+        lin = lambda m_: (m_.weight, m_.bias)
+        pe_ = None if self.skip_first_layer_pe else query_pe
+        qp, kp_, vp_ = ops.gemm_rows16_many([(queries, pe_) + lin(sa.q_proj), (queries, pe_) + lin(sa.k_proj), (queries, None) + lin(sa.v_proj)])
+        queries = sa.attend(qp, kp_, vp_, B, nq, nq, residual=None if self.skip_first_layer_pe else queries)
         queries = self.norm1(queries)
-        q = _add(queries, query_pe)
-        t2i = self.cross_attn_token_to_image
         if kp is None:
             kp, vp = t2i.k_proj(_add_bcast(keys, key_pe)), t2i.v_proj(keys)
-        queries = self.norm2(t2i.forward_projected(q, kp, vp, B, nq, nk, residual=queries))
+        (qp,) = ops.gemm_rows16_many([(queries, query_pe) + lin(t2i.q_proj)])
+        queries = self.norm2(t2i.attend(qp, kp, vp, B, nq, nk, residual=queries))
         queries = self.norm3(self.mlp(queries, residual=queries))
-        q = _add(queries, query_pe)
-        i2t = self.cross_attn_image_to_token
+        kt, vt = ops.gemm_rows16_many([(queries, query_pe) + lin(i2t.k_proj), (queries, None) + lin(i2t.v_proj)])
         hd = i2t.internal_dim // i2t.num_heads
-        keys, kp2, vp2 = ops.decimg_rows(keys, key_pe, i2t.k_proj(q), i2t.v_proj(queries), nq, (i2t.q_proj.weight, i2t.q_proj.bias),
+        keys, kp2, vp2 = ops.decimg_rows(keys, key_pe, kt, vt, nq, (i2t.q_proj.weight, i2t.q_proj.bias),
                                          (i2t.out_proj.weight, i2t.out_proj.bias), (self.norm4.weight, self.norm4.bias), self.norm4.eps,
                                          (nxt.k_proj.weight, nxt.k_proj.bias), (nxt.v_proj.weight, nxt.v_proj.bias), scale=hd ** -0.5)
         return queries, keys, kp2, vp2
@@ -461,25 +460,30 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = Attention(dim, heads, downsample_rate=2)
         self.norm_final_attn = NormParams(dim, 1e-5)
 
-    def _fusable(self, keys, key_pe, nq):
+    def _fusable(self, keys, key_pe, nq, B=1):
         """The one-launch image side (csrc/decimg.hip): inference, plain projections, SAM2's decoder geometry (256 wide, 128 internal = 8 heads x 16)."""
         a = self.final_attn_token_to_image
         mods = [a.k_proj, a.v_proj]
         for l in self.layers:
             mods += [l.cross_attn_image_to_token.q_proj, l.cross_attn_image_to_token.out_proj, l.cross_attn_token_to_image.k_proj, l.cross_attn_token_to_image.v_proj]
-        return (_DECIMG and not _ag() and keys.shape[1] == 256 and a.internal_dim == 128 and a.num_heads == 8 and nq <= 16 and key_pe.shape[0] >= 16
+        for l in self.layers:
+            mods += [l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj, l.cross_attn_token_to_image.q_proj, l.cross_attn_image_to_token.k_proj,
+                     l.cross_attn_image_to_token.v_proj]
+        mods.append(a.q_proj)
+        return (_DECIMG and not _ag() and keys.shape[1] == 256 and a.internal_dim == 128 and a.num_heads == 8 and B * nq <= 16 and key_pe.shape[0] >= 16
                 and all(l.cross_attn_image_to_token.internal_dim == 128 and l.cross_attn_image_to_token.num_heads == 8 for l in self.layers)
                 and not any(hasattr(m_, "lora_A") for m_ in mods))
 
     def forward(self, keys, key_pe, tokens, B, nq, nk):
         queries, query_pe = tokens, tokens
-        if self._fusable(keys, key_pe, nq):
+        if self._fusable(keys, key_pe, nq, B):
             kp = vp = None          # the image-side k / v of the next token-to-image attention, produced by the previous block's fused tail
             for li, layer in enumerate(self.layers):
                 nxt = self.layers[li + 1].cross_attn_token_to_image if li + 1 < len(self.layers) else self.final_attn_token_to_image
                 queries, keys, kp, vp = layer.forward_fused(queries, keys, query_pe, key_pe, B, nq, nk, kp, vp, nxt)
-            q = _add(queries, query_pe)
-            queries = self.norm_final_attn(self.final_attn_token_to_image.forward_projected(q, kp, vp, B, nq, nk, residual=queries))
+            fa = self.final_attn_token_to_image
+            (qp,) = ops.gemm_rows16_many([(queries, query_pe, fa.q_proj.weight, fa.q_proj.bias)])
+            queries = self.norm_final_attn(fa.attend(qp, kp, vp, B, nq, nk, residual=queries))
             return queries, keys
         for layer in self.layers:
             queries, keys = layer(queries, keys, query_pe, key_pe, B, nq, nk)

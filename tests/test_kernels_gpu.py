@@ -563,3 +563,23 @@ def test_gemm_token_rows(dev, M, N, K, act):
     buf = torch.zeros((M, N + 8), dtype=torch.bfloat16, device=dev)                        # strided output view
     ops.gemm(a, w, bias=bias, out=buf[:, :N], tile=41)
     assert torch.equal(buf[:, :N], ops.gemm(a, w, bias=bias, tile=41)) and float(buf[:, N:].abs().max()) == 0.0
+
+
+def test_gemm_token_rows_grouped_with_operand_sum(dev):
+    """gemm_rows16_many: several token-row products in one launch, some on the sum of two row operands (rounded to bf16 first, as a separate add launch would), mixed
+    shapes / activations / residuals -- each equal, bit for bit, to tile 41 on the pre-added operand."""
+    from rga3.hip import ops
+
+    a, pe = _rand((9, 256), dev, seed=1), _rand((9, 256), dev, 0.5, seed=2)
+    a5 = _rand((5, 2048), dev, seed=3)
+    w1, b1 = _rand((256, 256), dev, 0.05, seed=4), _rand((256,), dev, 0.5, seed=5)
+    w2, b2 = _rand((128, 256), dev, 0.05, seed=6), _rand((128,), dev, 0.5, seed=7)
+    w3 = _rand((250, 2048), dev, 0.05, seed=8)
+    res = _rand((9, 256), dev, seed=9)
+    outs = ops.gemm_rows16_many([(a, pe, w1, b1), (a, None, w2, b2, None, "relu"), (a5, None, w3, None, None, "gelu"), (a, pe, w1, b1, res)])
+    apre = ops.add(a, pe)
+    assert torch.equal(outs[0], ops.gemm(apre, w1, b1, tile=41))
+    assert torch.equal(outs[1], ops.gemm(a, w2, b2, act="relu", tile=41))
+    assert torch.equal(outs[2], ops.gemm(a5, w3, act="gelu", tile=41))
+    assert torch.equal(outs[3], ops.gemm(apre, w1, b1, residual=res, tile=41))
+    assert _rel_l2(outs[0], R.linear_ref((a.float() + pe.float()).to(torch.bfloat16).cpu(), w1.cpu(), b1.cpu())) < 6e-3
