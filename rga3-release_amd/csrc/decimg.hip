@@ -27,7 +27,8 @@ struct DecImgArgs {
     const unsigned short *ln_w, *ln_b; float eps;  // norm4
     const unsigned short *wk2, *bk2, *wv2, *bv2;   // the NEXT token-to-image attention's k_proj / v_proj [128, 256] (null: not wanted)
     unsigned short* keys_out; long ko_st;          // [M, 256]
-    unsigned short *k2, *v2; long kv_st;           // [M, 128] each
+    unsigned short *k2, *v2; long kv_st;           // [M, 128] each; v2_t != 0: v2 is written TRANSPOSED, [frames * 128, hw] (what rga3_attn_fewq reads)
+    int v2_t;
     float scale_log2;
     int M;
 };
@@ -217,18 +218,144 @@ __global__ __launch_bounds__(512) void decimg_rows_kernel(DecImgArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[ks], *(const bf16x8*)(ta + c * DI_STR + ks * 64 + g * 16), ak, 0, 0, 0);
-            av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[ks], *(const bf16x8*)(tb + c * DI_STR + ks * 64 + g * 16), av, 0, 0, 0);
+            // (both fragments have the same per-lane shape -- row c, k-chunk g -- so swapping them transposes the result: lane (c, g) then holds weight column c,
+            //  tokens 4 g .. 4 g + 3)
+            if (p.v2_t) av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(tb + c * DI_STR + ks * 64 + g * 16), fv[ks], av, 0, 0, 0);
+            else av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[ks], *(const bf16x8*)(tb + c * DI_STR + ks * 64 + g * 16), av, 0, 0, 0);
+        }
+        if (p.v2_t) {      // rows of v2^T: (frame, column 16 w + c), 4 consecutive tokens per lane; the block lies in one frame (hw % 16 == 0, checked by the entry point)
+            const float bv = p.bv2 ? bf2f(p.bv2[16 * w + c]) : 0.f;
+            const int t0 = m0 + 4 * g;
+            if (t0 < p.M) {
+                u32x2 pk;
+                pk[0] = pack_bf2(av[0] + bv, av[1] + bv);
+                pk[1] = pack_bf2(av[2] + bv, av[3] + bv);
+                *(u32x2*)(p.v2 + ((long)(m0 / p.hw) * DI_I + 16 * w + c) * p.hw + (t0 % p.hw)) = pk;
+            }
         }
         if (tok_ok) {
             u32x2 pk;
             pk[0] = pack_bf2(ak[0] + lo_hi(bk2v, 0), ak[1] + lo_hi(bk2v, 1));
             pk[1] = pack_bf2(ak[2] + lo_hi(bk2v, 2), ak[3] + lo_hi(bk2v, 3));
             *(u32x2*)(p.k2 + (long)tok * p.kv_st + hcol) = pk;
-            pk[0] = pack_bf2(av[0] + lo_hi(bv2v, 0), av[1] + lo_hi(bv2v, 1));
-            pk[1] = pack_bf2(av[2] + lo_hi(bv2v, 2), av[3] + lo_hi(bv2v, 3));
-            *(u32x2*)(p.v2 + (long)tok * p.kv_st + hcol) = pk;
+            if (!p.v2_t) {
+                pk[0] = pack_bf2(av[0] + lo_hi(bv2v, 0), av[1] + lo_hi(bv2v, 1));
+                pk[1] = pack_bf2(av[2] + lo_hi(bv2v, 2), av[3] + lo_hi(bv2v, 3));
+                *(u32x2*)(p.v2 + (long)tok * p.kv_st + hcol) = pk;
+            }
         }
     }
+}
+
+// ---- Attention of a FEW queries over many keys (reference model/sam2.py:1417-1481 Attention.forward as cross_attn_token_to_image / final_attn_token_to_image: the
+// frame's 9 tokens x 4096 image keys, 8 heads x 16).  The general kernel cuts the keys over workgroups and needs a merge launch (~10 + 7 us); here one workgroup per
+// (frame, head) holds everything: 16 waves x 16-key tiles, S^T = K Q^T by 16x16x16 MFMAs straight from global memory (K rows as they are, V TRANSPOSED so that a lane
+// reads 4 consecutive keys of one dim), all scores of a wave kept in registers, ONE maximum per query over all keys (two shuffles + an LDS exchange -- no online
+// rescaling), numerators rounded to bf16 for the value product (the S^T accumulator layout IS the next MFMA's B operand), partial sums of the 16 waves added in
+// wave order.  The value bias is added after the normalisation (softmax rows sum to one), so v^T can come from a product without a per-row bias.
+constexpr int FQ_NW = 16, FQ_MAXT = 16;      // waves; key tiles per wave (16 x 16 x 16 = 4096 keys)
+struct FewQArgs {
+    const unsigned short* q; long q_st;      // [frames * nq, H * 16] projected queries
+    const unsigned short* k; long k_st;      // [frames * nk, H * 16] projected keys
+    const unsigned short* vt;                // [frames * H * 16, nk] projected values, transposed
+    const unsigned short* vbias;             // [H * 16] or null
+    unsigned short* o; long o_st;            // [frames * nq, H * 16]
+    int nq, nk, H;
+    float scale_log2;
+};
+
+__global__ __launch_bounds__(64 * FQ_NW) void attn_fewq_kernel(FewQArgs p) {
+    __shared__ float smax[FQ_NW][16];
+    __shared__ float sl[FQ_NW][16];
+    __shared__ f32x4 so[FQ_NW][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, f = blockIdx.y;
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    // B operand of S^T = K Q^T: lane (c, g) holds Q[q c][4 g .. 4 g + 3] of this head (queries past nq: zeros)
+    s16x4 qf = {0, 0, 0, 0};
+    if (c < p.nq) qf = *(const s16x4*)(p.q + ((long)f * p.nq + c) * p.q_st + h * 16 + 4 * g);
+    const int ntile = (p.nk + 15) >> 4;
+    const unsigned short* kb = p.k + (long)f * p.nk * p.k_st + h * 16 + 4 * g;
+    const unsigned short* vb = p.vt + ((long)(f * p.H + h) * 16 + c) * p.nk + 4 * g;
+    s16x4 kf[FQ_MAXT], vf[FQ_MAXT];
+#pragma unroll
+    for (int i = 0; i < FQ_MAXT; ++i) {
+        const int t = w + i * FQ_NW;
+        kf[i] = s16x4{0, 0, 0, 0};
+        vf[i] = s16x4{0, 0, 0, 0};
+        if (t < ntile) {
+            kf[i] = *(const s16x4*)(kb + (long)min(16 * t + c, p.nk - 1) * p.k_st);
+            if (16 * t + 4 * g + 3 < p.nk) {
+                vf[i] = *(const s16x4*)(vb + 16 * t);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vf[i][r] = (16 * t + 4 * g + r < p.nk) ? (short)vb[16 * t + r] : (short)0;
+            }
+        }
+    }
+    // ---- scores: lane (c = query, g) holds keys 16 t + 4 g + r of tile t
+    f32x4 s[FQ_MAXT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < FQ_MAXT; ++i) {
+        const int t = w + i * FQ_NW;
+        s[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[i], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = t < ntile && 16 * t + 4 * g + r < p.nk;
+            s[i][r] = ok ? s[i][r] * p.scale_log2 : -INFINITY;
+            mx = fmaxf(mx, s[i][r]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (g == 0) smax[w][c] = mx;
+    __syncthreads();
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < FQ_NW; ++i) m = fmaxf(m, smax[i][c]);
+    // ---- numerators, row sums, O^T += V^T P^T
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < FQ_MAXT; ++i) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[r] = __builtin_amdgcn_exp2f(s[i][r] - m);      // -inf -> 0
+            l += e[r];
+        }
+        const unsigned p01 = pack_bf2(e[0], e[1]), p23 = pack_bf2(e[2], e[3]);
+        s16x4 pf;
+        pf[0] = (short)(p01 & 0xffffu); pf[1] = (short)(p01 >> 16); pf[2] = (short)(p23 & 0xffffu); pf[3] = (short)(p23 >> 16);
+        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[i], pf, o, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (g == 0) sl[w][c] = l;
+    so[w][lane] = o;                                         // lane (c = query, g): dims 4 g .. 4 g + 3
+    __syncthreads();
+    if (w != 0) return;
+    float lt = 0.f;
+    f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FQ_NW; ++i) {
+        lt += sl[i][c];
+        ot += so[i][lane];
+    }
+    if (c >= p.nq) return;
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.vbias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = bf2f(p.vbias[h * 16 + 4 * g + r]);
+    }
+    u32x2 pk;
+    pk[0] = pack_bf2(ot[0] * inv + bv[0], ot[1] * inv + bv[1]);
+    pk[1] = pack_bf2(ot[2] * inv + bv[2], ot[3] * inv + bv[3]);
+    *(u32x2*)(p.o + ((long)f * p.nq + c) * p.o_st + h * 16 + 4 * g) = pk;
 }
 
 }  // namespace rga3
@@ -240,8 +367,8 @@ using namespace rga3;
 // frame of hw image rows; kt / vt [B * nk, 128] contiguous; weights contiguous; row strides in elements (multiples of 8).
 extern "C" int rga3_decimg_rows(const void* keys, int64_t keys_stride, const void* pe, int64_t pe_stride, int hw, const void* kt, const void* vt, int nk, const void* wq,
                                 const void* bq, const void* wo, const void* bo, const void* ln_w, const void* ln_b, float eps, const void* wk2, const void* bk2,
-                                const void* wv2, const void* bv2, void* keys_out, int64_t keys_out_stride, void* k2, void* v2, int64_t kv_stride, float scale,
-                                int64_t M, void* stream) {
+                                const void* wv2, const void* bv2, void* keys_out, int64_t keys_out_stride, void* k2, void* v2, int64_t kv_stride, int v2_transposed,
+                                float scale, int64_t M, void* stream) {
     RGA3_CHECK_ARG(keys && pe && kt && vt && wq && wo && ln_w && keys_out && M > 0 && M < (1LL << 31), "decimg_rows: null pointer / M");
     RGA3_CHECK_ARG(hw >= DI_R && M % hw == 0 && nk >= 1 && nk <= DI_MAXK, "decimg_rows: hw %d, nk %d (1..16)", hw, nk);
     RGA3_CHECK_ARG(keys_stride >= DI_D && keys_stride % 8 == 0 && pe_stride >= DI_D && pe_stride % 8 == 0 && keys_out_stride >= DI_D && keys_out_stride % 4 == 0, "decimg_rows: strides");
@@ -257,10 +384,27 @@ extern "C" int rga3_decimg_rows(const void* keys, int64_t keys_stride, const voi
     a.wq = (const unsigned short*)wq; a.bq = (const unsigned short*)bq; a.wo = (const unsigned short*)wo; a.bo = (const unsigned short*)bo;
     a.ln_w = (const unsigned short*)ln_w; a.ln_b = (const unsigned short*)ln_b; a.eps = eps;
     a.wk2 = (const unsigned short*)wk2; a.bk2 = (const unsigned short*)bk2; a.wv2 = (const unsigned short*)wv2; a.bv2 = (const unsigned short*)bv2;
-    a.keys_out = (unsigned short*)keys_out; a.ko_st = keys_out_stride; a.k2 = (unsigned short*)k2; a.v2 = (unsigned short*)v2; a.kv_st = kv_stride;
+    RGA3_CHECK_ARG(!v2_transposed || (wk2 && hw % 16 == 0), "decimg_rows: the transposed v2 needs hw %% 16 == 0");
+    a.keys_out = (unsigned short*)keys_out; a.ko_st = keys_out_stride; a.k2 = (unsigned short*)k2; a.v2 = (unsigned short*)v2; a.kv_st = kv_stride; a.v2_t = v2_transposed;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.M = (int)M;
     hipLaunchKernelGGL(decimg_rows_kernel, dim3((unsigned)cdiv(M, DI_R)), dim3(512), 0, (hipStream_t)stream, a);
     RGA3_CHECK_LAUNCH("decimg_rows_kernel");
+    return 0;
+}
+
+// out [frames * nq, H * 16] bf16 = softmax(scale q k^T) v (+ vbias) per frame and head of 16 dims, for nq <= 16 queries over nk <= 4096 keys per frame:
+// q [frames * nq, H * 16], k [frames * nk, H * 16] (row strides in elements, multiples of 4), vt [frames * H * 16, nk] the values TRANSPOSED (contiguous), nk % 4 == 0.
+extern "C" int rga3_attn_fewq(const void* q, int64_t q_stride, const void* k, int64_t k_stride, const void* vt, const void* vbias, void* out, int64_t out_stride, int frames,
+                              int nq, int nk, int H, float scale, void* stream) {
+    RGA3_CHECK_ARG(q && k && vt && out && frames >= 1 && frames <= 65535 && H >= 1 && H <= 65535, "attn_fewq: null pointer / frames / heads");
+    RGA3_CHECK_ARG(nq >= 1 && nq <= 16 && nk >= 1 && nk <= 16 * FQ_NW * FQ_MAXT && nk % 4 == 0, "attn_fewq: nq %d (1..16), nk %d (<= 4096, multiple of 4)", nq, nk);
+    RGA3_CHECK_ARG(q_stride % 4 == 0 && k_stride % 4 == 0 && out_stride % 4 == 0 && q_stride >= 16L * H && k_stride >= 16L * H && out_stride >= 16L * H, "attn_fewq: strides");
+    RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 7) == 0 && scale > 0.f, "attn_fewq: alignment / scale");
+    FewQArgs a;
+    a.q = (const unsigned short*)q; a.q_st = q_stride; a.k = (const unsigned short*)k; a.k_st = k_stride; a.vt = (const unsigned short*)vt; a.vbias = (const unsigned short*)vbias;
+    a.o = (unsigned short*)out; a.o_st = out_stride; a.nq = nq; a.nk = nk; a.H = H; a.scale_log2 = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_fewq_kernel, dim3((unsigned)H, (unsigned)frames), dim3(64 * FQ_NW), 0, (hipStream_t)stream, a);
+    RGA3_CHECK_LAUNCH("attn_fewq_kernel");
     return 0;
 }

@@ -385,9 +385,13 @@ class Attention(nn.Module):
             o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5, max_k=nk)
         return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
 
-    def attend(self, qp, kp, vp, B, nq, nk, residual=None):
-        """softmax(QK^T)V + out_proj on projections that already exist (qp [B*nq, internal_dim], kp / vp [B*nk, internal_dim])."""
+    def attend(self, qp, kp, vp, B, nq, nk, residual=None, vt=False, vbias=None):
+        """softmax(QK^T)V + out_proj on projections that already exist (qp [B*nq, internal_dim], kp / vp [B*nk, internal_dim]; vt: vp is the TRANSPOSED values
+        [B * internal_dim, nk] for the few-query kernel, vbias its bias if not yet added)."""
         H, hd = self.num_heads, self.internal_dim // self.num_heads
+        if vt:
+            o = ops.attn_fewq(qp, kp, vp, nq, nk, H, hd ** -0.5, vbias)
+            return _lin(self.out_proj, o, residual=residual)
         o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, qp.device), _cu(B, nk, qp.device), nq, hd ** -0.5, max_k=nk)
         return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
 
@@ -440,16 +444,22 @@ class TwoWayAttentionBlock(nn.Module):
         qp, kp_, vp_ = ops.gemm_rows16_many([(queries, pe_) + lin(sa.q_proj), (queries, pe_) + lin(sa.k_proj), (queries, None) + lin(sa.v_proj)])
         queries = sa.attend(qp, kp_, vp_, B, nq, nq, residual=None if self.skip_first_layer_pe else queries)
         queries = self.norm1(queries)
+        fewq = B == 1 and nk <= 4096 and nk % 16 == 0      # the few-query attention kernel (values transposed, no merge launch: csrc/decimg.hip)
+        vbias = None
         if kp is None:
-            kp, vp = t2i.k_proj(_add_bcast(keys, key_pe)), t2i.v_proj(keys)
+            kp = t2i.k_proj(_add_bcast(keys, key_pe))
+            if fewq:
+                vp, vbias = ops.gemm(t2i.v_proj.weight, keys), t2i.v_proj.bias      # W_v keys^T = v^T [128, nk]; the bias goes in after the softmax
+            else:
+                vp = t2i.v_proj(keys)
         (qp,) = ops.gemm_rows16_many([(queries, query_pe) + lin(t2i.q_proj)])
-        queries = self.norm2(t2i.attend(qp, kp, vp, B, nq, nk, residual=queries))
+        queries = self.norm2(t2i.attend(qp, kp, vp, B, nq, nk, residual=queries, vt=fewq, vbias=vbias))
         queries = self.norm3(self.mlp(queries, residual=queries))
         kt, vt = ops.gemm_rows16_many([(queries, query_pe) + lin(i2t.k_proj), (queries, None) + lin(i2t.v_proj)])
         hd = i2t.internal_dim // i2t.num_heads
         keys, kp2, vp2 = ops.decimg_rows(keys, key_pe, kt, vt, nq, (i2t.q_proj.weight, i2t.q_proj.bias),
                                          (i2t.out_proj.weight, i2t.out_proj.bias), (self.norm4.weight, self.norm4.bias), self.norm4.eps,
-                                         (nxt.k_proj.weight, nxt.k_proj.bias), (nxt.v_proj.weight, nxt.v_proj.bias), scale=hd ** -0.5)
+                                         (nxt.k_proj.weight, nxt.k_proj.bias), (nxt.v_proj.weight, nxt.v_proj.bias), scale=hd ** -0.5, v_transposed=fewq)
         return queries, keys, kp2, vp2
 
 
@@ -483,7 +493,7 @@ class TwoWayTransformer(nn.Module):
                 queries, keys, kp, vp = layer.forward_fused(queries, keys, query_pe, key_pe, B, nq, nk, kp, vp, nxt)
             fa = self.final_attn_token_to_image
             (qp,) = ops.gemm_rows16_many([(queries, query_pe, fa.q_proj.weight, fa.q_proj.bias)])
-            queries = self.norm_final_attn(fa.attend(qp, kp, vp, B, nq, nk, residual=queries))
+            queries = self.norm_final_attn(fa.attend(qp, kp, vp, B, nq, nk, residual=queries, vt=(B == 1 and nk <= 4096 and nk % 16 == 0)))
             return queries, keys
         for layer in self.layers:
             queries, keys = layer(queries, keys, query_pe, key_pe, B, nq, nk)

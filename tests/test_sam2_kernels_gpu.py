@@ -505,6 +505,9 @@ def test_decoder_image_side_block_boundary(dev, B, hw, nk):
     xr = F.layer_norm(F.linear(of_.permute(0, 2, 1, 3).reshape(M, 128), f(wo), f(bo)) + f(keys), (256,), f(gam), f(bet), 1e-5)
     assert rel(out, xr) < 1.5e-2, rel(out, xr)
     assert rel(k2, F.linear(xr + pe_rows, f(wk), f(bk))) < 2e-2 and rel(v2, F.linear(xr, f(wv), f(bv))) < 2e-2
+    if hw % 16 == 0:     # the transposed form of v2 ([frames * 128, hw], what attn_fewq reads): the same numbers
+        _, k2t, v2t = ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, (wk, bk), (wv, bv), scale=0.25, v_transposed=True)
+        assert torch.equal(k2t, k2) and torch.equal(v2t.view(B, 128, hw).permute(0, 2, 1).reshape(M, 128), v2)
     only, n1, n2 = ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, scale=0.25)
     assert n1 is None and n2 is None and torch.equal(only, out)
     assert torch.equal(out, ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, (wk, bk), (wv, bv), scale=0.25)[0])
@@ -533,3 +536,27 @@ def test_two_way_transformer_fused_image_side_matches_separate_launches(dev):
         finally:
             S2._DECIMG = True
     assert rel(q1, q0) < 1e-2 and rel(k1, k0) < 1e-2, (rel(q1, q0), rel(k1, k0))
+
+
+@pytest.mark.parametrize("frames,nq,nk,H", [(1, 9, 4096, 8), (3, 16, 1000, 8), (2, 1, 20, 2), (1, 5, 64, 1)])
+def test_attention_few_queries(dev, frames, nq, nk, H):
+    """csrc/decimg.hip attn_fewq: up to 16 queries over up to 4096 keys per frame, heads of 16, values given transposed, one workgroup per (frame, head) -- against fp32
+    attention on the same bf16 operands and against the general kernel; ragged key counts (a last 16-key tile of 8 / 4), one query, the value bias added after the
+    softmax."""
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(frames * 1000 + nk)
+    q = (torch.randn(frames * nq, H * 16, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    k = (torch.randn(frames * nk, H * 16, generator=g) * (0.5 + 1.5 * torch.linspace(0, 1, frames * nk)[:, None])).to(torch.bfloat16).to(dev)
+    v = torch.randn(frames * nk, H * 16, generator=g).to(torch.bfloat16).to(dev)
+    vb = (torch.randn(H * 16, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    vt = v.view(frames, nk, H * 16).permute(0, 2, 1).reshape(frames * H * 16, nk).contiguous()
+    out = ops.attn_fewq(q, k, vt, nq, nk, H, 0.25, vb)
+    qf_, kf_, vf_ = (t.float().cpu().view(frames, -1, H, 16).permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = (torch.softmax(qf_ @ kf_.transpose(-1, -2) * 0.25, dim=-1) @ vf_).permute(0, 2, 1, 3).reshape(frames * nq, H * 16) + vb.float().cpu()
+    assert rel(out, ref) < 1e-2, rel(out, ref)
+    cuq = torch.arange(0, frames * nq + 1, nq, dtype=torch.int32, device=dev)
+    cuk = torch.arange(0, frames * nk + 1, nk, dtype=torch.int32, device=dev)
+    gen = ops.attn_varlen(q.view(-1, H, 16), k.view(-1, H, 16), v.view(-1, H, 16), cuq, cuk, nq, 0.25, max_k=nk).reshape(frames * nq, H * 16)
+    assert rel(ops.attn_fewq(q, k, vt, nq, nk, H, 0.25), gen) < 8e-3
+    assert torch.equal(out, ops.attn_fewq(q, k, vt, nq, nk, H, 0.25, vb))
