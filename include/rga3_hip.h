@@ -180,18 +180,19 @@ int rga3_conv3x3s2(const void* x, int x_dtype, const void* w, const void* bias, 
  * (TwoWayAttentionBlock.forward: cross_attn_image_to_token + norm4, then the next cross_attn_token_to_image's k / v projections, Attention :1417-1481):
  *   keys' [M, 256] = LayerNorm(bf16(bf16(attn((keys + pe) Wq^T + bq; kt, vt) Wo^T + bo) + keys)),   k2 = (keys' + pe) Wk2^T + bk2,  v2 = keys' Wv2^T + bv2  [M, 128]
  * with attn = 8 heads x 16 over the nk (<= 16) tokens of the row's frame (frame = row / hw, hw >= 16), kt / vt [frames * nk, 128] the token-side keys / values already
- * projected, pe [hw, 256] broadcast over frames.  wk2 = wv2 = NULL: only keys'.  v2_transposed != 0 (hw % 16 == 0): v2 is written as [frames * 128, hw] for
- * rga3_attn_fewq.  Strides in elements. */
+ * projected, pe [hw, 256] broadcast over frames.  wk2 = wv2 = NULL: only keys'.  v2_transposed != 0 (hw % 16 == 0): v2 is written as [frames * 128, hw] and k2 head-major
+ * [8][M][16] for rga3_attn_fewq.  Strides in elements. */
 int rga3_decimg_rows(const void* keys, int64_t keys_stride, const void* pe, int64_t pe_stride, int hw, const void* kt, const void* vt, int nk, const void* wq, const void* bq,
                      const void* wo, const void* bo, const void* ln_w, const void* ln_b, float eps, const void* wk2, const void* bk2, const void* wv2, const void* bv2,
                      void* keys_out, int64_t keys_out_stride, void* k2, void* v2, int64_t kv_stride, int v2_transposed, float scale, int64_t M, void* stream);
 /* Attention of a few queries over many keys, one workgroup per (frame, head) and no merge launch (csrc/decimg.hip), for reference model/sam2.py:1417-1481
  * (Attention.forward as cross_attn_token_to_image / final_attn_token_to_image: 9 tokens x 4096 image keys, 8 heads x 16):
- * out [frames * nq, H * 16] bf16 = softmax(scale q k^T) v (+ vbias), nq <= 16, nk <= 4096 (multiple of 4); q / k row-major [*, H * 16] (strides in elements),
+ * out [frames * nq, H * 16] bf16 = softmax(scale q k^T) v (+ vbias), nq <= 16, nk <= 4096 (multiple of 4); q row-major [*, H * 16]; key element (frame, j, h, d) at
+ * ((frame * nk + j) * k_stride + h * k_head_stride + d): row-major (H * 16, 16) or head-major [H][frames * nk][16] (16, frames * nk * 16), strides in elements;
  * vt [frames * H * 16, nk] the projected values TRANSPOSED (rga3_decimg_rows(v2_transposed = 1) writes that layout; so does a product with the operands swapped),
  * vbias [H * 16] added after the normalisation (softmax rows sum to one). */
-int rga3_attn_fewq(const void* q, int64_t q_stride, const void* k, int64_t k_stride, const void* vt, const void* vbias, void* out, int64_t out_stride, int frames, int nq,
-                   int nk, int H, float scale, void* stream);
+int rga3_attn_fewq(const void* q, int64_t q_stride, const void* k, int64_t k_stride, int64_t k_head_stride, const void* vt, const void* vbias, void* out, int64_t out_stride,
+                   int frames, int nq, int nk, int H, float scale, void* stream);
 /* n (<= 24) device-to-device copies in one launch (dst[i] <- src[i], bytes[i] bytes: multiples of 16, 16-byte aligned pointers, no overlap; the three arrays are HOST
  * arrays).  The copies a video-session frame makes around its captured graph (reference model/sam2.py:2829-2989 builds the bank with torch.cat / index ops per frame). */
 int rga3_copy_many(void* const* dst, const void* const* src, const int64_t* bytes, int n, void* stream);

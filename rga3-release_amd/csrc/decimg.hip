@@ -27,7 +27,7 @@ struct DecImgArgs {
     const unsigned short *ln_w, *ln_b; float eps;  // norm4
     const unsigned short *wk2, *bk2, *wv2, *bv2;   // the NEXT token-to-image attention's k_proj / v_proj [128, 256] (null: not wanted)
     unsigned short* keys_out; long ko_st;          // [M, 256]
-    unsigned short *k2, *v2; long kv_st;           // [M, 128] each; v2_t != 0: v2 is written TRANSPOSED, [frames * 128, hw] (what rga3_attn_fewq reads)
+    unsigned short *k2, *v2; long kv_st;           // [M, 128] each; v2_t != 0: v2 is written TRANSPOSED, [frames * 128, hw], and k2 head-major, [8][M][16] (what rga3_attn_fewq reads best)
     int v2_t;
     float scale_log2;
     int M;
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(512) void decimg_rows_kernel(DecImgArgs p) {
             u32x2 pk;
             pk[0] = pack_bf2(ak[0] + lo_hi(bk2v, 0), ak[1] + lo_hi(bk2v, 1));
             pk[1] = pack_bf2(ak[2] + lo_hi(bk2v, 2), ak[3] + lo_hi(bk2v, 3));
-            *(u32x2*)(p.k2 + (long)tok * p.kv_st + hcol) = pk;
+            if (p.v2_t) *(u32x2*)(p.k2 + ((long)w * p.M + tok) * 16 + 4 * g) = pk;      // head-major [8][M][16]: a head's keys are contiguous for rga3_attn_fewq
+            else *(u32x2*)(p.k2 + (long)tok * p.kv_st + hcol) = pk;
             if (!p.v2_t) {
                 pk[0] = pack_bf2(av[0] + lo_hi(bv2v, 0), av[1] + lo_hi(bv2v, 1));
                 pk[1] = pack_bf2(av[2] + lo_hi(bv2v, 2), av[3] + lo_hi(bv2v, 3));
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(512) void decimg_rows_kernel(DecImgArgs p) {
 constexpr int FQ_NW = 16, FQ_MAXT = 16;      // waves; key tiles per wave (16 x 16 x 16 = 4096 keys)
 struct FewQArgs {
     const unsigned short* q; long q_st;      // [frames * nq, H * 16] projected queries
-    const unsigned short* k; long k_st;      // [frames * nk, H * 16] projected keys
+    const unsigned short* k; long k_st, k_hst; // projected keys: element (frame f, key j, head h, dim d) at ((f * nk + j) * k_st + h * k_hst + d)
     const unsigned short* vt;                // [frames * H * 16, nk] projected values, transposed
     const unsigned short* vbias;             // [H * 16] or null
     unsigned short* o; long o_st;            // [frames * nq, H * 16]
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * FQ_NW) void attn_fewq_kernel(FewQArgs p) {
     s16x4 qf = {0, 0, 0, 0};
     if (c < p.nq) qf = *(const s16x4*)(p.q + ((long)f * p.nq + c) * p.q_st + h * 16 + 4 * g);
     const int ntile = (p.nk + 15) >> 4;
-    const unsigned short* kb = p.k + (long)f * p.nk * p.k_st + h * 16 + 4 * g;
+    const unsigned short* kb = p.k + (long)f * p.nk * p.k_st + (long)h * p.k_hst + 4 * g;
     const unsigned short* vb = p.vt + ((long)(f * p.H + h) * 16 + c) * p.nk + 4 * g;
     s16x4 kf[FQ_MAXT], vf[FQ_MAXT];
 #pragma unroll
@@ -394,15 +395,18 @@ extern "C" int rga3_decimg_rows(const void* keys, int64_t keys_stride, const voi
 }
 
 // out [frames * nq, H * 16] bf16 = softmax(scale q k^T) v (+ vbias) per frame and head of 16 dims, for nq <= 16 queries over nk <= 4096 keys per frame:
-// q [frames * nq, H * 16], k [frames * nk, H * 16] (row strides in elements, multiples of 4), vt [frames * H * 16, nk] the values TRANSPOSED (contiguous), nk % 4 == 0.
-extern "C" int rga3_attn_fewq(const void* q, int64_t q_stride, const void* k, int64_t k_stride, const void* vt, const void* vbias, void* out, int64_t out_stride, int frames,
-                              int nq, int nk, int H, float scale, void* stream) {
+// q [frames * nq, H * 16] (row stride q_stride); keys: element (frame, key j, head h, dim d) at ((frame * nk + j) * k_stride + h * k_head_stride + d) -- row-major
+// [frames * nk, H * 16]: (H * 16, 16); head-major [H][frames * nk][16]: (16, frames * nk * 16) -- a head's keys are then contiguous and a workgroup pulls 32 B per key
+// instead of a 128-byte line per key; vt [frames * H * 16, nk] the values TRANSPOSED (contiguous), nk % 4 == 0.
+extern "C" int rga3_attn_fewq(const void* q, int64_t q_stride, const void* k, int64_t k_stride, int64_t k_head_stride, const void* vt, const void* vbias, void* out,
+                              int64_t out_stride, int frames, int nq, int nk, int H, float scale, void* stream) {
     RGA3_CHECK_ARG(q && k && vt && out && frames >= 1 && frames <= 65535 && H >= 1 && H <= 65535, "attn_fewq: null pointer / frames / heads");
     RGA3_CHECK_ARG(nq >= 1 && nq <= 16 && nk >= 1 && nk <= 16 * FQ_NW * FQ_MAXT && nk % 4 == 0, "attn_fewq: nq %d (1..16), nk %d (<= 4096, multiple of 4)", nq, nk);
-    RGA3_CHECK_ARG(q_stride % 4 == 0 && k_stride % 4 == 0 && out_stride % 4 == 0 && q_stride >= 16L * H && k_stride >= 16L * H && out_stride >= 16L * H, "attn_fewq: strides");
+    RGA3_CHECK_ARG(q_stride % 4 == 0 && k_stride % 4 == 0 && k_head_stride % 4 == 0 && out_stride % 4 == 0 && q_stride >= 16L * H && k_stride >= 16 && out_stride >= 16L * H,
+                   "attn_fewq: strides");
     RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 7) == 0 && scale > 0.f, "attn_fewq: alignment / scale");
     FewQArgs a;
-    a.q = (const unsigned short*)q; a.q_st = q_stride; a.k = (const unsigned short*)k; a.k_st = k_stride; a.vt = (const unsigned short*)vt; a.vbias = (const unsigned short*)vbias;
+    a.q = (const unsigned short*)q; a.q_st = q_stride; a.k = (const unsigned short*)k; a.k_st = k_stride; a.k_hst = k_head_stride; a.vt = (const unsigned short*)vt; a.vbias = (const unsigned short*)vbias;
     a.o = (unsigned short*)out; a.o_st = out_stride; a.nq = nq; a.nk = nk; a.H = H; a.scale_log2 = scale * 1.4426950408889634f;
     hipLaunchKernelGGL(attn_fewq_kernel, dim3((unsigned)H, (unsigned)frames), dim3(64 * FQ_NW), 0, (hipStream_t)stream, a);
     RGA3_CHECK_LAUNCH("attn_fewq_kernel");

@@ -42,7 +42,7 @@ SIGNATURES = {
     "rga3_bilinear": [_p, _i, _p, _p, _i64, _i, _i, _i, _i, _p],
     "rga3_conv3x3s2": [_p, _i, _p, _p, _p, _i64, _i, _i, _i, _i, _f, _f, _p],
     "rga3_decimg_rows": [_p, _i64, _p, _i64, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _i, _f, _i64, _p],
-    "rga3_attn_fewq": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _f, _p],
+    "rga3_attn_fewq": [_p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _f, _p],
     "rga3_copy_many": [_p, _p, _p, _i, _p],
     "rga3_conv3x3s2_ln_gelu": [_p, _i, _p, _p, _p, _p, _f, _p, _i64, _i, _i, _i, _i, _f, _f, _p],
     "rga3_dwconv7x7": [_p, _p, _p, _p, _i64, _i, _i, _i, _p],

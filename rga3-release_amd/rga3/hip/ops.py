@@ -473,7 +473,7 @@ _conv_pack = {}
 def decimg_rows(keys, pe, kt, vt, nk: int, q_proj, out_proj, norm, eps: float, k_next=None, v_next=None, scale: float = 0.25, v_transposed: bool = False):
     """The image side of a mask-decoder block boundary in one launch (csrc/decimg.hip): keys [M, 256], pe [hw, 256] (broadcast over frames), kt / vt [frames * nk, 128]
     token-side keys / values (projected), q_proj / out_proj / k_next / v_next = (weight, bias) pairs, norm = (weight, bias).  -> (keys', k2, v2) (k2 = v2 = None
-    without k_next / v_next); v_transposed: v2 comes as [frames * 128, hw] (the layout attn_fewq reads)."""
+    without k_next / v_next); v_transposed: v2 comes as [frames * 128, hw] and k2 head-major [8, M, 16] (the layouts attn_fewq reads)."""
     _need_cuda(keys, pe, kt, vt, *q_proj, *out_proj, *norm)
     assert keys.dtype == torch.bfloat16 and keys.dim() == 2 and keys.shape[1] == 256 and keys.stride(1) == 1 and pe.shape[1] == 256 and pe.stride(1) == 1
     M, hw = keys.shape[0], pe.shape[0]
@@ -486,7 +486,7 @@ def decimg_rows(keys, pe, kt, vt, nk: int, q_proj, out_proj, norm, eps: float, k
     if k_next is not None:
         (wk2, bk2), (wv2, bv2) = k_next, v_next
         assert tuple(wk2.shape) == tuple(wv2.shape) == (128, 256) and wk2.is_contiguous() and wv2.is_contiguous()
-        k2 = torch.empty((M, 128), dtype=torch.bfloat16, device=keys.device)
+        k2 = torch.empty((8, M, 16) if v_transposed else (M, 128), dtype=torch.bfloat16, device=keys.device)
         assert not v_transposed or hw % 16 == 0
         v2 = torch.empty((M // hw * 128, hw) if v_transposed else (M, 128), dtype=torch.bfloat16, device=keys.device)
     _lib.check(_lib.load().rga3_decimg_rows(keys.data_ptr(), keys.stride(0), pe.data_ptr(), pe.stride(0), hw, kt.data_ptr(), vt.data_ptr(), int(nk), wq.data_ptr(), _ptr(bq),
@@ -495,15 +495,22 @@ def decimg_rows(keys, pe, kt, vt, nk: int, q_proj, out_proj, norm, eps: float, k
     return out, k2, v2
 
 
-def attn_fewq(q, k, vt, nq: int, nk: int, H: int, scale: float, vbias=None):
+def attn_fewq(q, k, vt, nq: int, nk: int, H: int, scale: float, vbias=None, k_head_major: bool = False):
     """softmax(scale q k^T) v (+ vbias) for nq <= 16 queries over nk <= 4096 keys per frame, heads of 16 dims, one launch without a merge (csrc/decimg.hip):
-    q [frames * nq, H * 16], k [frames * nk, H * 16] (row strides free), vt [frames * H * 16, nk] the values transposed.  -> [frames * nq, H * 16] bf16."""
+    q [frames * nq, H * 16], k [frames * nk, H * 16] (row stride free) or, k_head_major, [H, frames * nk, 16] (what decimg_rows(v_transposed=True) writes),
+    vt [frames * H * 16, nk] the values transposed.  -> [frames * nq, H * 16] bf16."""
     _need_cuda(q, k, vt, vbias)
-    assert q.dtype == k.dtype == vt.dtype == torch.bfloat16 and q.stride(1) == 1 and k.stride(1) == 1 and vt.is_contiguous() and q.shape[1] == k.shape[1] == 16 * H
+    assert q.dtype == k.dtype == vt.dtype == torch.bfloat16 and q.stride(1) == 1 and vt.is_contiguous() and q.shape[1] == 16 * H
     frames = q.shape[0] // nq
-    assert q.shape[0] == frames * nq and k.shape[0] == frames * nk and tuple(vt.shape) == (frames * H * 16, nk) and nq <= 16 and nk <= 4096 and nk % 4 == 0
+    assert q.shape[0] == frames * nq and tuple(vt.shape) == (frames * H * 16, nk) and nq <= 16 and nk <= 4096 and nk % 4 == 0
+    if k_head_major:
+        assert k.is_contiguous() and k.numel() == H * frames * nk * 16
+        kst, khst = 16, frames * nk * 16
+    else:
+        assert k.dim() == 2 and k.stride(1) == 1 and tuple(k.shape) == (frames * nk, 16 * H)
+        kst, khst = k.stride(0), 16
     out = torch.empty((frames * nq, 16 * H), dtype=torch.bfloat16, device=q.device)
-    _lib.check(_lib.load().rga3_attn_fewq(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), vt.data_ptr(), _ptr(vbias), out.data_ptr(), out.stride(0), frames, int(nq),
+    _lib.check(_lib.load().rga3_attn_fewq(q.data_ptr(), q.stride(0), k.data_ptr(), kst, khst, vt.data_ptr(), _ptr(vbias), out.data_ptr(), out.stride(0), frames, int(nq),
                                           int(nk), int(H), float(scale), _stream()), "attn_fewq")
     return out
 

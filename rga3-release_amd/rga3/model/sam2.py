@@ -385,12 +385,12 @@ class Attention(nn.Module):
             o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, q.device), _cu(B, nk, q.device), nq, hd ** -0.5, max_k=nk)
         return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
 
-    def attend(self, qp, kp, vp, B, nq, nk, residual=None, vt=False, vbias=None):
+    def attend(self, qp, kp, vp, B, nq, nk, residual=None, vt=False, vbias=None, k_head_major=False):
         """softmax(QK^T)V + out_proj on projections that already exist (qp [B*nq, internal_dim], kp / vp [B*nk, internal_dim]; vt: vp is the TRANSPOSED values
         [B * internal_dim, nk] for the few-query kernel, vbias its bias if not yet added)."""
         H, hd = self.num_heads, self.internal_dim // self.num_heads
         if vt:
-            o = ops.attn_fewq(qp, kp, vp, nq, nk, H, hd ** -0.5, vbias)
+            o = ops.attn_fewq(qp, kp, vp, nq, nk, H, hd ** -0.5, vbias, k_head_major=k_head_major)
             return _lin(self.out_proj, o, residual=residual)
         o = ops.attn_varlen(qp.view(-1, H, hd), kp.view(-1, H, hd), vp.view(-1, H, hd), _cu(B, nq, qp.device), _cu(B, nk, qp.device), nq, hd ** -0.5, max_k=nk)
         return _lin(self.out_proj, o.reshape(-1, self.internal_dim), residual=residual)
@@ -453,7 +453,7 @@ class TwoWayAttentionBlock(nn.Module):
             else:
                 vp = t2i.v_proj(keys)
         (qp,) = ops.gemm_rows16_many([(queries, query_pe) + lin(t2i.q_proj)])
-        queries = self.norm2(t2i.attend(qp, kp, vp, B, nq, nk, residual=queries, vt=fewq, vbias=vbias))
+        queries = self.norm2(t2i.attend(qp, kp, vp, B, nq, nk, residual=queries, vt=fewq, vbias=vbias, k_head_major=fewq and vbias is None))
         queries = self.norm3(self.mlp(queries, residual=queries))
         kt, vt = ops.gemm_rows16_many([(queries, query_pe) + lin(i2t.k_proj), (queries, None) + lin(i2t.v_proj)])
         hd = i2t.internal_dim // i2t.num_heads
@@ -493,7 +493,8 @@ class TwoWayTransformer(nn.Module):
                 queries, keys, kp, vp = layer.forward_fused(queries, keys, query_pe, key_pe, B, nq, nk, kp, vp, nxt)
             fa = self.final_attn_token_to_image
             (qp,) = ops.gemm_rows16_many([(queries, query_pe, fa.q_proj.weight, fa.q_proj.bias)])
-            queries = self.norm_final_attn(fa.attend(qp, kp, vp, B, nq, nk, residual=queries, vt=(B == 1 and nk <= 4096 and nk % 16 == 0)))
+            fq = B == 1 and nk <= 4096 and nk % 16 == 0
+            queries = self.norm_final_attn(fa.attend(qp, kp, vp, B, nq, nk, residual=queries, vt=fq, k_head_major=fq))
             return queries, keys
         for layer in self.layers:
             queries, keys = layer(queries, keys, query_pe, key_pe, B, nq, nk)

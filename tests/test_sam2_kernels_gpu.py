@@ -507,7 +507,7 @@ def test_decoder_image_side_block_boundary(dev, B, hw, nk):
     assert rel(k2, F.linear(xr + pe_rows, f(wk), f(bk))) < 2e-2 and rel(v2, F.linear(xr, f(wv), f(bv))) < 2e-2
     if hw % 16 == 0:     # the transposed form of v2 ([frames * 128, hw], what attn_fewq reads): the same numbers
         _, k2t, v2t = ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, (wk, bk), (wv, bv), scale=0.25, v_transposed=True)
-        assert torch.equal(k2t, k2) and torch.equal(v2t.view(B, 128, hw).permute(0, 2, 1).reshape(M, 128), v2)
+        assert torch.equal(k2t.permute(1, 0, 2).reshape(M, 128), k2) and torch.equal(v2t.view(B, 128, hw).permute(0, 2, 1).reshape(M, 128), v2)      # k2 head-major [8, M, 16]
     only, n1, n2 = ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, scale=0.25)
     assert n1 is None and n2 is None and torch.equal(only, out)
     assert torch.equal(out, ops.decimg_rows(keys, pe, kt, vt, nk, (wq, bq), (wo, bo), (gam, bet), 1e-5, (wk, bk), (wv, bv), scale=0.25)[0])
@@ -560,3 +560,5 @@ def test_attention_few_queries(dev, frames, nq, nk, H):
     gen = ops.attn_varlen(q.view(-1, H, 16), k.view(-1, H, 16), v.view(-1, H, 16), cuq, cuk, nq, 0.25, max_k=nk).reshape(frames * nq, H * 16)
     assert rel(ops.attn_fewq(q, k, vt, nq, nk, H, 0.25), gen) < 8e-3
     assert torch.equal(out, ops.attn_fewq(q, k, vt, nq, nk, H, 0.25, vb))
+    khm = k.view(frames * nk, H, 16).permute(1, 0, 2).contiguous()          # head-major keys: the same bits
+    assert torch.equal(out, ops.attn_fewq(q, khm, vt, nq, nk, H, 0.25, vb, k_head_major=True))

@@ -2,7 +2,8 @@
 """One steady-state frame of the SAM2 stream (bench.py --mode sam2_stream) from a rocprofv3 --kernel-trace CSV: frames are delimited by the launches of an anchor
 kernel that runs once per frame (default: the memory encoder's first conv, conv3x3s2_direct); the LAST full frame is listed launch by launch (start offset, duration,
 gap to the previous launch) and summarised by kernel name, so dependent-chain latency (gaps) can be told from kernel time.
-  python3 tools/frame_timeline.py <dir-or-csv> [--anchor NAME] [--list]"""
+  python3 tools/frame_timeline.py <dir-or-csv> [--anchor NAME] [--group-ms G] [--list]      (G: anchor launches closer than this belong to one frame; 1.5 by default,
+  0.3 for an anchor that runs once per frame now that a frame is shorter than 1.5 ms)"""
 import csv
 import glob
 import os
@@ -17,6 +18,7 @@ def arg(name, default):
 def main():
     src = sys.argv[1]
     anchor = arg("--anchor", "attn_split_combine")
+    group_ns = float(arg("--group-ms", "1.5")) * 1e6
     path = src if src.endswith(".csv") else sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[0]
     rows = []
     with open(path) as f:
@@ -27,7 +29,7 @@ def main():
     # frame boundary = first anchor launch after a stretch without one (the anchor may run several times per frame: group launches < 1.5 ms apart)
     starts = []
     for i in marks:
-        if not starts or rows[i][0] - rows[starts[-1][1]][0] > 1.5e6:
+        if not starts or rows[i][0] - rows[starts[-1][1]][0] > group_ns:
             starts.append([i, i])
         else:
             starts[-1][1] = i

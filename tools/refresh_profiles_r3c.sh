@@ -9,7 +9,7 @@ T="timeout -k 10"
 export RGA3_BENCH_TIMED_ONLY=1
 rm -rf /tmp/ps; $T 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -o stream -- $B --mode sam2_stream --steps 5 --warmup 2 > $O/r03_prof_stream.log 2>&1
 cp $(find /tmp/ps -name "*kernel_stats.csv" | head -1) $O/r03_bench_sam2_stream_kernel_stats.csv
-python3 $R/tools/frame_timeline.py /tmp/ps --anchor "conv3x3s2_ln_gelu_kernel<1" > $O/r03_stream_frame_timeline.txt 2>&1
+python3 $R/tools/frame_timeline.py /tmp/ps --anchor "conv3x3s2_ln_gelu_kernel<1" --group-ms 0.3 > $O/r03_stream_frame_timeline.txt 2>&1
 python3 $R/tools/kernel_stats_summary.py /tmp/ps memattn_cross $O/r03_bench_sam2_stream_memattn_summary.json
 rm -rf /tmp/sf /tmp/sw
 $T 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/sf -- $B --mode sam2_stream --steps 1 --warmup 1 --no-graph > $O/r03_pmc_stream_fetch.log 2>&1
