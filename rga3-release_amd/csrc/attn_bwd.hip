@@ -455,12 +455,14 @@ static int launch_bwd(const AttnBwdArgs& a0, int nseg, int max_q, int max_k, hip
     auto prep = [](const void* k, int lds) -> int {   // once per kernel instantiation
         if (lds <= 48 * 1024) return 0;
         static std::mutex mu;
-        static std::set<const void*> done;
+        static std::set<std::pair<const void*, int>> done;   // (kernel, device): the attribute is per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         std::lock_guard<std::mutex> lk(mu);
-        if (done.count(k)) return 0;
+        if (done.count({k, dev})) return 0;
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(-(int)e, "attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        done.insert(k);
+        done.insert({k, dev});
         return 0;
     };
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(a.total_q * a.Hq, 4)), dim3(256), 0, st, a);

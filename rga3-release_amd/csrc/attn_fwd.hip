@@ -607,12 +607,8 @@ template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, int KT = KV_TILE>
 static int launch_attn_p(const AttnArgs& a, int nseg, unsigned gx, hipStream_t st) {
     constexpr int LDS = 2 * KT * (DP * 2 + 32);
     auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, PAIR, false, false, KT>;
-    static bool attr_done = false;
-    if (!attr_done && LDS > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "attn")) return rc;
     AttnArgs b = a;
     b.gx = (int)gx;
     hipLaunchKernelGGL(kern, dim3(gx * (unsigned)a.Hq * (unsigned)nseg), dim3(64 * NWAVE), LDS, st, b);
@@ -637,12 +633,8 @@ static int launch_attn(const AttnArgs& a, int nseg, int max_q, hipStream_t st) {
     if (a.nsplit > 1) {
         constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
         auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, false, true>;
-        static bool attr_done = false;
-        if (!attr_done && LDS > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_done = true;
-        }
+        static LdsGrant lds_grant;
+        if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "attn")) return rc;
         AttnArgs b = a;
         b.gx = (int)(nqb * (unsigned)a.nsplit);
         hipLaunchKernelGGL(kern, dim3(nqb * (unsigned)a.nsplit * (unsigned)a.Hq * (unsigned)nseg), dim3(64 * NWAVE), LDS, st, b);
@@ -662,12 +654,8 @@ template <int DP>
 static int launch_rope_win(const AttnArgs& a, int nseg, hipStream_t st) {
     constexpr int LDS = 2 * KV_TILE * (DP * 2 + 32);
     auto kern = attn_fwd_kernel<DP, 1, 4, true, false, false, true>;
-    static bool attr_done = false;
-    if (!attr_done && LDS > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "attn")) return rc;
     AttnArgs b = a;
     b.gx = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)a.Hq * (unsigned)nseg), dim3(256), LDS, st, b);
@@ -681,12 +669,8 @@ static int launch_win(const AttnArgs& a, int nseg, int max_q, int max_k, hipStre
     const int nrows = (max_k + 63) & ~63;
     const int lds = 2 * nrows * chr * 16 + 256;
     auto kern = attn_win_kernel<DP, NW, QT, ROPE>;
-    static int lds_set = 0;   // grows monotonically; a racing second setter only repeats the call
-    if (lds > 48 * 1024 && lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(-(int)e, "attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        lds_set = lds;
-    }
+    static LdsGrant lds_grant;   // per device, grows monotonically; a racing second setter only repeats the call
+    if (int rc = grant_dyn_lds((const void*)kern, lds, lds_grant, "attn")) return rc;
     AttnArgs b = a;
     b.gx = (int)cdiv(max_q, 16 * QT * NW);
     hipLaunchKernelGGL(kern, dim3((unsigned)b.gx * (unsigned)a.Hq * (unsigned)nseg), dim3(64 * NW), lds, st, b);

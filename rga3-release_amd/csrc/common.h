@@ -12,6 +12,21 @@ namespace rga3 {
         if (e__ != hipSuccess) return ::rga3::fail(-(int)e__, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that launches on a second GPU must set it there too
+// (ADVICE r3).  One LdsGrant per kernel instantiation (a function-local static at the launch site) remembers the bytes granted on each device.
+struct LdsGrant { int bytes[16] = {0}; };
+inline int grant_dyn_lds(const void* kern, int bytes, LdsGrant& g, const char* name) {
+    if (bytes <= 48 * 1024) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const bool tracked = dev < 16;
+    if (tracked && g.bytes[dev] >= bytes) return 0;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(-(int)e, "%s: hipFuncSetAttribute(%d B dynamic LDS): %s", name, bytes, hipGetErrorString(e));
+    if (tracked) g.bytes[dev] = bytes;
+    return 0;
+}
+
 // ---- vector types
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

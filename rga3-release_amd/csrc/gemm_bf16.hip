@@ -1024,12 +1024,8 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
     }
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, MH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)sk.P), dim3(512), LDS, st, a, sk);
     RGA3_CHECK_LAUNCH("gemm_nt_sk_kernel");
     return 0;
@@ -1055,12 +1051,8 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1;
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_sk_kernel<ACT_NONE, false>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)sk.P), dim3(512), LDS, st, a, sk);
     RGA3_CHECK_LAUNCH("gemm_nt_sk_kernel<split-K>");
     SlabReduceArgs r;
@@ -1079,12 +1071,8 @@ static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     a.group_m = pick_group_m(a.ntm, 256);
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_pp_kernel<ACT, OUT_F32, LNF>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn)), dim3(512), LDS, st, a);
     RGA3_CHECK_LAUNCH("gemm_nt_pp_kernel");
     return 0;
@@ -1099,12 +1087,8 @@ static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int LDS = 2 * STAGE;
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, ACT, OUT_F32, PIPE, LNF>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
     dim3 grid((unsigned)(a.ntm * a.ntn));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, st, a);
     RGA3_CHECK_LAUNCH("gemm_nt_kernel");
@@ -1138,12 +1122,8 @@ static int launch_split64(const GemmArgs& a0, hipStream_t st) {
     a.ldc = a.N;
     constexpr int LDS = 2 * (64 + 64) * 128;
     auto kern = gemm_nt_kernel<64, 64, 2, 2, ACT_NONE, true, 0>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "gemm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)S), dim3(256), LDS, st, a);
     RGA3_CHECK_LAUNCH("gemm_nt_kernel<split 64>");
     const long n = (long)a0.M * a0.N;
@@ -1658,6 +1638,8 @@ extern "C" int rga3_gemm_rows16_many(const void* const* ptrs, const int64_t* dim
         RGA3_CHECK_ARG(s.lda % 8 == 0 && s.ldw % 8 == 0 && (!s.A2 || s.lda2 % 8 == 0), "gemm_rows16_many: set %d: strides must be multiples of 8", i);
         RGA3_CHECK_ARG((((uintptr_t)s.A | (uintptr_t)s.A2 | (uintptr_t)s.W) & 15) == 0, "gemm_rows16_many: set %d: 16-byte alignment", i);
         RGA3_CHECK_ARG(s.act == ACT_NONE || s.act == ACT_GELU || s.act == ACT_RELU, "gemm_rows16_many: set %d: act %d", i, s.act);
+        RGA3_CHECK_ARG(s.ldc >= s.N && (!s.res || s.ldr >= s.N), "gemm_rows16_many: set %d: ldc %ld / ldr %ld shorter than N %d (a residual row stride below N reads out of bounds)",
+                       i, (long)s.ldc, (long)s.ldr, s.N);
         if (s.N > maxn) maxn = s.N;
     }
     hipLaunchKernelGGL(gemm_rows16_many_kernel, dim3((unsigned)cdiv(maxn, 16), (unsigned)n), dim3(64 * R16_NW), 0, (hipStream_t)stream, P);

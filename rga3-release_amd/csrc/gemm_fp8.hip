@@ -428,12 +428,8 @@ extern "C" int rga3_gemm_fp8(const void* Aq, const void* Wq, const float* sa, co
     a.ntn = (int)cdiv(N, 256);
     a.group_m = a.ntm <= 16 ? a.ntm : 4;
     constexpr int LDS = 2 * 4 * 128 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "gemm_fp8: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)gemm_fp8_pp_kernel, LDS, lds_grant, "gemm_fp8")) return rc;
     hipLaunchKernelGGL(gemm_fp8_pp_kernel, dim3((unsigned)(a.ntm * a.ntn)), dim3(512), LDS, (hipStream_t)stream, a);
     RGA3_CHECK_LAUNCH("gemm_fp8_pp_kernel");
     return 0;

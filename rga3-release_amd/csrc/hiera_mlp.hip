@@ -237,12 +237,8 @@ extern "C" int rga3_hiera_mlp144(const void* x, const void* w1f, const float* c1
     RGA3_CHECK_ARG(x && w1f && c1 && d1 && w2 && b2 && y && M > 0, "hiera_mlp144: null pointer / M %ld", (long)M);
     RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1f | (uintptr_t)w2 | (uintptr_t)y | (uintptr_t)c1) & 15) == 0 && (((uintptr_t)b2 | (uintptr_t)d1) & 7) == 0, "hiera_mlp144: alignment");
     RGA3_CHECK_ARG(x != y, "hiera_mlp144: in place is not supported (the residual is re-read)");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)hiera_mlp144_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HM_LDS);
-        if (e != hipSuccess) return fail(-(int)e, "hiera_mlp144: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)hiera_mlp144_kernel, HM_LDS, lds_grant, "hiera_mlp144")) return rc;
     HmArgs a;
     a.x = (const unsigned short*)x; a.w1f = (const unsigned short*)w1f; a.c1 = c1; a.d1 = (const unsigned short*)d1;
     a.w2 = (const unsigned short*)w2; a.b2 = (const unsigned short*)b2; a.y = (unsigned short*)y; a.M = M; a.eps = eps;

@@ -275,12 +275,8 @@ static int memattn_launch(const void* q, const void* k, const void* m, void* out
     RGA3_CHECK_ARG(scale > 0.f, "%s: scale must be positive", name);
     RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)m | (uintptr_t)ws) & 15) == 0, "%s: 16-byte alignment", name);
     auto kern = memattn_cross_kernel<DM, NW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, MaGeom<DM>::LDS);
-        if (e != hipSuccess) return fail(-(int)e, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, MaGeom<DM>::LDS, lds_grant, name)) return rc;
     MemAttnArgs a;
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.m = (const unsigned short*)m; a.out = (unsigned short*)out;
     a.part_o = ws; a.part_ml = ws + (int64_t)nsplit * Nq * DM;

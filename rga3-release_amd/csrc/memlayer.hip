@@ -289,12 +289,8 @@ template <int K1, bool PARTIALS, int NT2, int RT>
 static int memlayer_launch(const MemLayerArgs& p, unsigned groups, hipStream_t st) {
     constexpr int R = 16 * RT, LDS = 2 * R * ML_STR + 2 * ML_NW * R * 4;
     auto kern = memlayer_rows_kernel<K1, PARTIALS, NT2, RT>;
-    static bool attr_done = false;
-    if (!attr_done && LDS > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return fail(-(int)e, "memlayer_rows: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "memlayer_rows")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(p.M, R), groups), dim3(64 * ML_NW), LDS, st, p);
     RGA3_CHECK_LAUNCH("memlayer_rows_kernel");
     return 0;

@@ -132,7 +132,8 @@ def gemm_rows16_many(sets):
         M, K = a.shape
         N = w.shape[0]
         assert M <= 16 and K % 8 == 0 and (a2 is None or (a2.shape == a.shape and a2.stride(1) == 1 and a2.dtype == torch.bfloat16))
-        assert b is None or (b.numel() == N and b.is_contiguous()) and (res is None or (tuple(res.shape) == (M, N) and res.stride(1) == 1))
+        assert b is None or (b.numel() == N and b.is_contiguous() and b.dtype == torch.bfloat16)
+        assert res is None or (tuple(res.shape) == (M, N) and res.stride(1) == 1 and res.stride(0) >= N and res.dtype == torch.bfloat16)
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
         outs.append(out)
         for j, t in enumerate((a, a2, w, b, res, out)):

@@ -593,7 +593,7 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
             # a frozen tower with constant pixels needs no graph: under no_grad the windowed blocks take the attention kernel that rotates q / k while loading
             # (no stand-alone rope pass) -- the reference freezes the vision tower during RGA3 training (train_joint.py:193-251 trains LoRA, heads, mask decoder)
             frozen = not px.requires_grad and not any(p_.requires_grad for p_ in self.visual.parameters())
-            emb = self._prefetched_vision(px, grid) if frozen else None
+            emb = self._prefetched_vision(px, grid, "image" if tok == c.image_token_id else "video") if frozen else None
             if emb is None:
                 with torch.no_grad() if frozen else contextlib.nullcontext():
                     emb = self.visual(px, _np(grid))
@@ -623,20 +623,25 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         cur = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(cur)                     # the pixels (and everything queued so far) come first
-        for px, grid in ((pixel_values, image_grid_thw), (pixel_values_videos, video_grid_thw)):
+        for slot, px, grid in (("image", pixel_values, image_grid_thw), ("video", pixel_values_videos, video_grid_thw)):
             if px is None or px.requires_grad:
                 continue
+            grid_np = _np(grid)
             with torch.cuda.stream(st), torch.no_grad():
                 st.wait_event(ready)
-                emb = self.visual(px, _np(grid))
+                px.record_stream(st)          # read on the side stream: the allocator must not recycle it before that stream is done with it
+                emb = self.visual(px, grid_np)
                 done = torch.cuda.Event()
                 done.record(st)
-            cache[px.data_ptr()] = ((px._version, tuple(px.shape), px.dtype), px, emb, done)     # holds px: its address cannot be recycled while the entry lives
+            # keyed by slot + address; valid only for the same tensor version / shape / dtype AND the same grid (the features of one pixel tensor differ
+            # by grid: window index, positions).  The entry holds px, so its address cannot be recycled while the entry lives.
+            sig = (px._version, tuple(px.shape), px.dtype, tuple(int(v) for v in np.asarray(grid_np).reshape(-1)))
+            cache[(slot, px.data_ptr())] = (sig, px, emb, done)
 
-    def _prefetched_vision(self, px, grid):
+    def _prefetched_vision(self, px, grid, slot="video"):
         cache = self.__dict__.get("_pf_cache")
-        hit = cache.pop(px.data_ptr(), None) if cache else None
-        if hit is None or hit[0] != (px._version, tuple(px.shape), px.dtype):
+        hit = cache.pop((slot, px.data_ptr()), None) if cache else None
+        if hit is None or hit[0] != (px._version, tuple(px.shape), px.dtype, tuple(int(v) for v in np.asarray(_np(grid)).reshape(-1))):
             return None
         _, _, emb, done = hit
         cur = torch.cuda.current_stream(px.device)

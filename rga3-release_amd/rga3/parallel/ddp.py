@@ -53,8 +53,13 @@ def sparse_candidates(model):
 
 
 class GradBucketReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, process_group=None, sparse_params=(), sparse: bool = True):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, process_group=None, sparse_params=(), sparse: bool = True,
+                 announce_cap: int = 8192):
         self.pg = process_group
+        # rows per rank that the forward-time announcement carries (ids, not only their number): with them every rank knows ALL ranks' row ids on the host
+        # before backward ends, so finish() needs neither a second id all-gather nor a device-side unique (a data-dependent shape = a device -> host wait
+        # with the optimizer's launches still to be issued).  A step whose union outgrows it falls back to the exchange-at-finish path.  Multiple of 8.
+        self._ann_cap = max(8, (int(announce_cap) + 7) // 8 * 8)
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.sync = True
         self.sparse_params: List[torch.nn.Parameter] = [p for p in sparse_params if p.requires_grad] if sparse else []
@@ -244,30 +249,34 @@ class GradBucketReducer:
         st["dev_ids"] = []
 
     def announce_sparse(self, p, uniq_ids_np):
-        """Forward of a micro-step: the rows this rank will contribute are known on the host.  The size of the running union is exchanged now, on a
-        side stream, so that finish() can size the all-gather without waiting for the GPU."""
+        """Forward of a micro-step: the rows this rank will contribute are known on the host.  The running union (its ids and their number) is exchanged
+        now, on a side stream, so that finish() can size the row all-gather, address every rank's rows and name the union of all ranks' rows without
+        waiting for the GPU.  Message per rank: [ids (announce_cap, padded with the scratch row id V) | count | 7 x pad] int64."""
         st = self._sp[id(p)]
         st["union"] = np.union1d(st["union"], uniq_ids_np)
         if self.world == 1:
             return
         dev = p.device
-        n = torch.tensor([st["union"].size], dtype=torch.int64)
+        cap, n_ids = self._ann_cap, int(st["union"].size)
+        msg = torch.full((cap + 8,), int(p.shape[0]), dtype=torch.int64)
+        msg[:min(n_ids, cap)] = torch.from_numpy(st["union"][:cap])
+        msg[cap] = n_ids
         if dev.type == "cuda" and self._nccl:
             side = st.setdefault("side", torch.cuda.Stream(device=dev))
-            n = n.pin_memory()
-            host = torch.empty(self.world, dtype=torch.int64).pin_memory()
+            msg = msg.pin_memory()
+            host = torch.empty((self.world, cap + 8), dtype=torch.int64).pin_memory()
             with torch.cuda.stream(side):
-                nd = n.to(dev, non_blocking=True)
-                out = torch.empty(self.world, dtype=torch.int64, device=dev)
-                dist.all_gather_into_tensor(out, nd, group=self.pg)
+                nd = msg.to(dev, non_blocking=True)
+                out = torch.empty((self.world, cap + 8), dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(out.view(-1), nd, group=self.pg)
                 host.copy_(out, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(side)
-            st["counts"] = (host, ev, (n, nd, out))
+            st["counts"] = (host, ev, (msg, nd, out))
         else:
-            outs = [torch.empty(1, dtype=torch.int64) for _ in range(self.world)]
-            dist.all_gather(outs, n, group=self.pg)
-            st["counts"] = (torch.cat(outs), None, None)
+            host = torch.empty((self.world, cap + 8), dtype=torch.int64)
+            dist.all_gather_into_tensor(host.view(-1), msg, group=self.pg)
+            st["counts"] = (host, None, None)
 
     def add_sparse(self, p, ids_dev, rows):
         """Backward of a micro-step: accumulate (unique row ids, summed rows) of this rank into the dense buffer."""
@@ -287,41 +296,65 @@ class GradBucketReducer:
             st["last_ids"] = ids
             self.sparse_bytes_last = 0
             return
-        host, ev, _keep = st["counts"]
+        host, ev, keep = st["counts"]
         if ev is not None:
-            ev.synchronize()
-        cap = (int(host.max()) + 63) // 64 * 64
+            ev.synchronize()      # recorded during forward: long done when backward ends
+        acap = self._ann_cap
+        counts = [int(v) for v in host[:, acap].tolist()]
         H = d.shape[1]
-        # send buffer: this rank's rows at its union ids, padded with the scratch row id V (ids) / zeros (rows)
-        send_ids = torch.full((cap,), d.shape[0], dtype=torch.int64, device=dev)
-        send_ids[:ids.numel()] = ids
+        cap = (max(counts) + 63) // 64 * 64
+        announced = max(counts) <= acap      # every rank's ids travelled with the announcement (the same decision on every rank: same gathered counts)
+        if announced:
+            if keep is not None:             # RCCL: the gathered ids are on the device already (side stream) -- this stream only has to wait for them
+                torch.cuda.current_stream(dev).wait_event(ev)
+                ids_all = keep[2]
+                ids_all.record_stream(torch.cuda.current_stream(dev))
+            else:
+                ids_all = host if dev.type != "cuda" else _upload(host, dev)
+            rank_ids = [ids_all[r, :counts[r]] for r in range(self.world)]
+            ids = rank_ids[dist.get_rank(self.pg)]     # this rank's union, as announced (sorted unique ids)
         send_rows = torch.zeros((cap, H), dtype=d.dtype, device=dev)
         if ids.numel():
             send_rows[:ids.numel()] = _gather(d, ids)
-        all_ids = torch.empty((self.world * cap,), dtype=torch.int64, device=dev)
         all_rows = torch.empty((self.world * cap, H), dtype=d.dtype, device=dev)
+        id_bytes = self.world * (acap + 8) * 8
+        if not announced:
+            # fallback (a union larger than announce_cap): ids go out here, padded with the scratch row id V, and the union is taken on the device
+            send_ids = torch.full((cap,), d.shape[0], dtype=torch.int64, device=dev)
+            send_ids[:ids.numel()] = ids
+            all_ids = torch.empty((self.world * cap,), dtype=torch.int64, device=dev)
+            id_bytes += self.world * cap * 8
         if self._nccl or dev.type != "cuda":
-            dist.all_gather_into_tensor(all_ids, send_ids, group=self.pg)
+            if not announced:
+                dist.all_gather_into_tensor(all_ids, send_ids, group=self.pg)
             dist.all_gather_into_tensor(all_rows, send_rows, group=self.pg)
         else:   # gloo has no all-gather on device tensors (functional multi-rank runs on a shared GPU, bench.py RGA3_BENCH_SHARE_GPU): stage through the host
-            hi, hr = torch.empty(all_ids.shape, dtype=all_ids.dtype), torch.empty(all_rows.shape, dtype=all_rows.dtype)
-            dist.all_gather_into_tensor(hi, send_ids.cpu(), group=self.pg)
+            if not announced:
+                hi = torch.empty(all_ids.shape, dtype=all_ids.dtype)
+                dist.all_gather_into_tensor(hi, send_ids.cpu(), group=self.pg)
+                all_ids.copy_(hi)
+            hr = torch.empty(all_rows.shape, dtype=all_rows.dtype)
             dist.all_gather_into_tensor(hr, send_rows.cpu(), group=self.pg)
-            all_ids.copy_(hi)
             all_rows.copy_(hr)
-        self.sparse_bytes_last = self.world * cap * (8 + H * d.element_size())
+        if not announced:
+            rank_ids = [all_ids[r * cap:r * cap + counts[r]] for r in range(self.world)]
+        self.sparse_bytes_last = id_bytes + self.world * cap * H * d.element_size()
         # local rows out, then the N contributions in rank order (every id list is unique within itself): identical bits on every rank
         if ids.numel():
             _zero_rows(d, ids)
-        counts = host.tolist()
         touched = []
         for r in range(self.world):
-            n = int(counts[r])
-            if n:
-                rid = all_ids[r * cap:r * cap + n]
-                _scatter_add(d, rid, all_rows[r * cap:r * cap + n], 1.0 / self.world)
-                touched.append(rid)
-        st["last_ids"] = torch.unique(torch.cat(touched)) if touched else None   # unique: the optimizer sums the gradient norm over exactly these rows
+            if counts[r]:
+                _scatter_add(d, rank_ids[r], all_rows[r * cap:r * cap + counts[r]], 1.0 / self.world)
+                touched.append(rank_ids[r])
+        # the union of all ranks' rows (unique, sorted: the optimizer sums the gradient norm over exactly these rows): from the announced host copy -- no
+        # device-side unique, whose data-dependent shape would stall the host at the end of backward
+        if announced:
+            hn = host.numpy()
+            parts = [hn[r, :counts[r]] for r in range(self.world) if counts[r]]
+            st["last_ids"] = _upload(np.unique(np.concatenate(parts)), dev) if parts else None
+        else:
+            st["last_ids"] = torch.unique(torch.cat(touched)) if touched else None
 
     def remove(self):
         for h in self._hooks:

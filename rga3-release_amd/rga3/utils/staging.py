@@ -5,8 +5,9 @@ The reference's trainer builds every batch on the CPU (collate_fn, reference uti
 (mRoPE positions, packing, cu_seqlens, CE targets, [SEG] rows are host-side integer plumbing): reading them back from the device is a device -> host
 sync per step, and uploading each derived index array from pageable memory is another.  Two rules remove both:
 
-* `dict_to_cuda` (same semantics as the reference's) keeps the CPU tensor it was handed as a companion of the device tensor it returns
-  (`host_of`): the plan is built from the collate function's own copy, no read-back;
+* `dict_to_cuda` (same semantics as the reference's) keeps a PRIVATE host copy of every integer tensor (the pinned staging copy the H2D transfer
+  reads, or a clone when the caller's tensor is already pinned) as a companion of the device tensor it returns (`host_of`): the plan is built from
+  exactly the bytes that went to the device, no read-back, and later writes into the caller's buffer cannot reach it;
 * every derived index array goes up through `upload`: one pinned staging block + a non-blocking copy on the current stream (ordered before its
   consumers like any launch; the caching host allocator holds the block until the copy has run).
 """
@@ -70,8 +71,16 @@ def dict_to_cuda(input_dict: dict, device=None) -> dict:
     def move(v):
         if v.is_cuda or device.type != "cuda":
             return v.to(device)
-        d = (v if v.is_pinned() else v.pin_memory()).to(device, non_blocking=True)
-        return attach_host(d, v) if (not v.is_floating_point() or v.numel() <= 4096) else d     # integer inputs, grids, second_per_grid_ts
+        small = not v.is_floating_point() or v.numel() <= 4096     # integer inputs, grids, second_per_grid_ts
+        # The companion must be PRIVATE: version counters do not see writes through a numpy view, a raw pointer or `.data` (a collate function that
+        # refills one persistent pinned buffer per batch does exactly that), and a companion that changed under the plan gives a silently wrong loss.
+        # A pageable tensor is staged through a pinned copy nobody else holds: that copy is the exact source of the H2D transfer and becomes the companion;
+        # a tensor the caller already pinned is the caller's, so the (small) companion is cloned from it.
+        p = v if v.is_pinned() else v.pin_memory()
+        d = p.to(device, non_blocking=True)
+        if not small:
+            return d
+        return attach_host(d, p if p is not v else v.clone())
 
     for k, v in input_dict.items():
         if isinstance(v, torch.Tensor):

@@ -127,32 +127,40 @@ def _worker_sparse(rank, world, port, q):
     V, H = 50, 16
     table = torch.nn.Parameter(torch.zeros(V, H))
     w = torch.nn.Parameter(torch.ones(4))
-    red = GradBucketReducer([table, w], bucket_mb=1.0, sparse_params=[table])
-    assert sparse_sink_for(table) is red and len(red.buckets) == 1
-    ok = True
-    for step in range(2):
-        red.begin_step()
-        dense_ref = torch.zeros(world, V, H)
-        for mi in range(2):
-            for r in range(world):   # every rank can rebuild everyone's contribution
-                g = torch.Generator().manual_seed(100 * step + 10 * r + mi)
-                ids = np.unique(torch.randint(0, V if r == 0 else V // 2, (5 + 3 * r,), generator=g).numpy()).astype(np.int64)
-                rows = torch.randn(len(ids), H, generator=g)
-                dense_ref[r][torch.from_numpy(ids)] += rows
-                if r == rank:
-                    mine = (ids, rows)
-            ctx = red.no_sync() if mi == 0 else __import__("contextlib").nullcontext()
-            with ctx:
-                red.begin_micro_step()
-                red.announce_sparse(table, mine[0])
-                (w * (rank + 1.0)).sum().backward()
-                red.add_sparse(table, torch.from_numpy(mine[0]), mine[1])
-        red.finish()
-        ref = dense_ref.mean(0)
-        ok = ok and torch.allclose(red.grad_view(table), ref, atol=1e-6)
-        ok = ok and torch.allclose(red.grad_view(w), torch.full((4,), 2.0 * (1 + world) / 2), atol=1e-6)   # two micro-steps, mean over ranks of (rank + 1)
-    q.put((rank, bool(ok), [red.grad_view(table).sum().item(), red.sparse_bytes_last]))
-    red.remove()
+    ok, sums = True, []
+    # announce_cap 8192: every rank's ids travel with the forward-time announcement (the union of the touched rows is taken on the host, no device-side unique);
+    # announce_cap 8: the unions (up to 16 ids) outgrow it and the step falls back to the id exchange at finish().  Same results either way.
+    for acap in (8192, 8):
+        table.data.zero_()
+        red = GradBucketReducer([table, w], bucket_mb=1.0, sparse_params=[table], announce_cap=acap)
+        assert sparse_sink_for(table) is red and len(red.buckets) == 1
+        for step in range(2):
+            red.begin_step()
+            dense_ref = torch.zeros(world, V, H)
+            for mi in range(2):
+                for r in range(world):   # every rank can rebuild everyone's contribution
+                    g = torch.Generator().manual_seed(100 * step + 10 * r + mi)
+                    ids = np.unique(torch.randint(0, V if r == 0 else V // 2, (5 + 3 * r,), generator=g).numpy()).astype(np.int64)
+                    rows = torch.randn(len(ids), H, generator=g)
+                    dense_ref[r][torch.from_numpy(ids)] += rows
+                    if r == rank:
+                        mine = (ids, rows)
+                ctx = red.no_sync() if mi == 0 else __import__("contextlib").nullcontext()
+                with ctx:
+                    red.begin_micro_step()
+                    red.announce_sparse(table, mine[0])
+                    (w * (rank + 1.0)).sum().backward()
+                    red.add_sparse(table, torch.from_numpy(mine[0]), mine[1])
+            red.finish()
+            ref = dense_ref.mean(0)
+            ok = ok and torch.allclose(red.grad_view(table), ref, atol=1e-6)
+            ok = ok and torch.allclose(red.grad_view(w), torch.full((4,), 2.0 * (1 + world) / 2), atol=1e-6)   # two micro-steps, mean over ranks of (rank + 1)
+            touched = torch.nonzero(dense_ref.abs().sum((0, 2)) > 0).flatten()      # the union of every rank's rows: what the optimizer's row mask / norm must follow
+            ok = ok and torch.equal(red._sp[id(table)]["last_ids"].cpu(), touched)
+        sums += [red.grad_view(table).sum().item(), red.sparse_bytes_last]
+        red.remove()
+    ok = ok and sums[0] == sums[2]       # announced and fallback paths: the same bits
+    q.put((rank, bool(ok), sums))
     dist.destroy_process_group()
 
 

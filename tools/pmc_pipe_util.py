@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Matrix-pipe / issue utilisation of the kernels that SHIP, from rocprofv3 --pmc passes.
+
+  run        python3 tools/pmc_pipe_util.py run          launches every target kernel a few times at its bench shape (the program a --pmc pass profiles)
+  summarise  python3 tools/pmc_pipe_util.py sum <dir> <out.json>    reads every *counter_collection.csv under <dir> (one sub-directory per pass)
+
+Targets (kernel name needle -> the call that launches it at the shape of the headline step / configs[1] forward / configs[3] stream):
+  gemm_nt_sk_kernel<2,       LLM gate-up with the SwiGLU epilogue, 2112 x 37888 x 3584 (tile 22)
+  gemm_nt_sk_kernel<0,       LLM down projection + residual, 2112 x 3584 x 18944 (tile 22)
+  gemm_nt_kernel<128, 192    Hiera-L stage-3 qkv, 32768 x 1728 x 576 (8 frames; tile 5)
+  gemm_nt_kernel<128, 256    LLM o-proj + residual, 2112 x 3584 x 3584 (tile 3)
+  attn_fwd_kernel<128        causal decoder attention, S = 2112, 28 / 4 heads x 128
+  attn_bwd_dkv / attn_bwd_dq its backward
+  attn_win_kernel<96, 8      Hiera stage-3 windows: 128 windows x 256 tokens, 8 heads x 72
+  memattn_cross_kernel       SAM2 memory cross-attention, 4096 queries x 28 736 keys
+
+Derivations (MI355X_MICROARCH.md, rocprofv3 PMC slots + cycle constants):
+  SQ_VALU_MFMA_BUSY_CYCLES  = matrix-pipe cycles summed over the chip's 1024 SIMDs (16 per 16x16x32 bf16 MFMA, 32 per 32x32x16)
+  GRBM_GUI_ACTIVE           = busy cycles summed over the 8 XCDs  ->  kernel cycles = GRBM_GUI_ACTIVE / 8
+  mfma_busy                 = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024)
+  SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY count quad-cycles per wave: their RATIOS say where a resident wave spends its time
+  (parked at s_waitcnt / barrier, issue-stalled, issuing); SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = share of LDS-array cycles lost to conflicts.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TARGETS = ["gemm_nt_sk_kernel<2,", "gemm_nt_sk_kernel<0,", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel", "attn_fwd_kernel<128", "attn_causal32_kernel",
+           "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_win_kernel<96, 8", "memattn_cross_kernel", "hiera_mlp576_kernel"]
+
+
+def run():
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
+    from rga3.hip import ops
+    dev = "cuda"
+    torch.manual_seed(0)
+    bf = torch.bfloat16
+    R = 4
+
+    def rn(*s, scale=1.0):
+        return (torch.randn(*s, device=dev) * scale).to(bf)
+
+    # ---- GEMMs (weights rotated so every launch streams them from HBM, as inside the model)
+    x = rn(2112, 3584)
+    wgu = [rn(37888, 3584, scale=0.02) for _ in range(2)]
+    for i in range(R):
+        ops.gemm(x, wgu[i % 2], act="swiglu", tile=22)
+    del wgu
+    h = rn(2112, 18944)
+    wd = [rn(3584, 18944, scale=0.02) for _ in range(2)]
+    for i in range(R):
+        ops.gemm(h, wd[i % 2], residual=x, tile=22)
+    del wd, h
+    wo = [rn(3584, 3584, scale=0.02) for _ in range(8)]
+    for i in range(2 * R):
+        ops.gemm(x, wo[i % 8], residual=x, tile=3)
+    xs = rn(32768, 576)
+    wq = [rn(1728, 576, scale=0.04) for _ in range(4)]
+    for i in range(R):
+        ops.gemm(xs, wq[i % 4], bias=rn(1728), tile=5)
+    # ---- causal decoder attention forward + backward
+    S, Hq, Hkv, D = 2112, 28, 4, 128
+    qkv = rn(S, Hq + 2 * Hkv, D)
+    q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hkv], qkv[:, Hq + Hkv:]
+    cu = torch.tensor([0, S], dtype=torch.int32, device=dev)
+    for i in range(R):
+        o, lse = ops.attn_varlen(q, k, v, cu, cu, S, D ** -0.5, causal=True, return_lse=True)
+    do = rn(S, Hq, D)
+    for i in range(R):
+        ops.attn_varlen_bwd(q, k, v, o, do, lse, cu, cu, S, S, D ** -0.5, True)
+    # ---- Hiera stage-3 windows (8 frames: 128 windows of 256 tokens, 8 heads x 72)
+    T, Hh, Dh = 32768, 8, 72
+    qkvh = rn(T, 3 * Hh, Dh)
+    cuw = torch.arange(0, T + 1, 256, dtype=torch.int32, device=dev)
+    for i in range(R):
+        ops.attn_varlen(qkvh[:, :Hh], qkvh[:, Hh:2 * Hh], qkvh[:, 2 * Hh:], cuw, cuw, 256, Dh ** -0.5, max_k=256)
+    # ---- SAM2 memory cross-attention at the full bank
+    mq, mk, mm = rn(4096, 256), rn(28736, 256), rn(28736, 64)
+    for i in range(R):
+        ops.memattn_cross(mq, mk, mm, 256 ** -0.5, partials=True)
+    torch.cuda.synchronize()
+    print("ok")
+
+
+def summarise(d, out):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"]
+                for t in TARGETS:
+                    if t in name:
+                        acc[t][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    res = {}
+    for t, cs in acc.items():
+        m = {k: sum(v) / len(v) for k, v in cs.items()}
+        e = {"launches": {k: len(v) for k, v in cs.items()}, "counters_mean_per_launch": {k: round(v, 1) for k, v in m.items()}}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+            e["kernel_cycles"] = round(cyc, 1)
+            e["mfma_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 4)
+        if m.get("SQ_WAVE_CYCLES"):
+            w = m["SQ_WAVE_CYCLES"]
+            for k, lab in (("SQ_WAIT_ANY", "wave_parked"), ("SQ_WAIT_INST_ANY", "wave_issue_stalled"), ("SQ_ACTIVE_INST_ANY", "wave_issuing"),
+                           ("SQ_ACTIVE_INST_VALU", "wave_valu"), ("SQ_ACTIVE_INST_LDS", "wave_lds_issue"), ("SQ_WAIT_INST_LDS", "wave_lds_stalled")):
+                if k in m:
+                    e[lab] = round(m[k] / w, 4)
+        if m.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_conflict_share"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"], 4)
+            if m.get("GRBM_GUI_ACTIVE"):
+                e["lds_array_busy"] = round(m["SQ_LDS_IDX_ACTIVE"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 256.0), 4)
+        res[t] = e
+    res["_derivation"] = ("mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); wave_* = share of SQ_WAVE_CYCLES; lds_array_busy = SQ_LDS_IDX_ACTIVE / "
+                          "(kernel cycles x 256 CUs); separate rocprofv3 --pmc passes per counter set, program directly after '--'")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("mfma_busy", "wave_parked", "wave_issue_stalled", "wave_issuing", "lds_array_busy", "lds_conflict_share")}
+                      for k, v in res.items() if isinstance(v, dict)}, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run()
+    else:
+        summarise(sys.argv[2], sys.argv[3])
