@@ -652,11 +652,12 @@ def measure_forward(model_fwd, inputs, args, rank, refine=True):
     assert torch.isfinite(lg).all(), "non-finite logits"
     real_gemm, seen, worst = ops.gemm, {}, [0.0, None]
 
-    def checked_gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.bfloat16, out=None, tile=-1, colscale=None):
-        r = real_gemm(a, w, bias, residual=residual, act=act, out_dtype=out_dtype, out=out, tile=tile, colscale=colscale)
+    def checked_gemm(a, w, bias=None, residual=None, act="none", out_dtype=torch.bfloat16, out=None, tile=-1, colscale=None, rms_in=None, rms_out=None):
+        r = real_gemm(a, w, bias, residual=residual, act=act, out_dtype=out_dtype, out=out, tile=tile, colscale=colscale, rms_in=rms_in, rms_out=rms_out)
         key = (a.shape[0], w.shape[0], a.shape[1], act, bias is not None, residual is not None)
         if key not in seen and out is None and tile == -1 and a.shape[0] > 4:
-            r10 = real_gemm(a, w, bias, residual=residual, act=act, out_dtype=out_dtype, tile=10, colscale=colscale)
+            # (the reference launch takes the same row sums in, but must not ADD its own into the caller's buffer a second time)
+            r10 = real_gemm(a, w, bias, residual=residual, act=act, out_dtype=out_dtype, tile=10, colscale=colscale, rms_in=rms_in)
             e = float((r.float() - r10.float()).norm() / (r10.float().norm() + 1e-30))
             seen[key] = e
             if e > worst[0]:

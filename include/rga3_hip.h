@@ -63,6 +63,18 @@ int rga3_last_error(char* buf, size_t n);
 int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, int act, int out_dtype, int tile,
                    void* workspace, int64_t workspace_bytes, void* stream);
+/* rga3_gemm_bf16 with an RMSNorm folded around it: replaces the norm launch + the write and re-read of the normalised rows between a residual-producing
+ * projection and the projection that consumes the normalised rows (HF modeling_qwen2_5_vl.py: Qwen2RMSNorm :470-486 between o_proj / down_proj and
+ * q|k|v / gate|up, :602-757; Qwen2_5_VLVisionBlock norm1 / norm2, :293-321).
+ *  consumer (row_sumsq_in != NULL): A = the un-normalised rows, W = weight with the norm weight folded in (W diag(gamma)); the accumulators are scaled by
+ *    1 / sqrt(row_sumsq_in[r] / 2^20 / norm_width + eps) before bias / activation (act as rga3_gemm_bf16, incl. SwiGLU);
+ *  producer (row_sumsq_out != NULL): the sums of squares of the bf16 rows written to C are ADDED to row_sumsq_out[r] as 2^20 fixed-point integers by no-return
+ *    integer atomics (the caller zeroes the array before the launch; any arrival order gives the same bits).
+ * bf16 output, M > 16, tiles with the shared epilogue (not 14 / 25 / 40 / 41). */
+int rga3_gemm_rms_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                       int64_t ldw, int64_t ldc, int64_t ldr, int act, int tile, void* workspace, int64_t workspace_bytes, const uint64_t* row_sumsq_in,
+                       int64_t norm_width, float eps, uint64_t* row_sumsq_out, void* stream);
+
 /* bytes of caller workspace tiles 22 / 25 want on the current device (4 KiB of flags + 256 KiB per CU; 0 on error).  The workspace is
  * zeroed ONCE by the caller and then kept for the calls of one stream (the kernels leave the flag words zero again); without it (NULL / too
  * small) those tilings run as 21 / 20. */

@@ -15,39 +15,11 @@
 //    row-major V image deliver.  Result again has the query on the lane: alpha scaling is lane-local.
 //  * K/V tiles are register-staged (global_load 16 B -> ds_write_b128) one tile ahead, into rows padded by
 //    32 B so that both the b128 K reads and the transposed V reads are bank-conflict-free.
-#include "common.h"
+#include "attn_args.h"
 #include <type_traits>
 
 namespace rga3 {
 
-struct AttnArgs {
-    const unsigned short* q;
-    const unsigned short* k;
-    const unsigned short* v;
-    unsigned short* o;
-    float* lse;
-    const int* cu_q;
-    const int* cu_k;
-    long q_st, q_sh, k_st, k_sh, v_st, v_sh, o_st, o_sh;
-    int Hq, Hkv, D;
-    long total_q;
-    float scale_log2;  // softmax scale * log2(e)
-    int causal;
-    // split-KV (few query blocks x heads, long key range: SAM2 memory attention is 64 workgroups of one head over 28 736 keys):
-    float* split_o;    // f32 [nsplit][total_q][Hq][D] normalised partial outputs
-    float* split_lse;  // f32 [nsplit][Hq][total_q] partial log2-sum-exp (of the scaled scores)
-    int nsplit;
-    // block-diagonal visibility inside a segment (several tiny windows packed into one segment: Hiera's 4- and 16-token windows would
-    // otherwise be one workgroup each): query i sees key j iff (i >> bq_shift) == (j >> bk_shift); -1 = off
-    int bq_shift, bk_shift;
-    // RoPE applied while loading (rotate-half pairing d <-> d +- D/2, tables [tokens, D] f32 indexed by the packed token): q always when rope_cos is set,
-    // k too when rope_kcos is set (windowed ViT attention loads every key exactly once per head, so the stand-alone rope pass disappears altogether)
-    const float* rope_cos;
-    const float* rope_sin;
-    const float* rope_kcos;
-    const float* rope_ksin;
-    int gx;            // workgroups per (segment, head): the grid is 1-D, gx * Hq * nseg, decoded XCD-aware in the kernel
-};
 
 // x[0..7] (bf16x8 as u32x4) of row `row_ptr` at column d, rotated: x cos + rotate_half(x) sin in f32, one bf16 rounding (rope_kernel's arithmetic)
 __device__ __forceinline__ u32x4 rope_chunk(u32x4 z, const unsigned short* row_ptr, int d, int D, const float* cs, const float* sn) {
@@ -731,8 +703,9 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
-    RGA3_CHECK_ARG(impl >= 0 && impl <= 3, "attn: impl %d", impl);
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 7, "attn: impl %d", impl);
     g_attn_variant = (impl & 2) ? 1 : 0;
+    const bool no_causal32 = (impl & 4) != 0;   // A/B and parity switch: keep the long causal rows on the general kernel
     impl &= 1;
     AttnArgs a;
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
@@ -763,6 +736,8 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
         }
     }
     hipStream_t st = (hipStream_t)stream;
+    // long causal rows at D = 128 (the decoder's prefill / training rows): 32-row waves balanced over the key range (attn_causal32.hip)
+    if (impl == 0 && g_attn_variant == 0 && !no_causal32 && causal && D == 128 && max_q >= 256 && block_q == 0) return launch_causal32(a, nseg, max_q, st);
     // whole-segment-in-LDS window kernel: non-causal, key range known and <= 256, D <= 96, 16-byte rows (impl bit 1 keeps the pipelined kernel: A/B)
     if (impl == 0 && g_attn_variant == 0 && !causal && a.nsplit == 1 && max_k > 0 && max_k <= 256 && D <= 96 && D % 8 == 0 &&
         (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0) {

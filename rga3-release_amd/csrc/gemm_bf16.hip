@@ -44,7 +44,15 @@ struct GemmArgs {
     const float* rowstat;  // LNF epilogues: [M][2] = (mean, 1/sqrt(var + eps)) of the rows of A (rga3_layernorm_stats)
     const float* colc;     // LNF epilogues: [N] column sums of the gamma-folded weight
     int ksl;      // gemm_nt_kernel only: K-tiles per grid.y slice (0: no split); slice y accumulates K-tiles [y ksl, (y+1) ksl) into f32 slab y of C
+    // RMSNorm folded into producer and consumer (rga3_gemm_rms_bf16): row sums of squares as 64-bit FIXED-POINT integers (2^20 per unit), so the cross-tile
+    // sum is a no-return integer atomic add -- associative, hence bitwise reproducible, unlike a float atomic.
+    const unsigned long long* rs_in = nullptr;   // [M]: sum_k A[r][k]^2 of the consumer's rows (A un-normalised, W with the norm weight folded in); null = off
+    float rs_in_scale = 0.f;                     // 2^-20 / (width of the normalised rows)
+    float rs_eps = 0.f;
+    unsigned long long* rs_out = nullptr;        // [M]: the output rows' sums of squares (of the bf16 values written) are ADDED here; null = off
 };
+
+constexpr float kRowSumFix = 1048576.0f;   // 2^20
 
 // 16 bytes of zeros in device memory: source for staging chunks that lie beyond K in the last K-tile
 __device__ const u32x4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -157,6 +165,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             ln_mean = st2.x;
             ln_rinv = st2.y;
         }
+        float rs_rinv = 1.f;   // RMSNorm of the A rows folded in: 1 / sqrt(mean(x^2) + eps) from the producer's fixed-point row sums
+        if (p.rs_in) {
+            const int rrow = min(m0 + wm * WTM + i * 16 + (lane & 15), p.M - 1);
+            rs_rinv = __builtin_amdgcn_rsqf((float)p.rs_in[rrow] * p.rs_in_scale + p.rs_eps);
+        }
 #pragma unroll
         for (int jo = 0; jo < OUT_NT; ++jo) {
             float v[4];
@@ -164,7 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 // packed weight layout: n-tile 2*jo = gate columns, 2*jo+1 = up columns of the same 16 outputs
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float gt = acc[i][2 * jo][r] + pc[2 * jo][r], up = acc[i][2 * jo + 1][r] + pc[2 * jo + 1][r];
+                    float gt = (acc[i][2 * jo][r] + pc[2 * jo][r]) * rs_rinv, up = (acc[i][2 * jo + 1][r] + pc[2 * jo + 1][r]) * rs_rinv;
                     if (p.bias) {
                         gt += pick(bpk[2 * jo], r);
                         up += pick(bpk[2 * jo + 1], r);
@@ -178,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][jo][r] + pc[jo][r];
+                    float x = (acc[i][jo][r] + pc[jo][r]) * rs_rinv;
                     if constexpr (LNF) x = ln_rinv * (x - ln_mean * cc[jo][r]);
                     if (p.bias) x += pick(bpk[jo], r);
                     if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
@@ -214,6 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 }
             }
         } else {
+            float rs_ss = 0.f;
 #pragma unroll
             for (int jo = 0; jo + 1 < OUT_NT; jo += 2) {
                 const auto r0 = __builtin_amdgcn_permlane16_swap(pk[jo][0], pk[jo + 1][0], false, false);
@@ -245,6 +259,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                     } else {
                         for (int e = 0; e < 8 && col + e < Nout; ++e) dst[e] = (unsigned short)(val[e >> 1] >> (16 * (e & 1)));
                     }
+                    if (p.rs_out) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v1 = (col + e < Nout) ? __uint_as_float((e & 1) ? (val[e >> 1] & 0xffff0000u) : (val[e >> 1] << 16)) : 0.f;
+                            rs_ss = __builtin_fmaf(v1, v1, rs_ss);
+                        }
+                    }
                 }
             }
             if constexpr (OUT_NT % 2 == 1) {  // leftover n-tile: 8 bytes per lane
@@ -265,7 +286,20 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 } else {
                     for (int e = 0; e < 4 && col + e < Nout; ++e) dst[e] = (unsigned short)(val[e >> 1] >> (16 * (e & 1)));
                 }
+                if (p.rs_out) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v1 = (col + e < Nout) ? __uint_as_float((e & 1) ? (val[e >> 1] & 0xffff0000u) : (val[e >> 1] << 16)) : 0.f;
+                        rs_ss = __builtin_fmaf(v1, v1, rs_ss);
+                    }
+                }
             }
+            }
+            if (p.rs_out) {
+                // the four lanes (g = 0..3) of a row hold different columns: one sum per row and wave, added as a fixed-point integer (order-free)
+                rs_ss += __shfl_xor(rs_ss, 16, 64);
+                rs_ss += __shfl_xor(rs_ss, 32, 64);
+                if (g == 0 && row_ok) atomicAdd(p.rs_out + row, (unsigned long long)(rs_ss * kRowSumFix + 0.5f));
             }
         }
     }
@@ -363,12 +397,45 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_all = (p.K + BK - 1) / BK;
-    static_assert(PIPE == 0, "the register-pipelined variant was removed (it spilled at 256x256 and lost to the ping-pong kernel)");
+    static_assert(PIPE == 0 || PIPE == 3, "PIPE: 0 = two LDS stages (one K-tile of prefetch), 3 = three stages (two K-tiles in flight)");
     // K split (tile 14, skinny products: M x 128 over K = 3584 is 66 tiles of 64 x 64): slice blockIdx.y takes ksl K-tiles and writes an f32 slab
     const int kt0 = p.ksl ? (int)blockIdx.y * p.ksl : 0;
     const int nk = p.ksl ? min(nk_all, kt0 + p.ksl) : nk_all;
     if (p.ksl) p.C = (void*)((float*)p.C + (long)blockIdx.y * p.M * p.ldc);
-    {
+    if constexpr (PIPE == 3) {
+        // Three LDS stages, TWO K-tiles of LDS-DMA in flight (cdna_hip_programming.md 5, "Pipelining across barriers": counted vmcnt, never 0 in the steady
+        // state, raw s_barrier).  With one tile of prefetch the loop waits out a whole memory round trip whenever a tile's load takes longer than one tile of
+        // MFMAs -- every K-tile when the weights stream from HBM (cold, as inside the model: tools/gemm_cold.py measured -10..20 % against warm operands).
+        // Order per K-tile: own loads of tile kt landed (all but the youngest tile's LPT loads) -> barrier (everyone's landed, and everyone has finished
+        // reading stage (kt - 1) % 3) -> refill that stage with tile kt + 2 -> consume stage kt % 3.
+        constexpr int LPT = APW + BPW;   // LDS-DMA instructions per lane and K-tile
+        stage_tile(0, kt0, kt0 + 1 == nk_all);
+        if (kt0 + 1 < nk) stage_tile(1, kt0 + 1, kt0 + 2 == nk_all);
+        int s0 = 0;
+        for (int kt = kt0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int s2 = s0 >= 1 ? s0 - 1 : 2;   // (s0 + 2) % 3
+            if (kt + 2 < nk) stage_tile(s2, kt + 2, kt + 3 == nk_all);
+            const char* As = smem + s0 * STAGE + (wm * WTM) * ROWB;
+            const char* Bs = smem + s0 * STAGE + BM * ROWB + (wn * WTN) * ROWB;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[MT], wf[NTL];
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) wf[j] = *(const bf16x8*)(Bs + j * 16 * ROWB + foff[kk]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(As + i * 16 * ROWB + foff[kk]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            s0 = s0 == 2 ? 0 : s0 + 1;
+        }
+    } else {
     stage_tile(kt0 & 1, kt0, kt0 + 1 == nk_all);
     for (int kt = kt0; kt < nk; ++kt) {
         // tile kt has landed (own loads: vmcnt(0); everyone's: barrier) and everyone is done reading
@@ -1085,7 +1152,8 @@ static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     a.ntn = (int)cdiv(a.N, BN);
     a.group_m = pick_group_m(a.ntm, BM);
     constexpr int STAGE = (BM + BN) * 128;
-    constexpr int LDS = 2 * STAGE;
+    constexpr int LDS = (PIPE == 3 ? 3 : 2) * STAGE;
+    static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, ACT, OUT_F32, PIPE, LNF>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
@@ -1599,6 +1667,11 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 5:   // 128x192: N = 576 = 3 x 192 (Hiera stage-3 proj / fc2 outputs: 2.25 tiles of 256 otherwise); 3 n-tiles per wave, so no SwiGLU pairs
             if constexpr (ACT != ACT_SWIGLU) return launch_cfg<128, 192, 2, 4, ACT, OUT_F32, 0>(a, st);
             else return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
+        case 6: return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 3>(a, st);   // 128x256, three LDS stages (144 KiB): two K-tiles in flight (cold weights)
+        case 7:   // 128x192, three stages (120 KiB, one workgroup per CU)
+            if constexpr (ACT != ACT_SWIGLU) return launch_cfg<128, 192, 2, 4, ACT, OUT_F32, 3>(a, st);
+            else return launch_cfg<128, 256, 2, 4, ACT, OUT_F32, 3>(a, st);
+        case 8: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 3>(a, st);   // 128x128 on 4 waves, three stages (96 KiB)
         case 10: return launch_cfg<256, 256, 2, 4, ACT, OUT_F32, 0>(a, st);
         case 13: return launch_cfg<64, 64, 2, 2, ACT, OUT_F32, 0>(a, st);   // small products (SAM2 per-frame 4096 x 256 x 256: 256 tiles instead of 64)
         case 14:   // 64 x 64 with a K split (skinny plain products)
@@ -1670,9 +1743,39 @@ extern "C" int64_t rga3_gemm_timeout_counter_offset(void) {
     return (int64_t)cus * 4;
 }
 
+static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
+                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
+                          int act, int out_dtype, int tile, void* workspace, int64_t workspace_bytes, const unsigned long long* rs_in, int64_t rs_width, float rs_eps,
+                          unsigned long long* rs_out, void* stream);
+
 extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
                               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                               int act, int out_dtype, int tile, void* workspace, int64_t workspace_bytes, void* stream) {
+    return gemm_bf16_impl(A, W, bias, residual, colscale, C, M, N, K, lda, ldw, ldc, ldr, act, out_dtype, tile, workspace, workspace_bytes, nullptr, 0, 0.f, nullptr, stream);
+}
+
+// rga3_gemm_bf16 with an RMSNorm folded around it (HF Qwen2RMSNorm, modeling_qwen2_5_vl.py:470-486 / Qwen2_5_VLRMSNorm; the norm -> projection pairs of
+// :602-757 and :211-321).  Consumer side (row_sumsq_in): A holds the UN-normalised rows x, W the weight with the norm weight folded in (W' = W diag(gamma)), and
+//   RMSNorm(x) W^T = rinv_r (x W'^T),  rinv_r = 1 / sqrt(row_sumsq_in[r] / 2^20 / norm_width + eps)
+// is applied to the accumulators before bias / activation.  Producer side (row_sumsq_out): the sums of squares of the bf16 output rows are ADDED to
+// row_sumsq_out[r] as fixed-point integers (the caller zeroes it; integer atomics: any arrival order gives the same bits).  bf16 output only; tiles whose
+// epilogue is the shared one (not 14 / 25 / 40 / 41).
+extern "C" int rga3_gemm_rms_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                  int64_t ldw, int64_t ldc, int64_t ldr, int act, int tile, void* workspace, int64_t workspace_bytes, const uint64_t* row_sumsq_in,
+                                  int64_t norm_width, float eps, uint64_t* row_sumsq_out, void* stream) {
+    RGA3_CHECK_ARG(row_sumsq_in || row_sumsq_out, "gemm_rms: neither row_sumsq_in nor row_sumsq_out given (use rga3_gemm_bf16)");
+    RGA3_CHECK_ARG(!row_sumsq_in || (norm_width > 0 && eps >= 0.f), "gemm_rms: norm_width %ld eps %g", (long)norm_width, (double)eps);
+    RGA3_CHECK_ARG((((uintptr_t)row_sumsq_in | (uintptr_t)row_sumsq_out) & 7) == 0, "gemm_rms: row sums must be 8-byte aligned");
+    RGA3_CHECK_ARG(tile != 14 && tile != 25 && tile != 40 && tile != 41, "gemm_rms: tile %d has its own epilogue", tile);
+    RGA3_CHECK_ARG(M > 16, "gemm_rms: M %ld (token-row products take the unfused route)", (long)M);
+    return gemm_bf16_impl(A, W, bias, residual, nullptr, C, M, N, K, lda, ldw, ldc, ldr, act, RGA3_BF16, tile, workspace, workspace_bytes,
+                          (const unsigned long long*)row_sumsq_in, norm_width, eps, (unsigned long long*)row_sumsq_out, stream);
+}
+
+static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
+                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
+                          int act, int out_dtype, int tile, void* workspace, int64_t workspace_bytes, const unsigned long long* rs_in, int64_t rs_width, float rs_eps,
+                          unsigned long long* rs_out, void* stream) {
     RGA3_CHECK_ARG(A && W && C, "gemm: null pointer");
     RGA3_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     RGA3_CHECK_ARG(K % 8 == 0, "gemm: K=%ld must be a multiple of 8 (16-byte staging chunks)", (long)K);
@@ -1682,7 +1785,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 4 || tile == 5 || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || (tile >= 3 && tile <= 8) || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;
@@ -1694,6 +1797,7 @@ extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, co
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.ws = workspace; a.ws_bytes = workspace_bytes; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
+    a.rs_in = rs_in; a.rs_in_scale = rs_in ? 1.0f / (kRowSumFix * (float)rs_width) : 0.f; a.rs_eps = rs_eps; a.rs_out = rs_out;
     hipStream_t st = (hipStream_t)stream;
     RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
     const bool rows16_ok = M <= 16 && !colscale && out_dtype == RGA3_BF16 && act != ACT_SWIGLU;
@@ -1713,6 +1817,8 @@ static int launch_ln(const GemmArgs& a, int tile, hipStream_t st) {
     switch (tile) {
         case 3: return launch_cfg<128, 256, 2, 4, ACT, false, 0, true>(a, st);
         case 5: return launch_cfg<128, 192, 2, 4, ACT, false, 0, true>(a, st);
+        case 6: return launch_cfg<128, 256, 2, 4, ACT, false, 3, true>(a, st);
+        case 7: return launch_cfg<128, 192, 2, 4, ACT, false, 3, true>(a, st);
         case 13: return launch_cfg<64, 64, 2, 2, ACT, false, 0, true>(a, st);
         case 20: return launch_pp<ACT, false, true>(a, st);
         default: return launch_cfg<128, 128, 2, 2, ACT, false, 0, true>(a, st);
@@ -1729,7 +1835,7 @@ extern "C" int rga3_gemm_ln_bf16(const void* A, const void* Wf, const void* bias
     RGA3_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "gemm_ln: lda/ldw must be multiples of 8 elements");
     RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)C | (uintptr_t)colc) & 15) == 0 && (((uintptr_t)rowstat) & 7) == 0, "gemm_ln: pointer alignment");
     RGA3_CHECK_ARG(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU, "gemm_ln: act %d", act);
-    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 5 || tile == 12 || tile == 13 || tile == 20, "gemm_ln: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || (tile >= 5 && tile <= 7) || tile == 12 || tile == 13 || tile == 20, "gemm_ln: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm_ln: operands must be < 2^32 elements");
     GemmArgs a;
     a.A = (const unsigned short*)A; a.W = (const unsigned short*)Wf; a.C = C;

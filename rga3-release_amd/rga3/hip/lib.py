@@ -19,6 +19,7 @@ SIGNATURES = {
     "rga3_version": [],
     "rga3_last_error": [C.c_char_p, _sz],
     "rga3_gemm_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _p, _i64, _p],
+    "rga3_gemm_rms_bf16": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p, _i64, _p, _i64, _f, _p, _p],
     "rga3_gemm_workspace_bytes": [],
     "rga3_gemm_tn_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _p, _i64, _p, _p],
     "rga3_attn_varlen_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,

@@ -66,8 +66,14 @@ def gemm_stream_k_timeouts(device=None) -> int:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = "none", out_dtype=torch.bfloat16,
-         out=None, tile: int = -1, colscale=None) -> torch.Tensor:
-    """out = residual + colscale * act(a @ w.T + bias).  a [M,K], w [N,K] (nn.Linear layout), bf16."""
+         out=None, tile: int = -1, colscale=None, rms_in=None, rms_out=None) -> torch.Tensor:
+    """out = residual + colscale * act(a @ w.T + bias).  a [M,K], w [N,K] (nn.Linear layout), bf16.
+
+    RMSNorm folded around the product (rga3_gemm_rms_bf16; M > 16, bf16 output, no column scale):
+      rms_in = (row_sumsq [M] int64, norm_width, eps): ``a`` holds the UN-normalised rows and ``w`` the weight with the norm weight folded in
+               (w * gamma[None, :]); the accumulators are scaled by 1 / sqrt(row_sumsq / 2^20 / norm_width + eps) before bias / activation;
+      rms_out = [M] int64 (zeroed by the caller): the sums of squares of the bf16 rows written are ADDED to it as 2^20 fixed-point integers
+                (integer atomics: any order, same bits) -- the rms_in of the product that consumes the normalised rows."""
     _need_cuda(a, w, bias, residual, out, colscale)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
@@ -97,10 +103,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     odt = BF16 if out_dtype == torch.bfloat16 else F32
     ws = gemm_workspace(a.device)
 
-    def run(t):
-        _lib.check(fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(colscale), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
-                      out.stride(0), ldr, ACT[act], odt, t, ws.data_ptr(), ws.numel(), _stream()), "gemm_bf16")
+    rms = rms_in is not None or rms_out is not None
+    if rms:
+        assert M > 16 and out_dtype == torch.bfloat16 and colscale is None, "gemm: the RMSNorm-folded form takes M > 16, bf16 output, no column scale"
+        rs_t, rs_width, rs_eps = rms_in if rms_in is not None else (None, 0, 0.0)
+        for t_ in (rs_t, rms_out):
+            assert t_ is None or (t_.is_cuda and t_.dtype == torch.int64 and t_.numel() == M and t_.is_contiguous())
+        fn_rms = _lib.load().rga3_gemm_rms_bf16
 
+    def run(t, final=True):
+        ro = rms_out if (rms and final) else None      # tuner trials must not ADD into the caller's row sums: only the final launch carries rms_out
+        if rms and (rs_t is not None or ro is not None):
+            _lib.check(fn_rms(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr,
+                              ACT[act], t, ws.data_ptr(), ws.numel(), _ptr(rs_t), int(rs_width), float(rs_eps), _ptr(ro), _stream()), "gemm_rms_bf16")
+        else:
+            _lib.check(fn(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), _ptr(colscale), out.data_ptr(), M, N, K, a.stride(0), w.stride(0),
+                          out.stride(0), ldr, ACT[act], odt, t, ws.data_ptr(), ws.numel(), _stream()), "gemm_bf16")
+
+    if rms:
+        if tile == -1:
+            tile = _tuner.pick(_tuner.key_of(M, N, K, act, odt, bias is not None, residual is not None), lambda t: run(t, final=False))
+            if tile in (14, 25, 40, 41):     # decided for the plain product of the same shape: those tilings have their own epilogues
+                tile = -1
+        run(tile)
+        return out
     if tile == -1 and M <= 4 and colscale is None:
         tile = 40   # decode step: a weight stream, not a tiled product (gemv_kernel)
     if tile == -1 and M * N * K >= (1 << 24) and not (residual is not None and residual.data_ptr() == out.data_ptr()):

@@ -175,6 +175,29 @@ def _versions(*params):
     return tuple((p.data_ptr(), p._version, p.dtype) for p in params if p is not None)
 
 
+# RMSNorm folded into the products on either side of it (inference / frozen towers only): the residual-producing projection (o_proj, down_proj, the ViT's proj /
+# fc2) leaves the row sums of squares of what it writes (rga3_gemm_rms_bf16, rms_out), the projection that consumes the normalised rows (q|k|v, gate|up) takes the
+# UN-normalised rows with the norm weight folded into its weight and scales its accumulators by 1 / rms (rms_in).  The stand-alone norm launch and the write +
+# re-read of the normalised rows disappear (2 x 57 launches of ~9 us in the decoder, 2 x 32 in the vision tower: profiles/r03_bench_forward_kernel_stats.csv).
+# Rounding differs from the eager order by the bf16 rounding of gamma * W (instead of the normalised rows): inside the stated 2e-2.  RGA3_RMS_FOLD=0 switches it off.
+_RMS_FOLD = os.environ.get("RGA3_RMS_FOLD", "1") != "0"
+
+
+def rms_fold_enabled() -> bool:
+    return _RMS_FOLD
+
+
+def set_rms_fold(on: bool):
+    """A/B switch (bench.py --no-rms-fold, tests)."""
+    global _RMS_FOLD
+    _RMS_FOLD = bool(on)
+
+
+def _fold_ok(x2d, *mods) -> bool:
+    # (no gradient is recorded under no_grad whatever requires_grad says; the folded weight copies follow their sources' version counters)
+    return _RMS_FOLD and not torch.is_grad_enabled() and x2d.shape[0] > 16 and x2d.dtype == torch.bfloat16 and _is_plain(*mods)
+
+
 def _interleave_rows(g: torch.Tensor, u: torch.Tensor, pad_to: int) -> torch.Tensor:
     """[I, K] gate / up -> [2*Ip, K] with 16-row blocks alternating gate / up (GEMM SwiGLU epilogue layout)."""
     I = g.shape[0]
@@ -211,11 +234,27 @@ class GatedMLP(nn.Module):
             self._pk = (key, wgu, bgu, wd)
         return self._pk[1:]
 
-    def forward(self, x2d, residual):
+    def _packed_folded(self, norm):
+        """gate|up pack with the preceding RMSNorm's weight folded in (W diag(gamma), one bf16 rounding), rebuilt when a source changes."""
+        wgu, _, _ = self._packed()
+        key = (self._pk[0], _versions(norm.weight))
+        pf = self.__dict__.get("_pkf")
+        if pf is None or pf[0] != key:
+            with torch.no_grad():
+                pf = (key, (wgu.float() * norm.weight.detach().float()[None, :]).to(wgu.dtype).contiguous())
+            self.__dict__["_pkf"] = pf
+        return pf[1]
+
+    def forward(self, x2d, residual, fold=None, rms_out=None):
+        """fold = (norm module, row sums of squares of x2d): x2d is then the UN-normalised row block (== residual) and the norm is applied inside the gate|up product."""
         if _is_plain(self.gate_proj, self.up_proj, self.down_proj):
             wgu, bgu, wd = self._packed()
-            a = ops.gemm(x2d, wgu, bgu, act="swiglu")
-            return ops.gemm(a, wd, self.down_proj.bias, residual=residual)
+            if fold is not None:
+                norm, rs = fold
+                a = ops.gemm(x2d, self._packed_folded(norm), bgu, act="swiglu", rms_in=(rs, x2d.shape[1], norm.variance_epsilon))
+            else:
+                a = ops.gemm(x2d, wgu, bgu, act="swiglu")
+            return ops.gemm(a, wd, self.down_proj.bias, residual=residual, rms_out=rms_out)
         a = ops.silu_mul(self.gate_proj(x2d).contiguous(), self.up_proj(x2d).contiguous())
         return ops.add(self.down_proj(a).contiguous(), residual)
 
@@ -249,16 +288,31 @@ class VisionAttention(nn.Module):
         self.qkv = Linear(c.hidden_size, c.hidden_size * 3, bias=True)
         self.proj = Linear(c.hidden_size, c.hidden_size, bias=True)
 
-    def forward(self, h, residual, cu, max_len, cos, sin):
+    def _qkv_folded(self, norm):
+        key = _versions(self.qkv.weight, norm.weight)
+        pf = self.__dict__.get("_pkf")
+        if pf is None or pf[0] != key:
+            with torch.no_grad():
+                pf = (key, (self.qkv.weight.detach().float() * norm.weight.detach().float()[None, :]).to(self.qkv.weight.dtype).contiguous())
+            self.__dict__["_pkf"] = pf
+        return pf[1]
+
+    def forward(self, h, residual, cu, max_len, cos, sin, fold=None, rms_out=None):
         N = h.shape[0]
         H, D = self.num_heads, self.head_dim
-        qkv = self.qkv(h).view(N, 3 * H, D)
+        if fold is not None:      # h is the un-normalised row block: norm1 is applied inside the qkv product
+            norm, rs = fold
+            qkv = ops.gemm(h, self._qkv_folded(norm), self.qkv.bias, rms_in=(rs, h.shape[1], norm.variance_epsilon)).view(N, 3 * H, D)
+        else:
+            qkv = self.qkv(h).view(N, 3 * H, D)
         if ops.attn_rope_win_ok(max_len, D) and not torch.is_grad_enabled():
             # windows: every key is loaded once per head, so q AND k are rotated while the attention kernel loads them -- no rope pass at all
             att = ops.attn_varlen_rope(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False, rope_k=True)
         else:
             ops.rope_(qkv, cos, sin, 0, 2 * H)  # q heads then k heads are contiguous in the fused buffer
             att = ops.attn_varlen(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, causal=False, max_k=max_len)
+        if rms_out is not None:
+            return ops.gemm(att.view(N, H * D), self.proj.weight, self.proj.bias, residual=residual, rms_out=rms_out)
         return self.proj(att.view(N, H * D), residual=residual)
 
 
@@ -270,9 +324,17 @@ class VisionBlock(nn.Module):
         self.attn = VisionAttention(c)
         self.mlp = GatedMLP(c.hidden_size, c.intermediate_size, bias=True)
 
-    def forward(self, x, cu, max_len, cos, sin):
-        x = self.attn(self.norm1(x), x, cu, max_len, cos, sin)
-        return self.mlp(self.norm2(x), x)
+    def forward(self, x, cu, max_len, cos, sin, rs=None):
+        """rs = (row sums of squares of x or None, buffer for this block's mid sums, buffer for the sums of this block's output or None): the RMSNorm-folded route."""
+        if rs is None:
+            x = self.attn(self.norm1(x), x, cu, max_len, cos, sin)
+            return self.mlp(self.norm2(x), x)
+        rs_x, rs_mid, rs_next = rs
+        if rs_x is None:       # first block: nothing produced the sums of its input
+            x = self.attn(self.norm1(x), x, cu, max_len, cos, sin, rms_out=rs_mid)
+        else:
+            x = self.attn(x, x, cu, max_len, cos, sin, fold=(self.norm1, rs_x), rms_out=rs_mid)
+        return self.mlp(x, x, fold=(self.norm2, rs_mid), rms_out=rs_next)
 
 
 class PatchMerger(nn.Module):
@@ -335,11 +397,15 @@ class VisionTransformer(nn.Module):
         unit = c.spatial_merge_size ** 2
         x = self.patch_embed(pixel_values.to(self.dtype))
         x = ops.gather_rows(x, pl["window_index"], rows_per_idx=unit)
+        fold = _fold_ok(x, *[m_ for b_ in self.blocks for m_ in (b_.attn.qkv, b_.attn.proj, b_.mlp.gate_proj, b_.mlp.up_proj, b_.mlp.down_proj)])
+        nb = len(self.blocks)
+        sums = torch.zeros((2 * nb, x.shape[0]), dtype=torch.int64, device=x.device) if fold else None    # one memset for the whole tower
         for i, blk in enumerate(self.blocks):
+            rs = (sums[2 * i - 1] if i > 0 else None, sums[2 * i], sums[2 * i + 1] if i + 1 < nb else None) if fold else None
             if i in c.fullatt_block_indexes:
-                x = blk(x, pl["cu_full"], pl["max_full"], pl["cos"], pl["sin"])
+                x = blk(x, pl["cu_full"], pl["max_full"], pl["cos"], pl["sin"], rs=rs)
             else:
-                x = blk(x, pl["cu_win"], pl["max_win"], pl["cos"], pl["sin"])
+                x = blk(x, pl["cu_win"], pl["max_win"], pl["cos"], pl["sin"], rs=rs)
         m = self.merger(x)
         out = torch.empty_like(m)
         ops.scatter_rows_(out, pl["window_index"], m)  # == merged[argsort(window_index)]
@@ -369,10 +435,24 @@ class DecoderAttention(nn.Module):
             self._pk = (key, w, b)
         return self._pk[1:]
 
-    def forward(self, h, residual, cos, sin, cu, max_len, cache=None):
+    def _packed_folded(self, norm):
+        w, _ = self._packed()
+        key = (self._pk[0], _versions(norm.weight))
+        pf = self.__dict__.get("_pkf")
+        if pf is None or pf[0] != key:
+            with torch.no_grad():
+                pf = (key, (w.float() * norm.weight.detach().float()[None, :]).to(w.dtype).contiguous())
+            self.__dict__["_pkf"] = pf
+        return pf[1]
+
+    def forward(self, h, residual, cos, sin, cu, max_len, cache=None, fold=None, rms_out=None):
         T = h.shape[0]
         Hq, Hk, D = self.num_heads, self.num_kv, self.head_dim
-        if _is_plain(self.q_proj, self.k_proj, self.v_proj):
+        if fold is not None:      # h is the un-normalised row block: input_layernorm is applied inside the q|k|v product
+            norm, rs = fold
+            _, b = self._packed()
+            qkv = ops.gemm(h, self._packed_folded(norm), b, rms_in=(rs, h.shape[1], norm.variance_epsilon)).view(T, Hq + 2 * Hk, D)
+        elif _is_plain(self.q_proj, self.k_proj, self.v_proj):
             w, b = self._packed()
             qkv = ops.gemm(h, w, b).view(T, Hq + 2 * Hk, D)
         elif all(type(m).__name__ in ("Linear", "LoRALinear") and type(m).__module__.startswith("rga3.") for m in (self.q_proj, self.k_proj, self.v_proj)):
@@ -387,6 +467,8 @@ class DecoderAttention(nn.Module):
             k, v, cu_k = cache.update(self.layer_idx, k, v, cu)
         # decode step (one query per sequence): every cached key is visible, and the non-causal form may split the key range over workgroups
         att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
+        if rms_out is not None:
+            return ops.gemm(att.view(T, Hq * D), self.o_proj.weight, self.o_proj.bias, residual=residual, rms_out=rms_out)
         return self.o_proj(att.view(T, Hq * D), residual=residual)
 
 
@@ -398,9 +480,17 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(c.hidden_size, c.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(c.hidden_size, c.rms_norm_eps)
 
-    def forward(self, x, cos, sin, cu, max_len, cache=None):
-        x = self.self_attn(self.input_layernorm(x), x, cos, sin, cu, max_len, cache)
-        return self.mlp(self.post_attention_layernorm(x), x)
+    def forward(self, x, cos, sin, cu, max_len, cache=None, rs=None):
+        """rs = (sums of squares of x's rows or None, buffer for the post-attention sums, buffer for the sums of this layer's output or None): RMSNorm-folded route."""
+        if rs is None:
+            x = self.self_attn(self.input_layernorm(x), x, cos, sin, cu, max_len, cache)
+            return self.mlp(self.post_attention_layernorm(x), x)
+        rs_x, rs_mid, rs_next = rs
+        if rs_x is None:       # first layer: the embeddings come without sums
+            x = self.self_attn(self.input_layernorm(x), x, cos, sin, cu, max_len, cache, rms_out=rs_mid)
+        else:
+            x = self.self_attn(x, x, cos, sin, cu, max_len, cache, fold=(self.input_layernorm, rs_x), rms_out=rs_mid)
+        return self.mlp(x, x, fold=(self.post_attention_layernorm, rs_mid), rms_out=rs_next)
 
 
 class KVCache:
@@ -506,8 +596,13 @@ class TextModel(nn.Module):
     def forward(self, x, pos3, cu, max_len, cache=None, collect_hidden=False):
         cos, sin = self.mrope_tables(pos3)
         hs = [x] if collect_hidden else None
-        for layer in self.layers:
-            x = layer(x, cos, sin, cu, max_len, cache)
+        fold = _fold_ok(x, *[m_ for l_ in self.layers for m_ in (l_.self_attn.q_proj, l_.self_attn.k_proj, l_.self_attn.v_proj, l_.self_attn.o_proj,
+                                                                  l_.mlp.gate_proj, l_.mlp.up_proj, l_.mlp.down_proj)])
+        nl = len(self.layers)
+        sums = torch.zeros((2 * nl, x.shape[0]), dtype=torch.int64, device=x.device) if fold else None    # one memset for all layers
+        for i, layer in enumerate(self.layers):
+            rs = (sums[2 * i - 1] if i > 0 else None, sums[2 * i], sums[2 * i + 1] if i + 1 < nl else None) if fold else None
+            x = layer(x, cos, sin, cu, max_len, cache, rs=rs)
             if collect_hidden:
                 hs.append(x)
         x = self.norm(x)

@@ -150,6 +150,46 @@ def test_gemm_rejects_bad_args(dev):
         ops.gemm(a.cpu(), w.cpu())
 
 
+@pytest.mark.parametrize("tile", [-1, 3, 12, 5, 6, 20, 21, 22, 31, 32])
+@pytest.mark.parametrize("shape", [(300, 320, 256), (2112, 1280, 1280)])
+def test_gemm_rmsnorm_folded(dev, tile, shape):
+    """RMSNorm folded into the products on either side (rga3_gemm_rms_bf16; HF Qwen2RMSNorm modeling_qwen2_5_vl.py:470-486 between o_proj / down_proj and
+    q|k|v / gate|up).  Producer: x2 = a W_o^T + r leaves the row sums of squares of the bf16 rows it writes as 2^20 fixed-point integers (integer atomics:
+    bit-identical run to run).  Consumer: (x2 (W diag(gamma))^T) / rms + b, plain and with the SwiGLU epilogue, against RMSNorm -> Linear in fp32."""
+    from rga3.hip import ops
+
+    M, N, K = shape
+    a, wo, r = _rand((M, K), dev, seed=1), _rand((N, K), dev, 0.05, seed=2), _rand((M, N), dev, seed=3)
+    sums = torch.zeros(M, dtype=torch.int64, device=dev)
+    x2 = ops.gemm(a, wo, residual=r, tile=tile, rms_out=sums)
+    assert torch.equal(x2, ops.gemm(a, wo, residual=r, tile=tile))            # the sums ride along: the product itself is unchanged
+    ss_ref = (x2.double() ** 2).sum(1)
+    assert ((sums.double() / 2 ** 20 - ss_ref).abs() / ss_ref).max().item() < 1e-5
+    sums2 = torch.zeros_like(sums)
+    ops.gemm(a, wo, residual=r, tile=tile, rms_out=sums2)
+    assert torch.equal(sums, sums2)
+    # consumer
+    gamma = (1.0 + 0.3 * torch.randn(N, generator=torch.Generator().manual_seed(4))).to(torch.bfloat16).to(dev)
+    eps = 1e-6
+    N2 = 384
+    w2, b2 = _rand((N2, N), dev, 0.05, seed=5), _rand((N2,), dev, seed=6)
+    wf = (w2.float() * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    xf = x2.float()
+    xn = (xf * torch.rsqrt((xf ** 2).mean(-1, keepdim=True) + eps)).to(torch.bfloat16).float() * gamma.float()     # HF: normalised rows rounded, then * weight
+    xn = xn.to(torch.bfloat16).float()
+    ref = xn @ w2.float().t() + b2.float()
+    y = ops.gemm(x2, wf, b2, tile=tile, rms_in=(sums, N, eps))
+    assert _rel_l2(y, ref) < 1e-2, (tile, shape)
+    # SwiGLU epilogue on the interleaved gate / up pack (16-row blocks)
+    g_w, u_w = w2[:192], w2[192:]
+    pack = torch.stack([g_w.view(12, 16, N), u_w.view(12, 16, N)], 1).reshape(N2, N)
+    packf = (pack.float() * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    gt, up = (xn @ g_w.float().t()).to(torch.bfloat16).float(), (xn @ u_w.float().t()).to(torch.bfloat16).float()
+    ref_s = torch.nn.functional.silu(gt).to(torch.bfloat16).float() * up
+    ys = ops.gemm(x2, packf, None, act="swiglu", tile=tile, rms_in=(sums, N, eps))
+    assert _rel_l2(ys, ref_s) < 1.5e-2, (tile, shape)
+
+
 ATTN_CASES = [
     # (seglens_q, seglens_k, Hq, Hkv, D, causal)
     ([64] * 6, None, 4, 4, 80, False),            # ViT windows
@@ -194,6 +234,70 @@ def test_attn_varlen(dev, case, impl):
     out, lse = ops.attn_varlen(q, k, v, cu_q.to(dev), cu_k.to(dev), max(lq), scale, causal, return_lse=True, impl=impl, max_k=max(lk))
     ref, lse_ref = R.attn_varlen_ref(q.cpu(), k.cpu(), v.cpu(), cu_q, cu_k, scale, causal)
     assert _rel_l2(out, ref) < 1e-2, (case, impl)
+    assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
+
+
+CAUSAL32_CASES = [
+    # (seglens_q, seglens_k, Hq, Hkv): causal, D = 128, longest segment >= 256 rows -> attn_causal32_kernel (32-row waves, key range of the heavy block split over
+    # the light block's waves, partial results merged in LDS)
+    ([2112], None, 28, 4),                 # the decoder's rows of the bench (17 blocks of 128: 8 pairs + the unpaired middle block; last block 64 rows)
+    ([256], None, 2, 1),                   # two blocks: one pair, nothing to split (kH - c = 1)
+    ([257], None, 2, 2),                   # three blocks, the last one a single row
+    ([385, 1, 700], None, 4, 2),           # ragged segments incl. a one-token segment (grid sized by the longest)
+    ([300], [900], 2, 1),                  # Lk > Lq (prefill against a cache): every row sees >= 601 keys
+    ([1000], [1037], 3, 3),                # shift not a multiple of the tile
+    ([4160], None, 4, 2),                  # config-5 length (33 blocks)
+    ([128, 640, 129, 1000, 512], None, 6, 2),
+]
+
+
+@pytest.mark.parametrize("case", CAUSAL32_CASES)
+def test_attn_causal32(dev, case):
+    """Long causal rows at D = 128 (csrc/attn_causal32.hip; HF modeling_qwen2_5_vl.py:602-700 through flash-attn varlen causal): against the fp32 softmax oracle at
+    the stated 1e-2 / 2e-2, against the general kernel it replaces (impl = 4 keeps that one), run-to-run bit-identical."""
+    from rga3.hip import ops
+
+    lq, lk, Hq, Hkv = case
+    lk = lk or lq
+    D = 128
+    cu_q = torch.tensor([0] + list(torch.tensor(lq).cumsum(0)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(torch.tensor(lk).cumsum(0)), dtype=torch.int32)
+    Tq, Tk = int(cu_q[-1]), int(cu_k[-1])
+    q = _rand((Tq, Hq, D), dev, seed=21)
+    kv = _rand((Tk, 2, Hkv, D), dev, seed=22)
+    k, v = kv[:, 0], kv[:, 1]
+    scale = D ** -0.5
+    out, lse = ops.attn_varlen(q, k, v, cu_q.to(dev), cu_k.to(dev), max(lq), scale, True, return_lse=True, max_k=max(lk))
+    ref, lse_ref = R.attn_varlen_ref(q.cpu(), k.cpu(), v.cpu(), cu_q, cu_k, scale, True)
+    assert _rel_l2(out, ref) < 1e-2, case
+    assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
+    old, lse_old = ops.attn_varlen(q, k, v, cu_q.to(dev), cu_k.to(dev), max(lq), scale, True, return_lse=True, max_k=max(lk), impl=4)
+    assert _rel_l2(out, old.float().cpu()) < 6e-3 and (lse - lse_old).abs().max().item() < 1e-3
+    again, lse2 = ops.attn_varlen(q, k, v, cu_q.to(dev), cu_k.to(dev), max(lq), scale, True, return_lse=True, max_k=max(lk))
+    assert torch.equal(out, again) and torch.equal(lse, lse2)
+
+
+def test_attn_causal32_rescale_branch(dev):
+    """The online-softmax rescale fires only when a later tile raises a row's maximum (cdna_hip_programming.md 5.4 rule 26: a rare data-dependent branch needs an
+    input that FORCES it).  Keys far down the row are aligned with their queries and scaled up, so the maximum of most rows jumps in the LAST tiles -- in group A's
+    range for some rows, in group B's range (the merged partial) for others."""
+    from rga3.hip import ops
+
+    S, Hq, Hkv, D = 1536, 2, 1, 128
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(S, Hq, D, generator=g)
+    k = torch.randn(S, Hkv, D, generator=g) * 0.3
+    v = torch.randn(S, Hkv, D, generator=g)
+    for i in range(64, S, 7):            # key i - 3 points along query i of head 0: a late, large score (visible: i - 3 <= i)
+        k[i - 3, 0] = q[i, 0] * 1.5
+    for i in range(700, S, 5):           # and an early one for other rows, so both key halves of a split row carry a spike somewhere
+        k[i // 3, 0] = q[i, 1] * 1.2
+    q, k, v = (t.to(torch.bfloat16).to(dev) for t in (q, k, v))
+    cu = torch.tensor([0, S], dtype=torch.int32)
+    out, lse = ops.attn_varlen(q, k, v, cu.to(dev), cu.to(dev), S, D ** -0.5, True, return_lse=True)
+    ref, lse_ref = R.attn_varlen_ref(q.cpu(), k.cpu(), v.cpu(), cu, cu, D ** -0.5, True)
+    assert _rel_l2(out, ref) < 1e-2
+    assert (out.float().cpu() - ref).abs().max().item() < 6e-2
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
 
 

@@ -51,6 +51,44 @@ def test_full_forward_parity(model, dev):
     assert out.logits[~m].abs().sum().item() == 0  # pad rows are not computed (packed tokens)
 
 
+def test_rmsnorm_fold_equals_unfolded_route(model, dev):
+    """The RMSNorm-folded route of the inference forward (producer leaves row sums of squares, consumer scales its accumulators; rga3_gemm_rms_bf16) against the
+    route with stand-alone norm launches on the same weights: ViT features and logits within bf16 noise of each other (both are within 2e-2 of the oracle:
+    test_vit_parity / test_full_forward_parity run with the fold on), bit-identical run to run."""
+    import rga3.model.qwen2_5_vl as QM
+
+    g = gold()
+    px = torch.cat([det_tensor("pixel_values_full0", (192, 1176), 1.0, seed=5), det_tensor("pixel_values_full1", (192, 1176), 1.0, seed=6)], 0).to(torch.bfloat16)
+    ids, am = (torch.from_numpy(g[k]) for k in ("full_input_ids", "full_attention_mask"))
+
+    def run():
+        with torch.no_grad():
+            vit = model.visual(px.to(dev), g["full_grid"])
+            out = model(input_ids=ids.to(dev), attention_mask=am.to(dev), pixel_values_videos=px.to(dev), video_grid_thw=torch.from_numpy(g["full_grid"]),
+                        second_per_grid_ts=torch.tensor([1.0, 1.0]))
+        return vit, out.logits
+
+    assert QM.rms_fold_enabled()
+    calls = []
+    real = QM.ops.gemm
+    QM.ops.gemm = lambda *a, **k: (calls.append(("rms_in" in k and k["rms_in"] is not None, k.get("rms_out") is not None)), real(*a, **k))[1]
+    try:
+        v1, l1 = run()
+    finally:
+        QM.ops.gemm = real
+    assert sum(c[0] for c in calls) >= 4 and sum(c[1] for c in calls) >= 4, "the folded route did not run"
+    v1b, l1b = run()
+    assert torch.equal(v1, v1b) and torch.equal(l1, l1b)
+    QM.set_rms_fold(False)
+    try:
+        v0, l0 = run()
+    finally:
+        QM.set_rms_fold(True)
+    m = am.bool()
+    assert rel_l2(v1, v0.float().cpu()) < 2e-2          # two bf16 pipelines with different rounding points: each is within 2e-2 of the fp32 oracle
+    assert rel_l2(l1[m], l0[m].float().cpu()) < 2e-2
+
+
 def test_kv_cache_decode_parity(model, dev):
     """Prefill + teacher-forced single-token decode steps through the KV cache reproduce the oracle's full-sequence
     logits (rel-L2 <= 2e-2) and its greedy token wherever the oracle's top-1/top-2 margin exceeds the bf16 noise."""
