@@ -70,7 +70,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float e = 1.0f - poly * t * __expf(-z * z);   // erf(|x| / sqrt 2)
     return 0.5f * x + 0.5f * fabsf(x) * e;               // x * (1 + sign(x) erf) / 2
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp; the result is rounded to bf16 right after): the IEEE division here was a ten-instruction sequence
+// (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup) on each of the 64 outputs a lane owns in a 256 x 256 SwiGLU epilogue -- the matrix pipe idles
+// while it runs
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ---- epilogue shared by all main loops.  Lane (g = lane>>4, c = lane&15) holds, for m-tile i / n-tile j of the wave's
 //      WTM x WTN block, row c and columns 4g..4g+3 of the 16x16 sub-block (swapped-operand MFMA).
@@ -146,6 +149,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     const int ncol0 = (ACT == ACT_SWIGLU) ? (n0 / 2 + wn * OW) : (n0 + wn * OW);  // first output column of this wave
     const int Nout = (ACT == ACT_SWIGLU) ? p.N / 2 : p.N;
 
+    // RMSNorm of the A rows folded in: 1 / sqrt(mean(x^2) + eps) from the producer's fixed-point row sums.  The wave's MT x 16 rows are fetched by lane
+    // (row lane, row lane + 64), all loads in flight together, and parked in the wave's epilogue staging bytes (unused since the stores go straight from
+    // registers): inside the m-tile loop every load's L2 round trip was in line (+12 us on the LLM gate-up product), and 8 long-lived registers per lane
+    // pushed the stream-K epilogue into scratch.
+    float* const rs_lds = (float*)est;
+    if (p.rs_in) {
+#pragma unroll
+        for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
+            const int rl = lane + 64 * q;
+            if (rl < MT * 16) {
+                const uint2 raw = *(const uint2*)(p.rs_in + min(m0 + wm * WTM + rl, p.M - 1));
+                // u64 -> f32 by halves (the generic conversion is a ~15-instruction emulation)
+                rs_lds[rl] = __builtin_amdgcn_rsqf(__builtin_fmaf((float)raw.y, 4294967296.0f, (float)raw.x) * p.rs_in_scale + p.rs_eps);
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         f32x4 pc[NTL];
@@ -165,11 +184,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             ln_mean = st2.x;
             ln_rinv = st2.y;
         }
-        float rs_rinv = 1.f;   // RMSNorm of the A rows folded in: 1 / sqrt(mean(x^2) + eps) from the producer's fixed-point row sums
-        if (p.rs_in) {
-            const int rrow = min(m0 + wm * WTM + i * 16 + (lane & 15), p.M - 1);
-            rs_rinv = __builtin_amdgcn_rsqf((float)p.rs_in[rrow] * p.rs_in_scale + p.rs_eps);
-        }
+        const float rs_rinv = p.rs_in ? rs_lds[i * 16 + (lane & 15)] : 1.f;   // same wave wrote it: program order + the compiler's lgkmcnt suffice
 #pragma unroll
         for (int jo = 0; jo < OUT_NT; ++jo) {
             float v[4];
@@ -299,7 +314,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 // the four lanes (g = 0..3) of a row hold different columns: one sum per row and wave, added as a fixed-point integer (order-free)
                 rs_ss += __shfl_xor(rs_ss, 16, 64);
                 rs_ss += __shfl_xor(rs_ss, 32, 64);
-                if (g == 0 && row_ok) atomicAdd(p.rs_out + row, (unsigned long long)(rs_ss * kRowSumFix + 0.5f));
+                if (g == 0 && row_ok) {
+                    // f32 -> 2^20 fixed point as (hi, lo) words: the value has 24 significant bits, so both steps are exact (the generic f32 -> u64
+                    // conversion is a long emulation sequence)
+                    const float xs = rs_ss * kRowSumFix + 0.5f;
+                    const unsigned hi = (unsigned)(xs * 2.3283064365386963e-10f);
+                    const unsigned lo = (unsigned)__builtin_fmaf(-(float)hi, 4294967296.0f, xs);
+                    atomicAdd(p.rs_out + row, ((unsigned long long)hi << 32) | lo);
+                }
             }
         }
     }

@@ -272,6 +272,14 @@ def _tn_counters(device):
     return t
 
 
+_attn_impl_or = [0]
+
+
+def set_causal32(on: bool):
+    """A/B switch (bench.py variants, tests): False keeps the long causal rows at D = 128 on the general kernel instead of attn_causal32_kernel."""
+    _attn_impl_or[0] = 0 if on else 4
+
+
 def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = False, out=None, return_lse=False,
                 impl: int = 0, block=None, max_k: int = 0):
     """softmax(q k^T * scale) v over packed variable-length segments.
@@ -302,7 +310,7 @@ def attn_varlen(q, k, v, cu_q, cu_k, max_q: int, scale: float, causal: bool = Fa
     rc = _lib.load().rga3_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(lse),
                                           cu_q.data_ptr(), cu_k.data_ptr(), nseg, int(max_q), Tq, Hq, Hkv, D,
                                           q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                          out.stride(0), out.stride(1), float(scale), int(bool(causal)), impl, _ptr(split_ws),
+                                          out.stride(0), out.stride(1), float(scale), int(bool(causal)), impl | _attn_impl_or[0], _ptr(split_ws),
                                           split_ws.numel() if split_ws is not None else 0, int(max_k), bq, bk, _stream())
     _lib.check(rc, "attn_varlen_fwd")
     return (out, lse) if return_lse else out
