@@ -681,8 +681,8 @@ __device__ __forceinline__ void mfma_inplace(f32x4& c, const bf16x8& a, const bf
 //   K-iterations and runs the epilogue) and the START of tile a+1 (partial sums go to this workgroup's f32 slab).
 //   Non-owner slices never wait and are computed first, owner slices last, so an owner only ever waits for work that needs
 //   nothing from anybody (no cycles; every spin is bounded all the same and reports into sk.tmo).
-//   Hand-off = cdna_hip_programming.md Guideline 16, plain-store form: slab stores, every wave vmcnt(0), barrier, one lane
-//   agent-scope release fence + wait, relaxed agent flag store; owner: one lane polls relaxed, agent-scope acquire fence,
+//   Hand-off = cdna_hip_programming.md Guideline 16, write-through form (R1): sc1 slab stores, every wave vmcnt(0), barrier, one lane's
+//   relaxed agent flag store (no release fence); owner: one lane polls relaxed, agent-scope acquire fence,
 //   wait, barrier, then plain vector loads.  Flags are zero at allocation and reset by their single consumer.
 //   The split is a pure function of (M, N, K, P): results are reproducible run to run.
 struct SkArgs {
@@ -694,6 +694,7 @@ struct SkArgs {
     int t_dp;         // tiles [0, t_dp) are data-parallel (t_dp % P == 0 or sk_tiles == 0)
     int sk_tiles;     // tiles [t_dp, t_dp + sk_tiles) are split
     int all_partial;  // split-K mode (tile 25): every slice only writes its slab; gemm_slab_reduce_kernel sums them afterwards
+    int plain_slabs;  // measurement builds only (RGA3_AB, env RGA3_SK_PLAIN=1): the round-3 hand-off -- plain slab stores + agent-scope release fence
 };
 
 // MH = 16-row m-tiles per A half-tile and wave row: 4 -> 256-row tiles, 3 -> 192-row tiles (M = 2112 = 11 x 192: no padded tile row;
@@ -922,19 +923,38 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
         if (cur_kind == 1) {
             // ---- non-owner slice: partial sums -> this workgroup's slab, then publish
             f32x4* slab = (f32x4*)sk.slabs + (size_t)w * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
+            // Slab stores are WRITE-THROUGH (sc1: cdna_hip_programming.md Guideline 16 R1, MI355X_MICROARCH.md price list "publish-large"): every storing wave drains
+            // its own stores, the workgroup meets, one lane raises the flag -- no agent-scope release fence.  The plain-store form paid a buffer_wbl2 (write back
+            // the XCD L2's dirty lines) behind 256 KiB of freshly dirtied slab per workgroup: 8.2 vs 3.0 us per publish in the guide's measurement.  The owner
+            // still acquires (agent scope) before its plain loads.  In split-K mode (tile 25) the kernel boundary is the hand-off: plain stores there.
+            if (sk.all_partial || sk.plain_slabs) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) {
-                    *slab = acc[i][j];
-                    slab += 64;
-                    asm volatile("" : "+v"(slab));  // one running address, not 32 precomputed ones
-                }
+                    for (int j = 0; j < NTL; ++j) {
+                        *slab = acc[i][j];
+                        slab += 64;
+                        asm volatile("" : "+v"(slab));  // one running address, not 32 precomputed ones
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(slab), "v"(acc[i][j]) : "memory");
+                        slab += 64;
+                        asm volatile("" : "+v"(slab));
+                    }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0 && !sk.all_partial) {   // split-K mode hands over at the kernel boundary instead
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RGA3_AB
+                if (sk.plain_slabs) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+#endif
                 __hip_atomic_store(sk.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
@@ -1066,6 +1086,15 @@ static int sk_workspace(void* ws, int64_t ws_bytes, SkWorkspace& out) {
     return 0;
 }
 
+static inline int sk_plain_slabs() {
+#ifdef RGA3_AB
+    const char* e = getenv("RGA3_SK_PLAIN");
+    return e && atoi(e) != 0;
+#else
+    return 0;
+#endif
+}
+
 template <int ACT, bool OUT_F32, bool LNF = false>
 static int launch_pp(const GemmArgs& a0, hipStream_t st);
 
@@ -1096,6 +1125,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.sk_tiles = 0;
         sk.P_sk = 0;
         sk.all_partial = 0;
+        sk.plain_slabs = sk_plain_slabs();
     } else {
         // slices per split tile <= 3 (owner + two contributors: the kernel's accumulator init reads at most two slabs)
         // <=> run length >= nk / 2 <=> P_sk <= 2 * sk_tiles; and no slice shorter than MIN_SEG K-iterations
@@ -1110,6 +1140,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         if (want < rem) want = rem;
         sk.P_sk = (int)want;
         sk.all_partial = 0;
+        sk.plain_slabs = sk_plain_slabs();
     }
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, MH>;
@@ -1137,7 +1168,7 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     if (S < 2) return launch_sk<ACT, OUT_F32>(a0, false, st);
     SkArgs sk;
     sk.slabs = ws.slabs; sk.flags = ws.flags; sk.tmo = ws.flags + ws.P;
-    sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1;
+    sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1; sk.plain_slabs = 0;
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_sk_kernel<ACT_NONE, false>;
     static LdsGrant lds_grant;
