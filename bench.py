@@ -926,7 +926,20 @@ def main():
         tt = torch.tensor([local_ms, ar_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         local_ms, ar_s = float(tt[0]), float(tt[1])
-        comm = {"dense_bucket_bytes_per_step": nbytes, "sparse_rows_bytes_per_step": reducer.sparse_bytes_last, "buckets": len(reducer.flat),
+        # what the communicator itself saw: a device-side all-reduce of ones (= the number of ranks RCCL connected), one id per rank gathered through it, and
+        # the library version -- so a SCALE record shows that the collective really ran over N ranks
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")     # (gloo -- functional runs only -- gathers on the host)
+        ones = torch.ones(1, device=cdev, dtype=torch.float32)
+        dist.all_reduce(ones)
+        ranks_seen = torch.empty(world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(ranks_seen, torch.tensor([rank], dtype=torch.int64, device=cdev))
+        try:
+            ccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:   # noqa: BLE001
+            ccl_version = None
+        comm = {"backend": dist.get_backend(), "rccl_version": ccl_version, "communicator_ranks_by_device_allreduce": int(round(float(ones.item()))),
+                "ranks_gathered": [int(v) for v in ranks_seen.tolist()], "world_size": dist.get_world_size(),
+                "dense_bucket_bytes_per_step": nbytes, "sparse_rows_bytes_per_step": reducer.sparse_bytes_last, "buckets": len(reducer.flat),
                 "allreduce_standalone_ms": round(ar_s * 1e3, 3), "bus_GB_per_s": round(2 * (world - 1) / world * nbytes / ar_s / 1e9, 1),
                 "step_ms_without_exchange": round(local_ms, 3), "exposed_comm_ms": round(ms - local_ms, 3),
                 "xgmi_peak_GB_per_s_per_gpu": 7 * 153}

@@ -38,6 +38,21 @@ _ALIGN = 8   # bucket slices start at multiples of 8 elements (16 B for bf16): t
 _sparse_sinks: "weakref.WeakValueDictionary[int, GradBucketReducer]" = weakref.WeakValueDictionary()
 
 
+@contextlib.contextmanager
+def _host_staged_collective():
+    """gloo has no all-gather on device tensors: the functional multi-rank runs on ONE shared GPU (bench.py RGA3_BENCH_SHARE_GPU, tests/test_ddp_shared_gpu.py)
+    stage the rows through the host, which synchronises by construction.  RCCL never takes this branch.  The staging is exempted from torch's sync debug mode so
+    that a test can run the whole multi-rank step under set_sync_debug_mode("error") and still catch every OTHER device -> host wait."""
+    mode = torch.cuda.get_sync_debug_mode() if torch.cuda.is_available() else 0
+    if mode:
+        torch.cuda.set_sync_debug_mode(0)
+    try:
+        yield
+    finally:
+        if mode:
+            torch.cuda.set_sync_debug_mode(mode)
+
+
 def sparse_sink_for(param):
     return _sparse_sinks.get(id(param))
 
@@ -182,7 +197,13 @@ class GradBucketReducer:
     def _launch(self, bi):
         if self.sync and self.world > 1:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            self.handles.append((bi, dist.all_reduce(self.flat[bi], op=op, group=self.pg, async_op=True)))
+            if self._nccl or not self.flat[bi].is_cuda:
+                self.handles.append((bi, dist.all_reduce(self.flat[bi], op=op, group=self.pg, async_op=True)))
+            else:     # gloo on device tensors (shared-GPU functional runs): its transfers are staged through the host and synchronise by construction --
+                      # in a worker thread, so the collective is run to completion inside the exemption (functional path: no overlap to lose)
+                with _host_staged_collective():
+                    dist.all_reduce(self.flat[bi], op=op, group=self.pg)
+                self.handles.append((bi, None))
 
     def begin_step(self):
         """Call before the first micro-step of an optimizer step."""
@@ -229,7 +250,8 @@ class GradBucketReducer:
                 mine = st.get("dev_ids") or []
                 st["last_ids"] = mine[0] if len(mine) == 1 and mine[0].numel() == st["union"].size else _upload(st["union"], st["dense"].device)
         for bi, h in self.handles:
-            h.wait()
+            if h is not None:
+                h.wait()          # RCCL: a stream dependency, no host wait
             if not self._avg and self.world > 1:
                 self.flat[bi].div_(self.world)
         self.handles = []
@@ -329,13 +351,14 @@ class GradBucketReducer:
                 dist.all_gather_into_tensor(all_ids, send_ids, group=self.pg)
             dist.all_gather_into_tensor(all_rows, send_rows, group=self.pg)
         else:   # gloo has no all-gather on device tensors (functional multi-rank runs on a shared GPU, bench.py RGA3_BENCH_SHARE_GPU): stage through the host
-            if not announced:
-                hi = torch.empty(all_ids.shape, dtype=all_ids.dtype)
-                dist.all_gather_into_tensor(hi, send_ids.cpu(), group=self.pg)
-                all_ids.copy_(hi)
-            hr = torch.empty(all_rows.shape, dtype=all_rows.dtype)
-            dist.all_gather_into_tensor(hr, send_rows.cpu(), group=self.pg)
-            all_rows.copy_(hr)
+            with _host_staged_collective():
+                if not announced:
+                    hi = torch.empty(all_ids.shape, dtype=all_ids.dtype)
+                    dist.all_gather_into_tensor(hi, send_ids.cpu(), group=self.pg)
+                    all_ids.copy_(hi)
+                hr = torch.empty(all_rows.shape, dtype=all_rows.dtype)
+                dist.all_gather_into_tensor(hr, send_rows.cpu(), group=self.pg)
+                all_rows.copy_(hr)
         if not announced:
             rank_ids = [all_ids[r * cap:r * cap + counts[r]] for r in range(self.world)]
         self.sparse_bytes_last = id_bytes + self.world * cap * H * d.element_size()
