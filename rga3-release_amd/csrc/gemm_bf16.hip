@@ -126,8 +126,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     {
         const int g4 = (lane >> 4) * 4;
         if (p.bias) {
+            if (n0 + wn * WTN + NTL * 16 <= p.N && (((size_t)p.bias) & 7) == 0) {   // wave-uniform: no per-load branch, the NTL loads fly together
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) bpk[j] = load4(p.bias, n0 + wn * WTN + j * 16 + g4, p.N);
+                for (int j = 0; j < NTL; ++j) bpk[j] = *(const u32x2*)(p.bias + n0 + wn * WTN + j * 16 + g4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) bpk[j] = load4(p.bias, n0 + wn * WTN + j * 16 + g4, p.N);
+            }
         }
         if constexpr (LNF) {
 #pragma unroll
@@ -154,6 +159,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     // registers): inside the m-tile loop every load's L2 round trip was in line (+12 us on the LLM gate-up product), and 8 long-lived registers per lane
     // pushed the stream-K epilogue into scratch.
     float* const rs_lds = (float*)est;
+    if constexpr (LNF) {   // the same for the LayerNorm-folded products: (mean, 1 / std) of the wave's rows fetched up front, not one L2 round trip per m-tile in line
+#pragma unroll
+        for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
+            const int rl = lane + 64 * q;
+            if (rl < MT * 16) *(float2*)(rs_lds + 2 * rl) = *(const float2*)(p.rowstat + 2L * min(m0 + wm * WTM + rl, p.M - 1));
+        }
+    }
     if (p.rs_in) {
 #pragma unroll
         for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
@@ -179,8 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
         f32x4 vf[OUT_F32 ? OUT_NT : 1];
         float ln_mean = 0.f, ln_rinv = 1.f;
         if constexpr (LNF) {
-            const int rrow = min(m0 + wm * WTM + i * 16 + (lane & 15), p.M - 1);
-            const float2 st2 = *(const float2*)(p.rowstat + 2L * rrow);
+            const float2 st2 = *(const float2*)(rs_lds + 2 * (i * 16 + (lane & 15)));
             ln_mean = st2.x;
             ln_rinv = st2.y;
         }
