@@ -7,8 +7,8 @@
 
 Parameter names of this build equal the reference's (strict load is a test), so loading is name-for-name; PEFT's
 `base_model.model.` prefix and `.base_layer.` infix are accepted.  PEFT and DeepSpeed are not in the image: the merge follows PEFT's
-published formula W += (alpha / r) * B @ A and is parity-unpinned; ZeRO-2 consolidation is not needed by this build's DDP optimizer
-(full bf16 parameters + fp32 moments live on every rank)."""
+published formula W += (alpha / r) * B @ A and is parity-unpinned; a DeepSpeed ZeRO-2 checkpoint DIRECTORY (what the reference trainer saves,
+train_joint.py:426-461) is consolidated by rga3.utils.zero_ckpt (this build's own DDP optimizer keeps whole parameters on every rank and never writes one)."""
 from __future__ import annotations
 
 import json
