@@ -75,6 +75,57 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // while it runs
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// ---- activations of the tile epilogues: table-driven.  The value t fed to GELU / SiLU has just been rounded to bf16 (the reference's bf16 nn.Linear output), so the
+//      activation is a function of 15 magnitude bits:   act(t) = relu(t) - |t| T(|t|),   T_gelu(a) = Phi(-a),  T_silu(a) = sigmoid(-a)   (tools/gen_act_tables.py:
+//      f32 T for every bf16 magnitude in [2^-14, 2^6), 10 KiB; outside the range the clamped entry is exact to < 3e-5 relative / 1e-26 absolute).  Five VALU
+//      slots and one ds_read_b32 per element instead of a quarter-rate v_rcp + v_exp and ten more (A-S erf) or 2 + 3 (sigmoid): the K = 576 GELU product of Hiera
+//      stage 3 was 70 % VALU-busy (profiles/r04_k576_pmc.json).  Exact to f32 rounding, including the negative tail's relative accuracy.
+#include "act_tables.inc"
+constexpr int kActTabBytes = kActTabN * 4;
+static_assert(kActTabBytes % 1024 == 0, "the table is staged in 1-KiB LDS-DMA pieces");
+template <int ACT> constexpr bool act_uses_table() { return ACT == ACT_GELU || ACT == ACT_SWIGLU; }
+
+typedef const __attribute__((address_space(3))) float lds_cfloat;
+// LDS byte address of the table minus the bytes of the magnitudes below its first entry (wave-uniform; computed once per epilogue)
+__device__ __forceinline__ unsigned act_tab_base(const char* tab) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)tab - kActTabLoBits * 4u; }
+// two activations from a PACKED bf16 pair (what v_cvt_pk_bf16_f32 just produced).  Per element: magnitude (v_and / v_bfe), clamp to the table (v_med3_u32), byte address
+// (v_lshl_add_u32), ds_read_b32, relu as a signed-integer max (no canonicalising v_max_f32 pair), one v_fma_f32 with |t| and the negation as source modifiers (asm:
+// left to itself the compiler pairs two elements into v_pk_fma_f32, which has no |x| modifier, and pays two extra v_and).
+__device__ __forceinline__ f32x2 act_tab2(unsigned pk, unsigned tb) {
+    float y0, y1;
+    constexpr unsigned LO = kActTabLoBits, HI = kActTabLoBits + kActTabN - 1;
+    asm("" : "+v"(pk));   // opaque: the compiler otherwise re-derives the low half by a second, single v_cvt_pk_bf16_f32
+    const unsigned m0 = pk & 0x7fffu, m1 = __builtin_amdgcn_ubfe(pk, 16, 15);
+    const unsigned a0 = (min(max(m0, LO), HI) << 2) + tb, a1 = (min(max(m1, LO), HI) << 2) + tb;
+    const float q0 = *(lds_cfloat*)(size_t)a0, q1 = *(lds_cfloat*)(size_t)a1;
+    const unsigned t0 = pk << 16, t1 = pk & 0xffff0000u;
+    const int r0 = max((int)t0, 0), r1 = max((int)t1, 0);
+    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y0) : "v"(t0), "v"(q0), "v"(r0));
+    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y1) : "v"(t1), "v"(q1), "v"(r1));
+    return f32x2{y0, y1};
+}
+// (s, s) in a REAL register pair.  Left to itself the compiler broadcasts a scalar into packed-f32 operations through op_sel (one half of a pair feeding both lanes of
+// the operation); the epilogue form  v_pk_mul_f32 t, c, v[n:n+1] op_sel_hi:[1,0]  +  v_pk_fma_f32 d, acc, v[m:m+1], t op_sel:[0,1,0]  returned d.lo WITHOUT the product term in
+// lanes 48-63 of a few percent of the waves when two workgroups shared a CU (MI355X, ROCm 7.2; timing-dependent, never with one workgroup per CU; the element-wise and
+// the plain-pair forms of the same arithmetic are exact; tools/probes/dbg_ln_gelu.py reproduces it with -DEPI_V3).  Every packed operation of the epilogue therefore
+// takes plain pairs.
+__device__ __forceinline__ f32x2 splat2(float s) {
+    f32x2 v = {s, s};
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ f32x2 widen_bf2(unsigned pk) { return f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)}; }
+// the workgroup's NWAVES waves copy table `which` (0 GELU, 1 SiLU) into LDS at dst by LDS-DMA; the caller waits (vmcnt) and synchronises before the epilogue reads it
+template <int NWAVES>
+__device__ __forceinline__ void stage_act_table(char* dst, int which, int wid, int lane) {
+    const char* src = (const char*)g_act_tab[which] + lane * 16;
+#pragma unroll
+    for (int pc = 0; pc < kActTabBytes / 1024; pc += NWAVES) {
+        const int q = pc + wid;   // wave-uniform
+        if (q < kActTabBytes / 1024) __builtin_amdgcn_global_load_lds((gbl_void*)(src + q * 1024), (lds_void*)(dst + q * 1024), 16, 0, 0);
+    }
+}
+
 // ---- epilogue shared by all main loops.  Lane (g = lane>>4, c = lane&15) holds, for m-tile i / n-tile j of the wave's
 //      WTM x WTN block, row c and columns 4g..4g+3 of the 16x16 sub-block (swapped-operand MFMA).
 template <int NTL, int ACT, bool OUT_F32>
@@ -85,8 +136,9 @@ constexpr int epi_wave_bytes() {  // LDS staging bytes one wave needs in gemm_ep
 // LNF (LayerNorm folded into the product, rga3_gemm_ln_bf16): A holds the UN-normalised rows x, W the weight with gamma folded in (W' = W . diag(gamma)), and
 //   LN(x) W^T + b  =  rinv_r (x W'^T - mean_r c_n) + d_n,   c_n = sum_k W'_nk,   d_n = sum_k beta_k W_nk + b_n  (handed over as the bias),
 // so the normalised activations are never written or re-read: a row-statistics pass (one read of x) replaces the LayerNorm pass (read + write).
-template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32, bool LNF = false>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmArgs& p, char* est, int lane, int m0, int n0,
+// PARTS: part1 / part2 are read (stream-K owner slices); tab: this kernel's activation table in LDS (act_tab; GELU / SwiGLU epilogues only).
+template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32, bool LNF = false, bool PARTS = false>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmArgs& p, char* est, const char* tab, int lane, int m0, int n0,
                                               int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr) {
     static_assert(!(LNF && ACT == ACT_SWIGLU), "the LayerNorm-folded epilogue has no SwiGLU form");
     // part1 / part2 (stream-K owner slices only): this lane's view of up to two f32 partial-sum slabs in accumulator order
@@ -103,7 +155,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             pn[i % PD][j] = v;
         }
     };
-    if (part1) {
+    if constexpr (PARTS) {
         load_part(0);
         if (PD > 1 && MT > 1) load_part(1);
     }
@@ -159,6 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     // registers): inside the m-tile loop every load's L2 round trip was in line (+12 us on the LLM gate-up product), and 8 long-lived registers per lane
     // pushed the stream-K epilogue into scratch.
     float* const rs_lds = (float*)est;
+    const unsigned tb = act_uses_table<ACT>() ? act_tab_base(tab) : 0u;
     if constexpr (LNF) {   // the same for the LayerNorm-folded products: (mean, 1 / std) of the wave's rows fetched up front, not one L2 round trip per m-tile in line
 #pragma unroll
         for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
@@ -179,58 +232,82 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        f32x4 pc[NTL];
+        // ---- values of this m-tile, whole quads at a time (f32x4 arithmetic lowers to v_pk_mul / v_pk_fma / v_pk_add: two elements per VALU slot).  Optional steps
+        //      sit behind ONE wave-uniform branch per m-tile, not per element: per-element forms compiled to both-sides-plus-select (bias) or a scalar branch in
+        //      every element (column scale), and the unconditional "+ partial sum" of the stream-K owner was an add of 0.0 in every other tile (not foldable: -0.0).
+        //      The epilogue is VALU time the matrix pipe idles through (r04 PMC: 70 % VALU-busy in the K = 576 GELU product).
+        f32x4 x[NTL];
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) pc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (part1) {
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) pc[j] = pn[i % PD][j];
+        for (int j = 0; j < NTL; ++j) {
+            x[j] = acc[i][j];
+            if constexpr (PARTS) x[j] += pn[i % PD][j];
+        }
+        if constexpr (PARTS) {
             if (i + PD < MT) load_part(i + PD);
+        }
+        if constexpr (LNF) {
+            const float2 st2 = *(const float2*)(rs_lds + 2 * (i * 16 + (lane & 15)));
+            const float ln_rinv = st2.y, nmr = -st2.x * st2.y;   // rinv (x - mean c) = rinv x + (-mean rinv) c
+            const f32x2 ri2 = splat2(ln_rinv), nm2 = splat2(nmr);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const f32x2 lo = x[j].xy * ri2 + cc[j].xy * nm2, hi = x[j].zw * ri2 + cc[j].zw * nm2;
+                x[j] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+        } else if (p.rs_in) {
+            const float rs_rinv = rs_lds[i * 16 + (lane & 15)];   // same wave wrote it: program order + the compiler's lgkmcnt suffice
+            const f32x2 rs2 = splat2(rs_rinv);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const f32x2 lo = x[j].xy * rs2, hi = x[j].zw * rs2;
+                x[j] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+                x[j] += f32x4{__uint_as_float(bpk[j][0] << 16), __uint_as_float(bpk[j][0] & 0xffff0000u), __uint_as_float(bpk[j][1] << 16),
+                              __uint_as_float(bpk[j][1] & 0xffff0000u)};
+        }
+        f32x4 v[OUT_NT];
+#pragma unroll
+        for (int jo = 0; jo < OUT_NT; ++jo) {
+            if constexpr (ACT == ACT_SWIGLU) {
+                // packed weight layout: n-tile 2*jo = gate columns, 2*jo+1 = up columns of the same 16 outputs.  The reference rounds the gate / up linear outputs
+                // to bf16 before the activation (bf16 nn.Linear), and silu(gate) before the product
+                const f32x4 &gq = x[2 * jo], &uq = x[2 * jo + 1];
+                const f32x2 s01 = act_tab2(pack_bf2(gq[0], gq[1]), tb), s23 = act_tab2(pack_bf2(gq[2], gq[3]), tb);
+                const f32x2 v01 = widen_bf2(pack_bf2(s01[0], s01[1])) * widen_bf2(pack_bf2(uq[0], uq[1]));
+                const f32x2 v23 = widen_bf2(pack_bf2(s23[0], s23[1])) * widen_bf2(pack_bf2(uq[2], uq[3]));
+                v[jo] = f32x4{v01[0], v01[1], v23[0], v23[1]};
+            } else if constexpr (ACT == ACT_GELU) {
+                const f32x2 y01 = act_tab2(pack_bf2(x[jo][0], x[jo][1]), tb), y23 = act_tab2(pack_bf2(x[jo][2], x[jo][3]), tb);
+                v[jo] = f32x4{y01[0], y01[1], y23[0], y23[1]};
+            } else if constexpr (ACT == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[jo][r] = fmaxf(x[jo][r], 0.f);
+            } else {
+                v[jo] = x[jo];
+            }
+        }
+        if (p.colscale) {   // rare (ConvNeXt layer scale)
+#pragma unroll
+            for (int jo = 0; jo < OUT_NT; ++jo)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float cs = bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);
+                    v[jo][r] = ((ACT == ACT_SWIGLU) ? v[jo][r] : bf2f(f2bf(v[jo][r]))) * cs;
+                }
         }
         u32x2 pk[OUT_NT];
         f32x4 vf[OUT_F32 ? OUT_NT : 1];
-        float ln_mean = 0.f, ln_rinv = 1.f;
-        if constexpr (LNF) {
-            const float2 st2 = *(const float2*)(rs_lds + 2 * (i * 16 + (lane & 15)));
-            ln_mean = st2.x;
-            ln_rinv = st2.y;
-        }
-        const float rs_rinv = p.rs_in ? rs_lds[i * 16 + (lane & 15)] : 1.f;   // same wave wrote it: program order + the compiler's lgkmcnt suffice
 #pragma unroll
         for (int jo = 0; jo < OUT_NT; ++jo) {
-            float v[4];
-            if constexpr (ACT == ACT_SWIGLU) {
-                // packed weight layout: n-tile 2*jo = gate columns, 2*jo+1 = up columns of the same 16 outputs
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float gt = (acc[i][2 * jo][r] + pc[2 * jo][r]) * rs_rinv, up = (acc[i][2 * jo + 1][r] + pc[2 * jo + 1][r]) * rs_rinv;
-                    if (p.bias) {
-                        gt += pick(bpk[2 * jo], r);
-                        up += pick(bpk[2 * jo + 1], r);
-                    }
-                    // reference rounds gate/up linear outputs to bf16 before the activation (bf16 nn.Linear)
-                    gt = bf2f(f2bf(gt));
-                    up = bf2f(f2bf(up));
-                    v[r] = bf2f(f2bf(silu_f(gt))) * up;
-                    if (p.colscale) v[r] *= bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);  // rare (ConvNeXt layer scale)
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = (acc[i][jo][r] + pc[jo][r]) * rs_rinv;
-                    if constexpr (LNF) x = ln_rinv * (x - ln_mean * cc[jo][r]);
-                    if (p.bias) x += pick(bpk[jo], r);
-                    if constexpr (ACT == ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
-                    if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
-                    if (p.colscale) x = bf2f(f2bf(x)) * bf2f(p.colscale[min(ncol0 + jo * 16 + 4 * g + r, Nout - 1)]);  // rare (ConvNeXt layer scale)
-                    v[r] = x;
-                }
-            }
             if constexpr (OUT_F32) {
-                vf[jo] = f32x4{v[0], v[1], v[2], v[3]};
+                vf[jo] = v[jo];
             } else {
-                pk[jo][0] = pack_bf2(v[0], v[1]);
-                pk[jo][1] = pack_bf2(v[2], v[3]);
+                pk[jo][0] = pack_bf2(v[jo][0], v[jo][1]);
+                pk[jo][1] = pack_bf2(v[jo][2], v[jo][3]);
             }
         }
         // ---- stores straight from registers (no LDS round trip).  f32: the lane's 4 columns are 16 B already.  bf16: one
@@ -351,6 +428,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     static_assert(APW >= 1 && BPW >= 1, "tile too small for wave count");
     static_assert(ACT != ACT_SWIGLU || (NTL % 2 == 0), "swiglu needs gate/up tile pairs");
 
+    // GELU / SwiGLU epilogues read their activation table from LDS: it is copied into a DEAD stage while the last K-tile is multiplied (all stages are live
+    // before that), and the epilogue's per-wave staging bytes then live in the stage consumed last, so the two never overlap
+    constexpr bool TAB = act_uses_table<ACT>();
+    static_assert(!TAB || (NW * epi_wave_bytes<NTL, ACT, OUT_F32>() <= STAGE && kActTabBytes <= STAGE), "activation table / epilogue staging do not fit a stage");
+    int tab_stage = 0, est_stage = 0;
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -451,6 +534,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
             __builtin_amdgcn_s_barrier();
             const int s2 = s0 >= 1 ? s0 - 1 : 2;   // (s0 + 2) % 3
             if (kt + 2 < nk) stage_tile(s2, kt + 2, kt + 3 == nk_all);
+            if constexpr (TAB) {
+                if (kt + 1 == nk) {
+                    stage_act_table<NW>(smem + s2 * STAGE, ACT == ACT_SWIGLU, wid, lane);
+                    tab_stage = s2;
+                    est_stage = s0;
+                }
+            }
             const char* As = smem + s0 * STAGE + (wm * WTM) * ROWB;
             const char* Bs = smem + s0 * STAGE + BM * ROWB + (wn * WTN) * ROWB;
 #pragma unroll
@@ -476,6 +566,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) stage_tile((kt + 1) & 1, kt + 1, kt + 2 == nk_all);
+        if constexpr (TAB) {
+            if (kt + 1 == nk) {
+                stage_act_table<NW>(smem + ((kt + 1) & 1) * STAGE, ACT == ACT_SWIGLU, wid, lane);
+                tab_stage = (kt + 1) & 1;
+                est_stage = kt & 1;
+            }
+        }
         const char* As = smem + (kt & 1) * STAGE + (wm * WTM) * ROWB;
         const char* Bs = smem + (kt & 1) * STAGE + BM * ROWB + (wn * WTN) * ROWB;
 #pragma unroll
@@ -493,8 +590,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         }
     }
     }
-    __syncthreads();  // all waves done with the last stage: LDS is free for the epilogue staging
-    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wm, wn);
+    if constexpr (TAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the table have landed ...
+    __syncthreads();  // ... everyone's; all waves done with the last stage: LDS is free for the epilogue staging
+    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + est_stage * STAGE + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + tab_stage * STAGE, lane, m0,
+                                                        n0, wm, wn);
 }
 
 // =====================================================================================================================
@@ -525,6 +624,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;  // waves w and w+4 share a SIMD: one of each group per SIMD
+
+    // activation table (GELU / SwiGLU epilogues): 10 KiB behind the two buffers, copied first (the oldest loads of every wave: every counted wait below covers them)
+    if constexpr (act_uses_table<ACT>()) stage_act_table<8>(smem + 2 * BUF, ACT == ACT_SWIGLU, wid, lane);
 
     const unsigned nwg = (unsigned)(p.ntm * p.ntn);
     const unsigned t = xcd_remap(blockIdx.x, nwg);
@@ -670,7 +772,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the groups
     __syncthreads();  // LDS is free for the epilogue staging
-    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), lane, m0, n0, wr, wc);
+    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + 2 * BUF, lane, m0, n0, wr, wc);
 }
 
 // In-place accumulate (C-in register == C-out register).  The builtin lets the register allocator pick a different
@@ -872,6 +974,9 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
 
+    // activation table (GELU / SwiGLU epilogues): 10 KiB behind the two buffers, once per workgroup = once per CU and launch
+    if constexpr (act_uses_table<ACT>()) stage_act_table<8>(smem + 2 * BUF, ACT == ACT_SWIGLU, wid, lane);
+
     int tile, kb, ke, kind;
     item(0, tile, kb, ke, kind);
     setup_tile(tile, lane);
@@ -994,7 +1099,8 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 part1 = (const f32x4*)sk.slabs + (size_t)(w - 1) * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
                 if (two) part2 = part1 - 512 * 32;
             }
-            gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32>(acc, p, est, lane_e, m0, n0, wr, wc, part1, part2);
+            if (cur_kind == 2) gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, true>(acc, p, est, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2);
+            else gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, false>(acc, p, est, smem + 2 * BUF, lane_e, m0, n0, wr, wc);
             if (cur_kind == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();  // every wave has consumed its slab values ...
@@ -1153,7 +1259,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.all_partial = 0;
         sk.plain_slabs = sk_plain_slabs();
     }
-    constexpr int LDS = 2 * 4 * 128 * 128;
+    constexpr int LDS = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
     auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, MH>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
@@ -1200,7 +1306,7 @@ static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.group_m = pick_group_m(a.ntm, 256);
-    constexpr int LDS = 2 * 4 * 128 * 128;
+    constexpr int LDS = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
     auto kern = gemm_nt_pp_kernel<ACT, OUT_F32, LNF>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
@@ -1370,7 +1476,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
     }
     __syncthreads();
     const float* ws_base = (const float*)p.C - (t.slab ? (long)blockIdx.z * t.slab : 0);
-    gemm_epilogue<4, 4, 64, 64, ACT_NONE, OUT_F32>(acc, p, smem, lane, m0, n0, wm, wn);
+    gemm_epilogue<4, 4, 64, 64, ACT_NONE, OUT_F32>(acc, p, smem, nullptr, lane, m0, n0, wm, wn);
     if constexpr (OUT_F32) {
         if (t.counters) {
             // hand-off (cdna_hip_programming.md Guideline 16): every wave drains its slab stores, one lane releases at agent scope and takes a ticket; the last
