@@ -190,6 +190,106 @@ def test_gemm_rmsnorm_folded(dev, tile, shape):
     assert _rel_l2(ys, ref_s) < 1.5e-2, (tile, shape)
 
 
+def _all_bf16_finite(dev):
+    bits = torch.arange(0, 65536, dtype=torch.int32)
+    bits = bits[(bits & 0x7f80) != 0x7f80]                       # no Inf / NaN
+    return bits.to(torch.int16).view(torch.bfloat16).to(dev)
+
+
+@pytest.mark.parametrize("tile", [-1, 3, 20, 21])
+def test_gemm_epilogue_activation_tables_every_bf16_input(dev, tile):
+    """GELU / SiLU of the tile epilogues are table-driven on the bf16-rounded linear output (csrc/act_tables.inc, tools/gen_act_tables.py): every finite bf16 value
+    goes through a product that reproduces it exactly (one-hot weights) and must come out as the correctly rounded exact-erf GELU (reference nn.GELU(), model/sam2.py
+    MLP :2305-2329) resp. silu(gate) * up with up = 1 (HF Qwen2MLP) -- inside the tabulated range [2^-14, 2^6) bit for bit against float64, outside it within one bf16
+    ulp / 1e-25 absolute."""
+    from rga3.hip import ops
+
+    t = _all_bf16_finite(dev)
+    M = (t.numel() + 255) // 256 * 256
+    K = 64
+    a = torch.zeros((M, K), dtype=torch.bfloat16, device=dev)
+    a[:t.numel(), 0] = t
+    td = a[:, 0].double().cpu()
+    inside = (td.abs() >= 2.0 ** -14) & (td.abs() < 63.75)      # the last entry (63.75) is 0: it also serves every larger magnitude
+
+    def check(out, ref64, what):
+        ref = ref64.to(torch.bfloat16)
+        o = out.cpu()
+        same = o.view(torch.int16) == ref.view(torch.int16)
+        both_zero = (o.float() == 0) & (ref.float() == 0)
+        bad_in = (~(same | both_zero)) & inside
+        assert int(bad_in.sum()) == 0, (what, tile, td[bad_in][:5], o[bad_in][:5], ref[bad_in][:5])
+        err = (o.double() - ref64).abs()
+        assert bool((err[~inside] <= 2.0 ** -8 * ref64.abs()[~inside] + 1e-25).all()), (what, tile)
+
+    # GELU: 16 output columns, all the identity
+    w = torch.zeros((256, K), dtype=torch.bfloat16, device=dev)
+    w[:, 0] = 1
+    out = ops.gemm(a, w, act="gelu", tile=tile)
+    check(out[:, 3], 0.5 * td * torch.erfc(-td / 2 ** 0.5), "gelu")
+    check(out[:, 200], 0.5 * td * torch.erfc(-td / 2 ** 0.5), "gelu")
+    # SwiGLU: interleaved 16-row blocks of gate | up; gate = t, up = 1 (a second input column of ones)
+    a[:, 1] = 1
+    wg = torch.zeros((512, K), dtype=torch.bfloat16, device=dev)
+    blocks = wg.view(16, 2, 16, K)
+    blocks[:, 0, :, 0] = 1      # gate rows pick t
+    blocks[:, 1, :, 1] = 1      # up rows pick 1
+    outs = ops.gemm(a, wg, act="swiglu", tile=tile)
+    silu = td / (1.0 + torch.exp(-td))
+    silu = torch.where(td < -700, torch.zeros_like(td), silu)
+    check(outs[:, 5], silu, "silu")
+    check(outs[:, 250], silu, "silu")
+
+
+@pytest.mark.parametrize("tile", [-1, 5, 12])
+def test_gemm_epilogues_two_workgroups_per_cu(dev, tile):
+    """The epilogue variants on grids of MORE than one workgroup per CU (the 64- / 80-KiB tilings co-reside): a packed-f32 form of the LayerNorm fold lost its product
+    term in a few waves only when two workgroups shared a CU -- every epilogue kind is therefore also checked at M = 8192 rows, three runs
+    each, bit-identical run to run and against fp32."""
+    import torch.nn.functional as F
+    from rga3.hip import ops
+
+    M, N, K = 8192, 1152, 320
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(M, K, generator=g) * 0.7 + torch.randn(M, 1, generator=g)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    b = (torch.randn(N, generator=g) * 0.2).to(torch.bfloat16).to(dev)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev)
+    beta = (0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev)
+    xf, wf32, bf32 = x.float().cpu(), w.float().cpu(), b.float().cpu()
+
+    def runs(fn, ref, tol, what):
+        outs = [fn() for _ in range(3)]
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (what, tile)
+        assert _rel_l2(outs[0], ref) < tol, (what, tile)
+
+    lin = xf @ wf32.t() + bf32
+    runs(lambda: ops.gemm(x, w, b, tile=tile), lin, 6e-3, "bias")
+    runs(lambda: ops.gemm(x, w, b, residual=r, tile=tile), lin.to(torch.bfloat16).float() + r.float().cpu(), 6e-3, "bias+residual")
+    runs(lambda: ops.gemm(x, w, b, act="gelu", tile=tile), F.gelu(lin.to(torch.bfloat16).float()), 8e-3, "gelu")
+    if tile != 5:     # 192-wide tiles hold three n-tiles per wave: no gate / up pairs
+        gt, up = lin[:, :N // 2], lin[:, N // 2:]
+        pack = torch.stack([w[:N // 2].view(-1, 16, K), w[N // 2:].view(-1, 16, K)], 1).reshape(N, K).contiguous()
+        bp = torch.stack([b[:N // 2].view(-1, 16), b[N // 2:].view(-1, 16)], 1).reshape(N).contiguous()
+        ref_s = F.silu(gt.to(torch.bfloat16).float()).to(torch.bfloat16).float() * up.to(torch.bfloat16).float()
+        runs(lambda: ops.gemm(x, pack, bp, act="swiglu", tile=tile), ref_s, 1e-2, "swiglu")
+    # LayerNorm folded in
+    st = ops.layernorm_stats(x, 1e-6)
+    wfold, colc, bfold = ops.fold_layernorm(w, b, gamma, beta)
+    ln = F.layer_norm(xf, (K,), gamma.float().cpu(), beta.float().cpu(), 1e-6) @ wf32.t() + bf32
+    runs(lambda: ops.gemm_ln(x, st, wfold, colc, bfold, act="none", tile=tile), ln, 8e-3, "ln")
+    runs(lambda: ops.gemm_ln(x, st, wfold, colc, bfold, act="gelu", tile=tile), F.gelu(ln), 8e-3, "ln+gelu")
+    # RMSNorm folded in (consumer side) with the producer's sums
+    sums = torch.zeros(M, dtype=torch.int64, device=dev)
+    x2 = ops.gemm(x, torch.eye(K, dtype=torch.bfloat16, device=dev), tile=tile, rms_out=sums)
+    assert torch.equal(x2, x)
+    wg = (w.float() * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    xn = (xf * torch.rsqrt((xf ** 2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16).float() * gamma.float().cpu()
+    ref_r = xn.to(torch.bfloat16).float() @ wf32.t() + bf32
+    runs(lambda: ops.gemm(x, wg, b, tile=tile, rms_in=(sums, K, 1e-6)), ref_r, 1e-2, "rms")
+
+
 ATTN_CASES = [
     # (seglens_q, seglens_k, Hq, Hkv, D, causal)
     ([64] * 6, None, 4, 4, 80, False),            # ViT windows

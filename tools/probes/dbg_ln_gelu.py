@@ -21,7 +21,7 @@ xf = x.float().cpu()
 ref0 = F.layer_norm(xf, (K,), gamma.float().cpu(), beta.float().cpu(), 1e-6) @ w.float().cpu().t() + b.float().cpu()
 for act in ("none", "gelu"):
     ref = F.gelu(ref0) if act == "gelu" else ref0
-    for tile in (-1, 3, 5, 7, 20):
+    for tile in (-1, 5, 20, 21):
         for rep in range(2):
             out = ops.gemm_ln(x, st, wf, colc, bf, act=act, tile=tile).float().cpu()
             d = (out - ref)
