@@ -170,6 +170,35 @@ __global__ __launch_bounds__(512) void attn_causal32_kernel(AttnArgs p) {
         const unsigned short* qrow = p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh + 8 * h;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qrow + 16 * kk);
+        if (p.rope_cos) {
+            // RoPE on the UN-rotated queries as they are loaded (rga3_attn_varlen_fwd_rope; HF apply_multimodal_rotary_pos_emb, modeling_qwen2_5_vl.py:557-599): the
+            // rotate-half partner of column d is d + 64, i.e. fragment kk + 4 of the same lane, so the rotation is lane-local.  Tables [token][128] f32; f32
+            // arithmetic and one bf16 rounding, as the stand-alone pass (rope_kernel).
+            const float* cs = p.rope_cos + (long)(qs + qi) * 128 + 8 * h;
+            const float* sn = p.rope_sin + (long)(qs + qi) * 128 + 8 * h;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const u32x4 zl = __builtin_bit_cast(u32x4, qf[kk]), zh = __builtin_bit_cast(u32x4, qf[kk + 4]);
+                float cl[8], sl[8], ch[8], sh[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const f32x4 a0 = *(const f32x4*)(cs + 16 * kk + 4 * q4), a1 = *(const f32x4*)(sn + 16 * kk + 4 * q4);
+                    const f32x4 a2 = *(const f32x4*)(cs + 64 + 16 * kk + 4 * q4), a3 = *(const f32x4*)(sn + 64 + 16 * kk + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cl[4 * q4 + e] = a0[e]; sl[4 * q4 + e] = a1[e]; ch[4 * q4 + e] = a2[e]; sh[4 * q4 + e] = a3[e]; }
+                }
+                u32x4 ol, oh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = __uint_as_float(zl[e] << 16), x1 = __uint_as_float(zl[e] & 0xffff0000u);
+                    const float y0 = __uint_as_float(zh[e] << 16), y1 = __uint_as_float(zh[e] & 0xffff0000u);
+                    ol[e] = pack_bf2(x0 * cl[2 * e] - y0 * sl[2 * e], x1 * cl[2 * e + 1] - y1 * sl[2 * e + 1]);
+                    oh[e] = pack_bf2(y0 * ch[2 * e] + x0 * sh[2 * e], y1 * ch[2 * e + 1] + x1 * sh[2 * e + 1]);
+                }
+                qf[kk] = __builtin_bit_cast(bf16x8, ol);
+                qf[kk + 4] = __builtin_bit_cast(bf16x8, oh);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll

@@ -754,7 +754,10 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
                                         int64_t v_sh, int64_t o_st, int64_t o_sh, float scale, int causal, const float* cos_q, const float* sin_q,
                                         const float* cos_k, const float* sin_k, void* stream) {
     RGA3_CHECK_ARG(q && k && v && o && cu_q && cu_k && cos_q && sin_q && ((cos_k == nullptr) == (sin_k == nullptr)), "attn_varlen_fwd_rope: null pointer");
-    RGA3_CHECK_ARG(nseg > 0 && nseg <= 65535 && max_q > 0 && max_q <= 64 && total_q > 0, "attn_varlen_fwd_rope: nseg=%d max_q=%d (windows of <= 64 queries)", nseg, max_q);
+    // long causal rows at D = 128 (decoder prefill): the paired-block kernel rotates its query fragments on load (keys arrive rotated: cos_k must be null)
+    const bool c32 = causal && D == 128 && max_q >= 256 && !cos_k;
+    RGA3_CHECK_ARG(nseg > 0 && nseg <= 65535 && max_q > 0 && (max_q <= 64 || c32) && total_q > 0,
+                   "attn_varlen_fwd_rope: nseg=%d max_q=%d (windows of <= 64 queries, or causal D = 128 rows of >= 256 queries with rotated keys)", nseg, max_q);
     RGA3_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq <= 65535 && D >= 16 && D <= 128 && D % 16 == 0, "attn_varlen_fwd_rope: Hq=%d Hkv=%d D=%d", Hq, Hkv, D);
     RGA3_CHECK_ARG(q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0 && o_st % 4 == 0 && o_sh % 4 == 0,
                    "attn_varlen_fwd_rope: strides");
@@ -772,6 +775,7 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
     a.bq_shift = a.bk_shift = -1;
     a.split_o = nullptr; a.split_lse = nullptr; a.nsplit = 1; a.gx = 1;
     hipStream_t st = (hipStream_t)stream;
+    if (c32) return launch_causal32(a, nseg, max_q, st);
 #ifdef RGA3_AB   // measurement builds only (tools/): the product library has one behaviour
     static const bool old_rope = [] { const char* e = getenv("RGA3_ATTN_ROPE_OLD"); return e && atoi(e) != 0; }();   // A/B switch: the pipelined rope kernel
 #else

@@ -181,6 +181,7 @@ def _versions(*params):
 # re-read of the normalised rows disappear (2 x 57 launches of ~9 us in the decoder, 2 x 32 in the vision tower: profiles/r03_bench_forward_kernel_stats.csv).
 # Rounding differs from the eager order by the bf16 rounding of gamma * W (instead of the normalised rows): inside the stated 2e-2.  RGA3_RMS_FOLD=0 switches it off.
 _RMS_FOLD = os.environ.get("RGA3_RMS_FOLD", "1") != "0"
+_ROPE_IN_ATTN = os.environ.get("RGA3_ROPE_IN_ATTN", "1") != "0"   # decoder prefill: queries rotated inside the causal attention kernel (inference route)
 
 
 def rms_fold_enabled() -> bool:
@@ -191,6 +192,12 @@ def set_rms_fold(on: bool):
     """A/B switch (bench.py --no-rms-fold, tests)."""
     global _RMS_FOLD
     _RMS_FOLD = bool(on)
+
+
+def set_rope_in_attn(on: bool):
+    """A/B switch (tests): decoder prefill queries rotated inside the causal attention kernel instead of by the stand-alone RoPE pass."""
+    global _ROPE_IN_ATTN
+    _ROPE_IN_ATTN = bool(on)
 
 
 def _fold_ok(x2d, *mods) -> bool:
@@ -460,13 +467,22 @@ class DecoderAttention(nn.Module):
             qkv = qkv_with_lora(self, h, seeds=getattr(self, "_lora_drop_seeds", None))[0].view(T, Hq + 2 * Hk, D)
         else:  # foreign wrappers (e.g. PEFT): honour them, then assemble the fused buffer
             qkv = torch.cat([self.q_proj(h), self.k_proj(h), self.v_proj(h)], dim=-1).view(T, Hq + 2 * Hk, D)
-        ops.rope_(qkv, cos, sin, 0, Hq + Hk)
         q, k, v = qkv[:, :Hq], qkv[:, Hq:Hq + Hk], qkv[:, Hq + Hk:]
+        # prefill without autograd: only the Hk key heads go through the stand-alone RoPE pass, the queries are rotated by the attention kernel as it loads them
+        # (rga3_attn_varlen_fwd_rope -> attn_causal32_kernel: the rotate-half partner d + 64 sits in the same lane)
+        q_in_attn = _ROPE_IN_ATTN and not torch.is_grad_enabled() and D == 128 and max_len >= 256 and qkv.dtype == torch.bfloat16
+        if q_in_attn:
+            ops.rope_(qkv, cos, sin, Hq, Hk)
+        else:
+            ops.rope_(qkv, cos, sin, 0, Hq + Hk)
         cu_k = cu
         if cache is not None:
             k, v, cu_k = cache.update(self.layer_idx, k, v, cu)
         # decode step (one query per sequence): every cached key is visible, and the non-causal form may split the key range over workgroups
-        att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
+        if q_in_attn:
+            att = ops.attn_varlen_rope(q, k, v, cu, cu_k, max_len, D ** -0.5, cos, sin, causal=True)
+        else:
+            att = ops.attn_varlen(q, k, v, cu, cu_k, max_len, D ** -0.5, causal=(max_len > 1))
         if rms_out is not None:
             return ops.gemm(att.view(T, Hq * D), self.o_proj.weight, self.o_proj.bias, residual=residual, rms_out=rms_out)
         return self.o_proj(att.view(T, Hq * D), residual=residual)

@@ -190,6 +190,29 @@ def test_gemm_rmsnorm_folded(dev, tile, shape):
     assert _rel_l2(ys, ref_s) < 1.5e-2, (tile, shape)
 
 
+@pytest.mark.parametrize("S,Hq,Hkv", [(2112, 28, 4), (300, 4, 2), (1000, 7, 1)])
+def test_attn_causal32_rope_on_load(dev, S, Hq, Hkv):
+    """Decoder prefill with the queries rotated as the causal attention kernel loads them (rga3_attn_varlen_fwd_rope -> attn_causal32_kernel; HF
+    apply_multimodal_rotary_pos_emb modeling_qwen2_5_vl.py:557-599) against the stand-alone RoPE pass on q and k followed by the same kernel: the same f32 arithmetic and
+    one bf16 rounding either way, so the outputs agree to bf16 rounding of the attention sums."""
+    from rga3.hip import ops
+
+    D = 128
+    g = torch.Generator().manual_seed(S)
+    qkv = torch.randn(S, Hq + 2 * Hkv, D, generator=g).to(torch.bfloat16).to(dev)
+    pos = torch.arange(S, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, D // 2, dtype=torch.float32) / (D // 2)))[None, :]
+    cos, sin = torch.cat([pos.cos(), pos.cos()], 1).contiguous().to(dev), torch.cat([pos.sin(), pos.sin()], 1).contiguous().to(dev)
+    cu = torch.tensor([0, S], dtype=torch.int32, device=dev)
+    a = qkv.clone()
+    ops.rope_(a, cos, sin, 0, Hq + Hkv)
+    ref = ops.attn_varlen(a[:, :Hq], a[:, Hq:Hq + Hkv], a[:, Hq + Hkv:], cu, cu, S, D ** -0.5, causal=True)
+    b = qkv.clone()
+    ops.rope_(b, cos, sin, Hq, Hkv)
+    assert torch.equal(b[:, Hq:Hq + Hkv], a[:, Hq:Hq + Hkv]) and torch.equal(b[:, :Hq], qkv[:, :Hq])
+    out = ops.attn_varlen_rope(b[:, :Hq], b[:, Hq:Hq + Hkv], b[:, Hq + Hkv:], cu, cu, S, D ** -0.5, cos, sin, causal=True)
+    assert float((out.float() - ref.float()).abs().max()) < 2e-2 and _rel_l2(out, ref.float().cpu()) < 2e-3
+
+
 def _all_bf16_finite(dev):
     bits = torch.arange(0, 65536, dtype=torch.int32)
     bits = bits[(bits & 0x7f80) != 0x7f80]                       # no Inf / NaN
