@@ -129,17 +129,46 @@ __device__ __forceinline__ void stage_act_table(char* dst, int which, int wid, i
 // ---- epilogue shared by all main loops.  Lane (g = lane>>4, c = lane&15) holds, for m-tile i / n-tile j of the wave's
 //      WTM x WTN block, row c and columns 4g..4g+3 of the 16x16 sub-block (swapped-operand MFMA).
 template <int NTL, int ACT, bool OUT_F32>
-constexpr int epi_wave_bytes() {  // LDS staging bytes one wave needs in gemm_epilogue (16 rows, padded)
-    return 16 * (((ACT == ACT_SWIGLU) ? NTL / 2 : NTL) * 16 * (OUT_F32 ? 4 : 2) + 16);
+constexpr int epi_wave_bytes() {  // LDS bytes one wave parks per-row statistics in during gemm_epilogue (<= 128 rows x (mean, 1/std)); outputs go to memory straight from registers
+    return 1024;
 }
 
 // LNF (LayerNorm folded into the product, rga3_gemm_ln_bf16): A holds the UN-normalised rows x, W the weight with gamma folded in (W' = W . diag(gamma)), and
 //   LN(x) W^T + b  =  rinv_r (x W'^T - mean_r c_n) + d_n,   c_n = sum_k W'_nk,   d_n = sum_k beta_k W_nk + b_n  (handed over as the bias),
 // so the normalised activations are never written or re-read: a row-statistics pass (one read of x) replaces the LayerNorm pass (read + write).
+// ---- residual rows through LDS.  The epilogue's residual loads sat inside the m-tile loop: every m-tile paid an HBM / Infinity-Cache round trip in line (8 per
+//      128-row wave tile: 31 000 of a 133 000-cycle Hiera fc2 item, tools/probes/sk_items.py).  The wave's whole residual block is instead fetched by LDS-DMA in one
+//      burst before the loop (no registers, one round trip) and read back with ds_read_b128.  Image: MT*16 rows of OW/8 + 1 sixteen-byte slots (one pad slot per row:
+//      the 16 lanes that read one chunk column of 16 consecutive rows then hit 16 different bank groups); slot s of the lane-linear DMA image = (row s / CPRP, chunk
+//      s % CPRP), the source address is per lane.  Each wave reads only what it staged itself: its own vmcnt wait is all the synchronisation needed.
+// ping-pong kernel: residual staging for the plain bf16 epilogue (8 waves x 128 x 64 blocks = 147 KiB + 8 KiB parking: more than the two 64-KiB buffers, so the launcher
+// asks for it; one workgroup per CU either way)
+template <int ACT, bool OUT_F32>
+constexpr bool pp_res_lds() { return ACT == ACT_NONE && !OUT_F32; }
+template <int MT, int OW>
+constexpr int res_stage_bytes() { return ((MT * 16 * (OW / 8 + 1) * 16 + 1023) / 1024) * 1024; }
+
+template <int MT, int OW>
+__device__ __forceinline__ void stage_residual(const GemmArgs& p, char* dst, int row0, int col0, int lane) {
+    constexpr int CPR = OW / 8, CPRP = CPR + 1, SLOTS = MT * 16 * CPRP, NI = (SLOTS + 63) / 64;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int sl = min(k * 64 + lane, SLOTS - 1);
+        const int row = sl / CPRP, ch = min(sl - row * CPRP, CPR - 1);
+        const unsigned short* src = p.res + (long)min(row0 + row, p.M - 1) * p.ldr + col0 + ch * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + k * 1024), 16, 0, 0);
+    }
+}
+// wave-uniform: the wave's OW output columns lie inside the matrix and the residual rows can be fetched in aligned 16-byte pieces
+template <int OW, bool OUT_F32>
+__device__ __forceinline__ bool residual_stageable(const GemmArgs& p, int col0, int Nout) {
+    return !OUT_F32 && p.res && col0 + OW <= Nout && (p.ldr & 7) == 0 && (p.ldc & 7) == 0 && ((((size_t)p.res) & 15) == 0);
+}
+
 // PARTS: part1 / part2 are read (stream-K owner slices); tab: this kernel's activation table in LDS (act_tab; GELU / SwiGLU epilogues only).
 template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32, bool LNF = false, bool PARTS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmArgs& p, char* est, const char* tab, int lane, int m0, int n0,
-                                              int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr) {
+                                              int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr, const char* resl = nullptr) {
     static_assert(!(LNF && ACT == ACT_SWIGLU), "the LayerNorm-folded epilogue has no SwiGLU form");
     // part1 / part2 (stream-K owner slices only): this lane's view of up to two f32 partial-sum slabs in accumulator order
     // (quad (i, j) at [(i * NTL + j) * 64]).  They are added to the accumulators as those are READ, one m-tile ahead of use,
@@ -230,6 +259,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             }
         }
     }
+    if (resl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's staged residual rows have landed (plain LDS reads do not wait for LDS-DMA by themselves)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         // ---- values of this m-tile, whole quads at a time (f32x4 arithmetic lowers to v_pk_mul / v_pk_fma / v_pk_add: two elements per VALU slot).  Optional steps
@@ -343,7 +373,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                     if (p.res) {
                         const unsigned short* rs = p.res + (long)row * p.ldr + col;
                         u32x4 rv;
-                        if (vec && ((p.ldr & 7) == 0) && ((((size_t)p.res) & 15) == 0)) {
+                        if (resl) {   // staged by this wave (stage_residual): row i*16 + c, chunk (col - ncol0) / 8
+                            rv = *(const u32x4*)(resl + (((i * 16 + c) * (OW / 8 + 1) + ((col - ncol0) >> 3)) << 4));
+                        } else if (vec && ((p.ldr & 7) == 0) && ((((size_t)p.res) & 15) == 0)) {
                             rv = *(const u32x4*)rs;
                         } else {
 #pragma unroll
@@ -376,7 +408,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             if (row_ok && col < Nout) {
                 u32x2 val = pk[OUT_NT - 1];
                 unsigned short* dst = (unsigned short*)p.C + (long)row * p.ldc + col;
-                if (p.res) {
+                if (p.res && resl) {   // staged residual: 8 bytes of chunk (col - ncol0) / 8
+                    const u32x2 rv = *(const u32x2*)(resl + (((i * 16 + c) * (OW / 8 + 1) + ((col - ncol0) >> 3)) << 4) + (((col - ncol0) & 4) << 1));
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        val[e] = pack_bf2(__uint_as_float(val[e] << 16) + __uint_as_float(rv[e] << 16), __uint_as_float(val[e] & 0xffff0000u) + __uint_as_float(rv[e] & 0xffff0000u));
+                } else if (p.res) {
                     const unsigned short* rs = p.res + (long)row * p.ldr + col;
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
@@ -592,8 +629,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     }
     if constexpr (TAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of the table have landed ...
     __syncthreads();  // ... everyone's; all waves done with the last stage: LDS is free for the epilogue staging
+    // residual rows of the wave's block: one LDS-DMA burst behind the per-wave parking bytes (epilogues without an activation table; the block must fit the tile's LDS)
+    constexpr int OW = (ACT == ACT_SWIGLU ? NTL / 2 : NTL) * 16;
+    constexpr int RSB = res_stage_bytes<MT, OW>();
+    constexpr bool RES_LDS = !TAB && !OUT_F32 && (NW * 1024 + NW * RSB <= (PIPE == 3 ? 3 : 2) * STAGE);
+    const char* resl = nullptr;
+    if constexpr (RES_LDS) {
+        const int col0 = (ACT == ACT_SWIGLU) ? (n0 / 2 + wn * OW) : (n0 + wn * OW);
+        if (residual_stageable<OW, OUT_F32>(p, col0, (ACT == ACT_SWIGLU) ? p.N / 2 : p.N)) {
+            char* dst = smem + NW * 1024 + wid * RSB;
+            stage_residual<MT, OW>(p, dst, m0 + wm * WTM, col0, lane);
+            resl = dst;
+        }
+    }
     gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + est_stage * STAGE + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + tab_stage * STAGE, lane, m0,
-                                                        n0, wm, wn);
+                                                        n0, wm, wn, nullptr, nullptr, resl);
 }
 
 // =====================================================================================================================
@@ -772,7 +822,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the groups
     __syncthreads();  // LDS is free for the epilogue staging
-    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + 2 * BUF, lane, m0, n0, wr, wc);
+    constexpr int OW = (ACT == ACT_SWIGLU ? NTL / 2 : NTL) * 16;
+    constexpr int RSB = res_stage_bytes<MT, OW>();
+    const char* resl = nullptr;
+    if constexpr (pp_res_lds<ACT, OUT_F32>()) {   // the launcher grants 8 KiB + 8 x RSB of LDS for these instantiations
+        const int col0 = (ACT == ACT_SWIGLU) ? (n0 / 2 + wc * OW) : (n0 + wc * OW);
+        if (residual_stageable<OW, OUT_F32>(p, col0, (ACT == ACT_SWIGLU) ? p.N / 2 : p.N)) {
+            char* dst = smem + 8 * 1024 + wid * RSB;
+            stage_residual<MT, OW>(p, dst, m0 + wr * 128, col0, lane);
+            resl = dst;
+        }
+    }
+    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + 2 * BUF, lane, m0, n0, wr, wc, nullptr, nullptr, resl);
 }
 
 // In-place accumulate (C-in register == C-out register).  The builtin lets the register allocator pick a different
@@ -1074,6 +1135,18 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 __hip_atomic_store(sk.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
+            // the LAST item of a workgroup has no prologue in flight: both buffers are free, and the wave's residual rows go through LDS in one burst (before an
+            // owner slice starts waiting for its contributors)
+            const char* resl = nullptr;
+            char* est_i = est;
+            if constexpr (pp_res_lds<ACT, OUT_F32>()) {
+                if (!has_next && residual_stageable<64, OUT_F32>(p, n0 + wc * 64, p.N)) {
+                    char* dst = smem + 8 * 1024 + wid * res_stage_bytes<MT, 64>();
+                    stage_residual<MT, 64>(p, dst, m0 + wr * 32 * MH, n0 + wc * 64, lane_e);
+                    resl = dst;
+                    est_i = smem + wid * 1024;
+                }
+            }
             const f32x4 *part1 = nullptr, *part2 = nullptr;
             if (cur_kind == 2) {
                 // ---- owner slice: add the partial sums of the (at most two: P_sk <= 2 * sk_tiles) lower-numbered
@@ -1099,8 +1172,8 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 part1 = (const f32x4*)sk.slabs + (size_t)(w - 1) * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
                 if (two) part2 = part1 - 512 * 32;
             }
-            if (cur_kind == 2) gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, true>(acc, p, est, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2);
-            else gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, false>(acc, p, est, smem + 2 * BUF, lane_e, m0, n0, wr, wc);
+            if (cur_kind == 2) gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, true>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2, resl);
+            else gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, false>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, nullptr, nullptr, resl);
             if (cur_kind == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();  // every wave has consumed its slab values ...
@@ -1259,7 +1332,10 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.all_partial = 0;
         sk.plain_slabs = sk_plain_slabs();
     }
-    constexpr int LDS = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
+    constexpr int LDS_MAIN = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
+    constexpr int LDS_RES = pp_res_lds<ACT, OUT_F32>() ? 8 * 1024 + 8 * res_stage_bytes<2 * MH, 64>() : 0;
+    constexpr int LDS = LDS_MAIN > LDS_RES ? LDS_MAIN : LDS_RES;
+    static_assert(LDS <= 160 * 1024, "persistent kernel: LDS");
     auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, MH>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
@@ -1306,7 +1382,10 @@ static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.group_m = pick_group_m(a.ntm, 256);
-    constexpr int LDS = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
+    constexpr int LDS_MAIN = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
+    constexpr int LDS_RES = pp_res_lds<ACT, OUT_F32>() ? 8 * 1024 + 8 * res_stage_bytes<8, 64>() : 0;
+    constexpr int LDS = LDS_MAIN > LDS_RES ? LDS_MAIN : LDS_RES;
+    static_assert(LDS <= 160 * 1024, "ping-pong kernel: LDS");
     auto kern = gemm_nt_pp_kernel<ACT, OUT_F32, LNF>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
