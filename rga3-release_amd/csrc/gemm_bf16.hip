@@ -869,6 +869,7 @@ struct SkArgs {
     int sk_tiles;     // tiles [t_dp, t_dp + sk_tiles) are split
     int all_partial;  // split-K mode (tile 25): every slice only writes its slab; gemm_slab_reduce_kernel sums them afterwards
     int plain_slabs;  // measurement builds only (RGA3_AB, env RGA3_SK_PLAIN=1): the round-3 hand-off -- plain slab stores + agent-scope release fence
+    unsigned long long* dbg = nullptr;   // measurement builds only (RGA3_AB, env RGA3_SK_DBG=1): [P][8 items][8] s_memtime stamps of wave 0 (tools/probes/sk_items.py)
 };
 
 // MH = 16-row m-tiles per A half-tile and wave row: 4 -> 256-row tiles, 3 -> 192-row tiles (M = 2112 = 11 x 192: no padded tile row;
@@ -1052,8 +1053,14 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
 #pragma unroll
             for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef RGA3_AB
+        if (sk.dbg && tid == 0 && it < 8) sk.dbg[(size_t)w * 64 + it * 8 + 0] = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef RGA3_AB
+        if (sk.dbg && tid == 0 && it < 8) sk.dbg[(size_t)w * 64 + it * 8 + 1] = __builtin_amdgcn_s_memtime();
+#endif
         if (wr == 1) __builtin_amdgcn_s_barrier();
         const int nkt = ke - kb;
         const int last = 4 * nkt - 1;
@@ -1084,6 +1091,9 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
         asm volatile("s_nop 15" ::: "memory");  // asm MFMA results -> first compiler-generated reader (hipcc pads nothing for asm)
         if (wr == 0) __builtin_amdgcn_s_barrier();
         __syncthreads();  // every wave is past its last fragment read: both buffers are free
+#ifdef RGA3_AB
+        if (sk.dbg && tid == 0 && it < 8) sk.dbg[(size_t)w * 64 + it * 8 + 2] = __builtin_amdgcn_s_memtime();
+#endif
 
         const int cur_kind = kind;
         const bool has_next = it + 1 < n_items;
@@ -1097,6 +1107,9 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             if constexpr (PREFETCH) prologue_issue(kb, ke);
         }
 
+#ifdef RGA3_AB
+        if (sk.dbg && tid == 0 && it < 8) sk.dbg[(size_t)w * 64 + it * 8 + 3] = __builtin_amdgcn_s_memtime();
+#endif
         if (cur_kind == 1) {
             // ---- non-owner slice: partial sums -> this workgroup's slab, then publish
             f32x4* slab = (f32x4*)sk.slabs + (size_t)w * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
@@ -1183,7 +1196,13 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 }
             }
         }
+#ifdef RGA3_AB
+        if (sk.dbg && tid == 0 && it < 8) sk.dbg[(size_t)w * 64 + it * 8 + 4] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();  // epilogue staging reads are done before phase 0 / 1 of the next item restage A1 / B1 of buffer 0
+#ifdef RGA3_AB
+        if (sk.dbg && tid == 0 && it < 8) sk.dbg[(size_t)w * 64 + it * 8 + 5] = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (!PREFETCH) {
             if (has_next) prologue_issue(kb, ke);
         }
@@ -1332,6 +1351,13 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.all_partial = 0;
         sk.plain_slabs = sk_plain_slabs();
     }
+#ifdef RGA3_AB
+    {   // stamps go to the start of the slab area: tile 21 / 31 only (no stream-K tail writes slabs there)
+        static const bool dbg = [] { const char* e = getenv("RGA3_SK_DBG"); return e && atoi(e) != 0; }();
+        SkWorkspace w2;
+        sk.dbg = (dbg && !split && !sk_workspace(ws_ptr, ws_bytes, w2)) ? (unsigned long long*)w2.slabs : nullptr;
+    }
+#endif
     constexpr int LDS_MAIN = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
     constexpr int LDS_RES = pp_res_lds<ACT, OUT_F32>() ? 8 * 1024 + 8 * res_stage_bytes<2 * MH, 64>() : 0;
     constexpr int LDS = LDS_MAIN > LDS_RES ? LDS_MAIN : LDS_RES;

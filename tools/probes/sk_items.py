@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a persistent-GEMM item spends its time (AB build librga3_hip_ab.so, RGA3_SK_DBG=1): wave 0 of every workgroup stamps s_memtime at
+"""Where a persistent-GEMM item spends its time (AB build: hipcc ... -DRGA3_AB -c csrc/gemm_bf16.hip linked with the product objects into rga3-release_amd/librga3_hip_ab.so; RGA3_SK_DBG=1): wave 0 of every workgroup stamps s_memtime at
 0 item start | 1 first K-tile landed + barrier | 2 main loop done | 3 next item set up + its prologue issued | 4 epilogue done | 5 item end."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

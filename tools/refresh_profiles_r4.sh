@@ -13,6 +13,13 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTI
   i=$((i+1)); timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d /tmp/pu/p$i -- python3 $R/tools/pmc_pipe_util.py run > $O/r04_pmc_pipe_p$i.log 2>&1; echo "pipe pass $i rc $?"
 done
 python3 $R/tools/pmc_pipe_util.py sum /tmp/pu $O/r04_pmc_pipe_util.json > $O/r04_pmc_pipe_util.txt 2>&1; mkdir -p $R/profiles; cp $O/r04_pmc_pipe_util.json $R/profiles/
+# 0b. Hiera stage-3 products (K = 576 family): time per tiling + PMC passes (L2 hit rate, fetch / write bytes, MFMA-busy, VALU share)
+timeout -k 10 400 python3 $R/tools/probes/k576_probe.py time $O/r04_k576_time.json > $O/r04_k576_time.log 2>&1; grep -v amdgpu $O/r04_k576_time.log | tail -4
+rm -rf /tmp/pk; i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
+  i=$((i+1)); timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pk/p$i -- python3 $R/tools/probes/k576_probe.py pmc > $O/r04_k576_pmc_p$i.log 2>&1; echo "k576 pmc pass $i rc $?"
+done
+python3 $R/tools/probes/k576_probe.py sum /tmp/pk $O/r04_k576_pmc.json > $O/r04_k576_pmc.txt 2>&1
 # 1. the driver's command (default mode = BASELINE metric) and its kernel statistics
 $B --gpus 1 --steps 20 --warmup 5 > $O/r04_bench_headline.json 2> $O/r04_bench_headline.err; tail -c 300 $O/r04_bench_headline.json
 rm -rf /tmp/p1; timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o head -- $B --steps 20 --warmup 5 --no-cpu-baseline > $O/r04_prof_headline.log 2>&1
