@@ -661,19 +661,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
 //    into a region whose last read was >= 2 phases earlier, then waits until all but the 4 youngest half-tiles (8 loads
 //    per lane) have landed => S[<= g+2] are complete, and they are first read in phase g+1 (two barriers later).
 // LDS: 2 buffers x 4 half-tiles x 16 KiB = 128 KiB, one workgroup per CU, 2 waves per SIMD.
-template <int ACT, bool OUT_F32, bool LNF = false>
+// N192 (tile 23): the same loop on a 4 x 2 wave grid -- wave blocks of 64 x 96, tile 256 x 192 -- for widths that are multiples of 192 but not of 256 (Hiera stage 3:
+// N = 576 is 3 x 192 against 2.25 x 256: a quarter of the 256-wide tiles' MFMAs multiply padding).  A half-tile: 4 wave rows x 32 rows; B half-tile: 2 wave columns x 48
+// columns = 96 LDS rows of its 128-row region (waves 4-7 repeat the second staging piece of waves 0-3, as the 192-ROW form of the persistent kernel does, so that every
+// wave still issues two loads per half-tile); quadrant = 2 x 3 x 2 = 12 MFMAs.
+template <int ACT, bool OUT_F32, bool LNF = false, bool N192 = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
+    constexpr int BM = 256, BN = N192 ? 192 : 256, BK = 64, ROWB = 128;
     constexpr int HALF = 128 * ROWB;  // 16 KiB
     constexpr int BUF = 4 * HALF;     // A0 | A1 | B0 | B1
-    constexpr int MT = 8, NTL = 4;
+    constexpr int WC = N192 ? 2 : 4;                 // wave columns (wave rows = 8 / WC)
+    constexpr int MI = N192 ? 2 : 4, NI = N192 ? 3 : 2;   // 16-row m-tiles / 16-column n-tiles of a wave per half-tile
+    constexpr int AH = 16 * MI, BH = 16 * NI;        // rows / columns of a wave inside one half-tile
+    constexpr int MT = 2 * MI, NTL = 2 * NI;
+    constexpr int WTM = 2 * AH, WTN = 2 * BH;        // wave block
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;  // waves w and w+4 share a SIMD: one of each group per SIMD
+    const int wr = wid / WC, wc = wid % WC;  // waves w and w+4 share a SIMD: one of each group (wid >> 2) per SIMD
+    const int grp = wid >> 2;
 
     // activation table (GELU / SwiGLU epilogues): 10 KiB behind the two buffers, copied first (the oldest loads of every wave: every counted wait below covers them)
     if constexpr (act_uses_table<ACT>()) stage_act_table<8>(smem + 2 * BUF, ACT == ACT_SWIGLU, wid, lane);
@@ -696,10 +705,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wid + 8 * i) * 8 + (lane >> 3);  // LDS row of the half-tile, 0..127
+        // 96-row B half-tiles (N192): piece 12 + w of waves 4-7 does not exist; they repeat piece 8 + (w & 3) (same destination: see stage)
+        const int rb = (!N192 || i == 0 || wid < 4) ? r : ((8 + (wid & 3)) * 8 + (lane >> 3));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int arow = (r >> 6) * 128 + h * 64 + (r & 63);
-            const int bcol = (r >> 5) * 64 + h * 32 + (r & 31);
+            const int arow = (r / AH) * (2 * AH) + h * AH + (r % AH);
+            const int bcol = (rb / BH) * (2 * BH) + h * BH + (rb % BH);
             soff[h][i] = (unsigned)((long)min(m0 + arow, p.M - 1) * p.lda + sch * 8);
             soff[2 + h][i] = (unsigned)((long)min(n0 + bcol, p.N - 1) * p.ldw + sch * 8);
         }
@@ -710,17 +721,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
         constexpr int kind = decltype(KIND)::value;
         const unsigned short* base = ((kind < 2) ? p.A : p.W) + (long)kt * BK;  // scalar part first: saddr + 32-bit voffset form
         char* dst = smem + buf * BUF + kind * HALF + wid * 1024;
+        const int second = (N192 && kind >= 2 && wid >= 4) ? (8 + (wid & 3) - wid) * 1024 : 8192;   // second piece: 8 KiB on (N192 B half-tiles: see soff)
         if (ktail && kt == nk - 1) {
             const bool ok = kt * BK + sch * 8 < p.K;  // chunks at or beyond K come from 16 zero bytes
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const unsigned short* src = ok ? base + soff[kind][i] : (const unsigned short*)&g_zero16;
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + i * 8192), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + i * second), 16, 0, 0);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(base + soff[kind][i]), (lds_void*)(dst + i * 8192), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(base + soff[kind][i]), (lds_void*)(dst + i * second), 16, 0, 0);
         }
     };
     using K_A0 = std::integral_constant<int, 0>;
@@ -739,8 +751,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     int foff[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) foff[kk] = (lane & 15) * ROWB + (((kk * 4 + (lane >> 4)) ^ ((lane >> 1) & 7)) << 4);
-    const int a_rd = (wr * 64) * ROWB;                 // + h*HALF + mi*2048 + foff[kk]
-    const int b_rd = 2 * HALF + (wc * 32) * ROWB;      // + h*HALF + ni*2048 + foff[kk]
+    const int a_rd = (wr * AH) * ROWB;                 // + h*HALF + mi*2048 + foff[kk]
+    const int b_rd = 2 * HALF + (wc * BH) * ROWB;      // + h*HALF + ni*2048 + foff[kk]
 
     f32x4 acc[MT][NTL];
 #pragma unroll
@@ -748,20 +760,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    bf16x8 af[MI][2], b0[NI][2], b1[NI][2];
     auto read_a = [&](const char* cur, int h) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8*)(cur + a_rd + h * HALF + mi * 2048 + foff[kk]);
     };
-    auto read_b = [&](bf16x8 (&bf)[2][2], const char* cur, int h) {
+    auto read_b = [&](bf16x8 (&bf)[NI][2], const char* cur, int h) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) bf[ni][kk] = *(const bf16x8*)(cur + b_rd + h * HALF + ni * 2048 + foff[kk]);
     };
-    auto mma_quadrant = [&](auto HA, auto HB, const bf16x8 (&bf)[2][2]) {
+    auto mma_quadrant = [&](auto HA, auto HB, const bf16x8 (&bf)[NI][2]) {
         constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -769,11 +781,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[ha * 4 + mi][hb * 2 + ni] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni][kk], af[mi][kk], acc[ha * 4 + mi][hb * 2 + ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[ha * MI + mi][hb * NI + ni] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni][kk], af[mi][kk], acc[ha * MI + mi][hb * NI + ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -791,7 +803,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     }
     wait_halftiles(nk > 1 ? 4 : 2);  // S[0], S[1] landed (own loads) ...
     __builtin_amdgcn_s_barrier();    // ... and everyone's
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind the first
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind the first
 
     const int last = 4 * nk - 1;  // index of the last half-tile
     for (int kt = 0; kt < nk; ++kt) {
@@ -820,7 +832,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
         if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_halftiles(max(min(g + 9, last) - (g + 5), 0));
         mma_quadrant(H1{}, H0{}, b0);
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the groups
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the groups
     __syncthreads();  // LDS is free for the epilogue staging
     constexpr int OW = (ACT == ACT_SWIGLU ? NTL / 2 : NTL) * 16;
     constexpr int RSB = res_stage_bytes<MT, OW>();
@@ -829,11 +841,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
         const int col0 = (ACT == ACT_SWIGLU) ? (n0 / 2 + wc * OW) : (n0 + wc * OW);
         if (residual_stageable<OW, OUT_F32>(p, col0, (ACT == ACT_SWIGLU) ? p.N / 2 : p.N)) {
             char* dst = smem + 8 * 1024 + wid * RSB;
-            stage_residual<MT, OW>(p, dst, m0 + wr * 128, col0, lane);
+            stage_residual<MT, OW>(p, dst, m0 + wr * WTM, col0, lane);
             resl = dst;
         }
     }
-    gemm_epilogue<MT, NTL, 128, 64, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + 2 * BUF, lane, m0, n0, wr, wc, nullptr, nullptr, resl);
+    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + 2 * BUF, lane, m0, n0, wr, wc, nullptr, nullptr, resl);
 }
 
 // In-place accumulate (C-in register == C-out register).  The builtin lets the register allocator pick a different
@@ -1304,7 +1316,7 @@ static inline int sk_plain_slabs() {
 #endif
 }
 
-template <int ACT, bool OUT_F32, bool LNF = false>
+template <int ACT, bool OUT_F32, bool LNF = false, bool N192 = false>
 static int launch_pp(const GemmArgs& a0, hipStream_t st);
 
 template <int ACT, bool OUT_F32, int MH = 4>
@@ -1402,17 +1414,17 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
-template <int ACT, bool OUT_F32, bool LNF>
+template <int ACT, bool OUT_F32, bool LNF, bool N192>
 static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, 256);
-    a.ntn = (int)cdiv(a.N, 256);
+    a.ntn = (int)cdiv(a.N, N192 ? 192 : 256);
     a.group_m = pick_group_m(a.ntm, 256);
     constexpr int LDS_MAIN = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
-    constexpr int LDS_RES = pp_res_lds<ACT, OUT_F32>() ? 8 * 1024 + 8 * res_stage_bytes<8, 64>() : 0;
+    constexpr int LDS_RES = pp_res_lds<ACT, OUT_F32>() ? 8 * 1024 + 8 * (N192 ? res_stage_bytes<4, 96>() : res_stage_bytes<8, 64>()) : 0;
     constexpr int LDS = LDS_MAIN > LDS_RES ? LDS_MAIN : LDS_RES;
     static_assert(LDS <= 160 * 1024, "ping-pong kernel: LDS");
-    auto kern = gemm_nt_pp_kernel<ACT, OUT_F32, LNF>;
+    auto kern = gemm_nt_pp_kernel<ACT, OUT_F32, LNF, N192>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn)), dim3(512), LDS, st, a);
@@ -1953,6 +1965,9 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
             if constexpr (ACT == ACT_NONE) return launch_split64<OUT_F32>(a, st);
             else return launch_cfg<64, 64, 2, 2, ACT, OUT_F32, 0>(a, st);
         case 20: return launch_pp<ACT, OUT_F32>(a, st);
+        case 23:   // ping-pong on 256 x 192 tiles (4 x 2 wave grid, 6 n-tiles per wave: SwiGLU pairs exist, but its packed widths are multiples of 256 anyway)
+            if constexpr (ACT == ACT_NONE) return launch_pp<ACT, OUT_F32, false, true>(a, st);
+            else return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
         case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
         case 31: return launch_sk<ACT, OUT_F32, 3>(a, false, st);   // 192 x 256 tiles, persistent
@@ -2060,7 +2075,7 @@ static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const 
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || (tile >= 3 && tile <= 8) || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 22) || tile == 25 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || (tile >= 3 && tile <= 8) || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 23) || tile == 25 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;

@@ -137,6 +137,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
             extra = extra + (14,)
         if M <= 16 and colscale is None and out_dtype == torch.bfloat16 and act != "swiglu":   # token rows (smaller products take tile 41 without asking)
             extra = extra + (41,)
+        if act == "none" and N % 192 == 0 and N % 256 != 0 and M >= 1024:   # widths of 3 / 9 x 192 (Hiera stage 3): the ping-pong loop on 256 x 192 tiles
+            extra = extra + (23,)
         tile = _tuner.pick(_tuner.key_of(M, N, K, act, odt, bias is not None, residual is not None), run, extra)
     run(tile)
     return out

@@ -26,7 +26,7 @@ def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed / mis-mapped C fragment layout."""
     from rga3.hip import ops
 
-    for tile in (3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 31, 32):
+    for tile in (3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 20, 21, 22, 23, 31, 32):
         n, k = 256, 256
         a = torch.eye(k, dtype=torch.bfloat16, device=dev)
         w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(torch.bfloat16).to(dev)
@@ -36,7 +36,7 @@ def test_gemm_identity_asymmetric(dev):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (2112, 512, 3584), (8192, 1280, 1280), (64, 3456, 1280),
                                    (17, 24, 64), (1000, 152064 // 16, 192)])
-@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 23, 31, 32])
 def test_gemm_plain(dev, M, N, K, tile):
     from rga3.hip import ops
 
@@ -113,7 +113,7 @@ def test_gemm_stream_k_split_shapes(dev):
 
 
 @pytest.mark.parametrize("act", ["none", "gelu", "relu", "swiglu"])
-@pytest.mark.parametrize("tile", [3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 31, 32])
+@pytest.mark.parametrize("tile", [3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 23, 31, 32])
 def test_gemm_epilogues(dev, act, tile):
     from rga3.hip import ops
 
@@ -150,7 +150,7 @@ def test_gemm_rejects_bad_args(dev):
         ops.gemm(a.cpu(), w.cpu())
 
 
-@pytest.mark.parametrize("tile", [-1, 3, 12, 5, 6, 20, 21, 22, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 12, 5, 6, 20, 21, 22, 23, 31, 32])
 @pytest.mark.parametrize("shape", [(300, 320, 256), (2112, 1280, 1280)])
 def test_gemm_rmsnorm_folded(dev, tile, shape):
     """RMSNorm folded into the products on either side (rga3_gemm_rms_bf16; HF Qwen2RMSNorm modeling_qwen2_5_vl.py:470-486 between o_proj / down_proj and
@@ -264,7 +264,7 @@ def test_gemm_epilogue_activation_tables_every_bf16_input(dev, tile):
     check(outs[:, 250], silu, "silu")
 
 
-@pytest.mark.parametrize("tile", [-1, 5, 12])
+@pytest.mark.parametrize("tile", [-1, 5, 12, 23])
 def test_gemm_epilogues_two_workgroups_per_cu(dev, tile):
     """The epilogue variants on grids of MORE than one workgroup per CU (the 64- / 80-KiB tilings co-reside): a packed-f32 form of the LayerNorm fold lost its product
     term in a few waves only when two workgroups shared a CU -- every epilogue kind is therefore also checked at M = 8192 rows, three runs
@@ -301,8 +301,9 @@ def test_gemm_epilogues_two_workgroups_per_cu(dev, tile):
     st = ops.layernorm_stats(x, 1e-6)
     wfold, colc, bfold = ops.fold_layernorm(w, b, gamma, beta)
     ln = F.layer_norm(xf, (K,), gamma.float().cpu(), beta.float().cpu(), 1e-6) @ wf32.t() + bf32
-    runs(lambda: ops.gemm_ln(x, st, wfold, colc, bfold, act="none", tile=tile), ln, 8e-3, "ln")
-    runs(lambda: ops.gemm_ln(x, st, wfold, colc, bfold, act="gelu", tile=tile), F.gelu(ln), 8e-3, "ln+gelu")
+    if tile != 23:    # rga3_gemm_ln_bf16 has no 256 x 192 form
+        runs(lambda: ops.gemm_ln(x, st, wfold, colc, bfold, act="none", tile=tile), ln, 8e-3, "ln")
+        runs(lambda: ops.gemm_ln(x, st, wfold, colc, bfold, act="gelu", tile=tile), F.gelu(ln), 8e-3, "ln+gelu")
     # RMSNorm folded in (consumer side) with the producer's sums
     sums = torch.zeros(M, dtype=torch.int64, device=dev)
     x2 = ops.gemm(x, torch.eye(K, dtype=torch.bfloat16, device=dev), tile=tile, rms_out=sums)

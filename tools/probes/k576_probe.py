@@ -17,7 +17,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 M = 65536
 SHAPES = {"fc1": (2304, 576, "ln+gelu"), "qkv": (1728, 576, "ln"), "fc2": (576, 2304, "res"), "proj": (576, 576, "res")}
-TILES = {"fc1": (5, 3, 6, 20, -1), "qkv": (5, 3, 6, 20, -1), "fc2": (5, 12, 3, 20, 21), "proj": (5, 12, 3, 20)}
+TILES = {"fc1": (5, 3, 6, 20, -1), "qkv": (5, 3, 6, 20, -1), "fc2": (5, 12, 3, 20, 21, 23), "proj": (5, 12, 3, 20, 23)}
 PMC_CASES = [("fc1", 5), ("fc1", 20), ("qkv", 5), ("qkv", 20), ("fc2", 5), ("fc2", 20), ("proj", 5)]
 
 

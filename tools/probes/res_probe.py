@@ -20,7 +20,7 @@ def timeit(fn, n=6, inner=4):
         e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1) / inner * 1e3)
     ts.sort(); return ts[len(ts) // 2]
 cases = [("LLM o-proj", 2112, 3584, 3584, (3, 12, 20, 31, 5)), ("LLM down", 2112, 3584, 18944, (22, 21, 20)), ("ViT proj", 8192, 1280, 1280, (4, 3, 20, 12)), ("ViT down", 8192, 1280, 3456, (4, 3, 20, 12)),
-         ("Hiera fc2", 65536, 576, 2304, (20, 21, 5, 12)), ("Hiera proj", 65536, 576, 576, (5, 12, 20)), ("Hiera s2 fc2", 16384, 1152, 4608, (20, 3, 5)), ("ragged", 1000, 1000, 320, (3, 5, 12, 13, 20))]
+         ("Hiera fc2", 65536, 576, 2304, (20, 21, 5, 12, 23)), ("Hiera proj", 65536, 576, 576, (5, 12, 20, 23)), ("Hiera s2 fc2", 16384, 1152, 4608, (20, 3, 5, 23)), ("ragged", 1000, 1000, 320, (3, 5, 12, 13, 20, 23))]
 for name, M, N, K, tiles in cases:
     x, w, b, r = rn(M, K), rn(N, K, scale=0.02), rn(N), rn(M, N)
     ref = ops.gemm(x, w, bias=b, residual=r, tile=13)
