@@ -87,6 +87,11 @@ int64_t rga3_gemm_workspace_bytes(void);
  * tile last (which one is timing, the order of the additions is not: deterministic). */
 int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                       int64_t ldc, int out_dtype, void* workspace, int64_t workspace_bytes, void* counters, void* stream);
+/* n (<= 4) such products in ONE launch (+ one slab-sum launch): the four LoRA weight gradients of a decoder layer (dB_q, dA_q, dB_v, dA_v: autograd of PEFT's
+ * lora_A / lora_B under reference train_joint.py:193-232, 534) were four launches of 1 - 28 tiles and four slab sums.  ptrs: n x 3 {A, B, C}; dims: n x 7
+ * {M, N, K, lda, ldb, ldc, out_dtype}; HOST arrays.  Every product is K-split exactly as rga3_gemm_tn_bf16 with a full-size workspace splits it (same bits); the
+ * caller's workspace must hold sum_i Z_i M_i N_i floats, Z_i = min(64, 256 / tiles_i, K_i / 256) (>= 1), or the call fails. */
+int rga3_gemm_tn_many(const void* const* ptrs, const int64_t* dims, int n, void* workspace, int64_t workspace_bytes, void* stream);
 
 
 /* Variable-length fused attention forward (online softmax, fp32 statistics), bf16 in/out.

@@ -1512,7 +1512,7 @@ struct TnArgs {
 };
 
 template <bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
+__device__ __forceinline__ void gemm_tn_body(GemmArgs p, TnArgs t, const unsigned bx, const unsigned by, const unsigned bz, const unsigned gx, const unsigned gz) {
     constexpr int BM = 128, BN = 128, BK = 32;
     constexpr int STRIDE = BM * 2 + 32;          // bytes per staged k-row (both operands: BM == BN)
     constexpr int TILE = BK * STRIDE;
@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int g = lane >> 4, c = lane & 15;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
 
     // staging: 32 rows x 16 chunks (16 B) per operand tile = 512 chunks, two per thread
     int srow[2], scol[2];
@@ -1571,9 +1571,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk_all = (t.K + BK - 1) / BK;
-    const int kt0 = (int)blockIdx.z * t.kt_per_z;            // this workgroup's K range (the whole of K without a split)
+    const int kt0 = (int)bz * t.kt_per_z;            // this workgroup's K range (the whole of K without a split)
     const int nk = min(nk_all, kt0 + t.kt_per_z);
-    if (t.slab) p.C = (void*)((float*)p.C + (long)blockIdx.z * t.slab);
+    if (t.slab) p.C = (void*)((float*)p.C + (long)bz * t.slab);
     load_tile(kt0);
     for (int kt = kt0; kt < nk; ++kt) {
         store_tile(kt & 1);
@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
-    const float* ws_base = (const float*)p.C - (t.slab ? (long)blockIdx.z * t.slab : 0);
+    const float* ws_base = (const float*)p.C - (t.slab ? (long)bz * t.slab : 0);
     gemm_epilogue<4, 4, 64, 64, ACT_NONE, OUT_F32>(acc, p, smem, nullptr, lane, m0, n0, wm, wn);
     if constexpr (OUT_F32) {
         if (t.counters) {
@@ -1601,12 +1601,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
             __shared__ unsigned s_last;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned tile = by * gx + bx;
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const unsigned prev = __hip_atomic_fetch_add(t.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = (prev == gridDim.z - 1) ? 1u : 0u;
+                s_last = (prev == gz - 1) ? 1u : 0u;
                 if (s_last) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
             }
             __syncthreads();
             if (s_last) {
-                const int Z = (int)gridDim.z;
+                const int Z = (int)gz;
                 for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
                     const int r = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
                     const int row = m0 + r, col = n0 + c4;
@@ -1639,6 +1639,58 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
 }
 
 // out[i] = sum_z slabs[z][i] in fixed order (deterministic), to bf16 or f32; 4 elements per thread
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p, TnArgs t) {
+    gemm_tn_body<OUT_F32>(p, t, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+}
+
+// Up to 4 independent TN products in ONE launch (rga3_gemm_tn_many: the four LoRA weight-gradient products of a decoder layer, dB_q / dA_q / dB_v / dA_v -- each a
+// handful of 128 x 128 tiles over K = 2112 tokens -- were four launches of 1 - 28 tiles plus four slab sums).  Every product is K-split into f32 slabs exactly as the
+// single form would split it; workgroup b belongs to the product whose [first, first_next) range holds it.
+struct TnMany {
+    GemmArgs a[4];
+    TnArgs t[4];
+    unsigned first[5];   // first workgroup of every product; first[n] = grid size
+    int n;
+};
+__global__ __launch_bounds__(256) void gemm_tn_many_kernel(TnMany P) {
+    const unsigned b = blockIdx.x;
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) q += (i < P.n && b >= P.first[i]) ? 1 : 0;
+    const unsigned local = b - P.first[q];
+    const unsigned gx = (unsigned)P.a[q].ntn, gy = (unsigned)P.a[q].ntm;
+    gemm_tn_body<true>(P.a[q], P.t[q], local % gx, (local / gx) % gy, local / (gx * gy), gx, 0u);
+}
+struct SlabSumMany {
+    const float* slabs[4];
+    void* out[4];
+    long n[4], ldc[4];
+    int ncols[4], Z[4], out_f32[4];
+    unsigned first[5];   // first 256-thread block of every product
+    int np;
+};
+__global__ __launch_bounds__(256) void tn_slab_sum_many_kernel(SlabSumMany S) {
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) q += (i < S.np && blockIdx.x >= S.first[i]) ? 1 : 0;
+    const long i4 = ((long)(blockIdx.x - S.first[q]) * 256 + threadIdx.x) * 4;
+    const long n = S.n[q];
+    if (i4 >= n) return;
+    const float* slabs = S.slabs[q];
+    f32x4 acc = *(const f32x4*)(slabs + i4);
+    for (int z = 1; z < S.Z[q]; ++z) acc += *(const f32x4*)(slabs + (long)z * n + i4);
+    const long r = i4 / S.ncols[q], c = i4 % S.ncols[q];     // ncols % 8 == 0: a quad never crosses a row
+    if (S.out_f32[q]) {
+        *(f32x4*)((float*)S.out[q] + r * S.ldc[q] + c) = acc;
+    } else {
+        u32x2 pk;
+        pk[0] = pack_bf2(acc[0], acc[1]);
+        pk[1] = pack_bf2(acc[2], acc[3]);
+        *(u32x2*)((unsigned short*)S.out[q] + r * S.ldc[q] + c) = pk;
+    }
+}
+
 __global__ __launch_bounds__(256) void tn_slab_sum_kernel(const float* __restrict__ slabs, void* __restrict__ out, long n, long ldc, int ncols, int Z, int out_f32) {
     const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
@@ -2198,5 +2250,64 @@ extern "C" int rga3_gemm_tn_bf16(const void* A, const void* B, const void* bias,
     hipLaunchKernelGGL(tn_slab_sum_kernel, dim3((unsigned)cdiv(M * N / 4, 256)), dim3(256), 0, st, (const float*)workspace, C, (long)(M * N), (long)ldc, (int)N, Z,
                        out_dtype == RGA3_F32 ? 1 : 0);
     RGA3_CHECK_LAUNCH("tn_slab_sum_kernel");
+    return 0;
+}
+
+// n (<= 4) products C_i [M_i, N_i] = A_i^T B_i (A_i [K_i, M_i], B_i [K_i, N_i] bf16 row-major) in one launch + one slab-sum launch.  ptrs: n x 3 {A, B, C}; dims: n x 7
+// {M, N, K, lda, ldb, ldc, out_dtype} (HOST arrays).  Every product is cut into the K slices rga3_gemm_tn_bf16 would cut it into (same slab sums, same bits); the
+// workspace must hold all slabs (sum of Z_i M_i N_i floats), else -> error (the caller then issues the products one by one).
+extern "C" int rga3_gemm_tn_many(const void* const* ptrs, const int64_t* dims, int n, void* workspace, int64_t workspace_bytes, void* stream) {
+    RGA3_CHECK_ARG(ptrs && dims && n >= 1 && n <= 4 && workspace && (((uintptr_t)workspace) & 15) == 0, "gemm_tn_many: bad args (1 <= n <= 4, workspace required)");
+    TnMany P;
+    SlabSumMany S;
+    P.n = n; S.np = n;
+    unsigned wg = 0, sb = 0;
+    int64_t used = 0;
+    for (int i = 0; i < n; ++i) {
+        const void *A = ptrs[3 * i], *B = ptrs[3 * i + 1];
+        void* C = (void*)ptrs[3 * i + 2];
+        const int64_t M = dims[7 * i], N = dims[7 * i + 1], K = dims[7 * i + 2], lda = dims[7 * i + 3], ldb = dims[7 * i + 4], ldc = dims[7 * i + 5];
+        const int out_dtype = (int)dims[7 * i + 6];
+        RGA3_CHECK_ARG(A && B && C, "gemm_tn_many: null pointer (product %d)", i);
+        RGA3_CHECK_ARG(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0, "gemm_tn_many: bad shape M=%ld N=%ld K=%ld (product %d)", (long)M, (long)N, (long)K, i);
+        RGA3_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_tn_many: lda/ldb must be multiples of 8 elements, ldc of 4 (product %d)", i);
+        RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "gemm_tn_many: pointers must be 16-byte aligned (product %d)", i);
+        RGA3_CHECK_ARG(out_dtype == RGA3_BF16 || out_dtype == RGA3_F32, "gemm_tn_many: out_dtype %d", out_dtype);
+        GemmArgs& a = P.a[i];
+        a = GemmArgs();
+        a.A = nullptr; a.W = nullptr; a.bias = nullptr; a.res = nullptr; a.colscale = nullptr;
+        a.M = (int)M; a.N = (int)N; a.K = (int)K;
+        a.lda = 0; a.ldw = 0; a.ldr = 0;
+        a.ntm = (int)cdiv(M, 128); a.ntn = (int)cdiv(N, 128); a.group_m = 1;
+        a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
+        TnArgs& t = P.t[i];
+        t.A = (const unsigned short*)A; t.B = (const unsigned short*)B; t.lda = lda; t.ldb = ldb; t.K = (int)K;
+        t.counters = nullptr; t.out = nullptr; t.ldo = 0; t.out_f32 = 0;
+        const int nk = (int)cdiv(K, 32);
+        const long tiles = (long)a.ntm * a.ntn;
+        int Z = 1;
+        if (tiles < 128 && nk >= 32) {     // the single form's rule
+            Z = (int)(256 / tiles);
+            if (Z > 64) Z = 64;
+            if (Z > nk / 8) Z = nk / 8;
+            if (Z < 2) Z = 1;
+        }
+        t.kt_per_z = (int)cdiv(nk, Z);
+        Z = (int)cdiv(nk, t.kt_per_z);
+        t.slab = M * N;
+        RGA3_CHECK_ARG(used + (int64_t)Z * M * N * 4 <= workspace_bytes, "gemm_tn_many: workspace too small (%ld bytes needed so far)", (long)(used + (int64_t)Z * M * N * 4));
+        a.C = (char*)workspace + used; a.ldc = N;
+        S.slabs[i] = (const float*)a.C; S.out[i] = C; S.n[i] = M * N; S.ldc[i] = ldc; S.ncols[i] = (int)N; S.Z[i] = Z; S.out_f32[i] = out_dtype == RGA3_F32 ? 1 : 0;
+        used += (int64_t)Z * M * N * 4;
+        P.first[i] = wg; wg += (unsigned)(tiles * Z);
+        S.first[i] = sb; sb += (unsigned)cdiv(M * N / 4, 256);
+    }
+    for (int i = n; i <= 4; ++i) { P.first[i] = wg; S.first[i] = sb; }
+    for (int i = n; i < 4; ++i) { P.a[i] = P.a[0]; P.t[i] = P.t[0]; S.slabs[i] = S.slabs[0]; S.out[i] = S.out[0]; S.n[i] = 0; S.ldc[i] = 0; S.ncols[i] = 8; S.Z[i] = 1; S.out_f32[i] = 0; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_many_kernel, dim3(wg), dim3(256), 0, st, P);
+    RGA3_CHECK_LAUNCH("gemm_tn_many_kernel");
+    hipLaunchKernelGGL(tn_slab_sum_many_kernel, dim3(sb), dim3(256), 0, st, S);
+    RGA3_CHECK_LAUNCH("tn_slab_sum_many_kernel");
     return 0;
 }

@@ -262,6 +262,37 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16, out=None
     return out
 
 
+def gemm_tn_many(pairs, out_dtype=torch.bfloat16):
+    """[a_i^T @ b_i for (a_i [K_i, M_i], b_i [K_i, N_i]) in pairs] (<= 4 products, bf16 operands) in ONE launch + one slab-sum launch (rga3_gemm_tn_many) --
+    bit-identical to gemm_tn on each pair; products the grouped entry point does not take (ragged widths) fall back to gemm_tn."""
+    import ctypes
+    n = len(pairs)
+    assert 1 <= n <= 4
+    ok = all(a.dtype == b.dtype == torch.bfloat16 and a.dim() == b.dim() == 2 and a.shape[0] == b.shape[0] and a.stride(1) == b.stride(1) == 1 and a.shape[1] % 8 == 0 and
+             b.shape[1] % 8 == 0 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 for a, b in pairs)
+    if n == 1 or not ok:
+        return [gemm_tn(a, b, out_dtype=out_dtype) for a, b in pairs]
+    ptrs, dims, outs, need = (ctypes.c_void_p * (3 * n))(), (ctypes.c_int64 * (7 * n))(), [], 0
+    for i, (a, b) in enumerate(pairs):
+        _need_cuda(a, b)
+        K, M = a.shape
+        N = b.shape[1]
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        outs.append(out)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        nk = (K + 31) // 32
+        z = max(1, min(64, 256 // tiles, nk // 8)) if (tiles < 128 and nk >= 32) else 1
+        need += z * M * N
+        for j, t in enumerate((a, b, out)):
+            ptrs[3 * i + j] = t.data_ptr()
+        for j, v in enumerate((M, N, K, a.stride(0), b.stride(0), out.stride(0), BF16 if out_dtype == torch.bfloat16 else F32)):
+            dims[7 * i + j] = int(v)
+    ws = torch.empty((need,), dtype=torch.float32, device=pairs[0][0].device)
+    _lib.check(_lib.load().rga3_gemm_tn_many(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dims, ctypes.c_void_p), n, ws.data_ptr(), ws.numel() * 4, _stream()),
+               "gemm_tn_many")
+    return outs
+
+
 _tn_cnt = {}
 
 

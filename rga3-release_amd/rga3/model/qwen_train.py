@@ -389,20 +389,22 @@ class DecoderLayerFn(torch.autograd.Function):
             dh1 = _fgemm(dqkv2, at, "wqkv_t", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: ops.transpose(wqkv))   # [T, H]
             grads = [None, None, None, None]
             if lq is not None or lv is not None:
+                tn_pairs, tn_slots = [], []      # the layer's weight-gradient products (dB = dsl^T t_s, dA = dt^T dropout(h1) per LoRA module): ONE grouped launch below
                 for slot, lp, lin, t_, cols, pdrop, hin, sd in ((0, lq, at.q_proj, tq, (0, Hq * D), pq, hq_in, 0),
                                                                 (2, lv, at.v_proj, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D), pv, hv_in, 1)):
                     if lp is None:
                         continue
                     _, At, Bts = _lora_ops(lin)                                         # A^T [H, r], (sB)^T [r, out]: once per step for all layers
                     dsl = dqkv2[:, cols[0]:cols[1]]                                    # [T, out]
-                    dB = ops.gemm_tn(dsl, t_)                                           # [out, r] = dsl^T t_s  (t_s carries s; contraction over tokens)
                     dt = ops.gemm(dsl, Bts)                                             # [T, r] = dsl (sB)
-                    dA = ops.gemm_tn(dt, h1 if pdrop == 0.0 else hin)                   # [r, H] = dt^T dropout(h1): lora_A saw the dropped input
+                    tn_pairs += [(dt, h1 if pdrop == 0.0 else hin), (dsl, t_)]          # dA [r, H] (lora_A saw the dropped input), dB [out, r] (t_s carries s)
+                    tn_slots += [slot, slot + 1]
                     if pdrop == 0.0:
                         ops.gemm(dt, At, residual=dh1, out=dh1)                         # dh1 += dt A
                     else:                                                               # dh1 += mask / keep * (dt A): same seed, same mask
                         ops.dropout(ops.gemm(dt, At), pdrop, ctx.seeds[sd], out=dh1, accumulate=True)
-                    grads[slot], grads[slot + 1] = dA, dB
+                for sl, gw in zip(tn_slots, ops.gemm_tn_many(tn_pairs)):
+                    grads[sl] = gw
             dx = ops.rmsnorm_bwd(x, w1.weight, dh1, w1.variance_epsilon, add=dx1)
         return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, None, None)
 

@@ -213,6 +213,27 @@ def test_attn_causal32_rope_on_load(dev, S, Hq, Hkv):
     assert float((out.float() - ref.float()).abs().max()) < 2e-2 and _rel_l2(out, ref.float().cpu()) < 2e-3
 
 
+def test_gemm_tn_many_equals_single_products(dev):
+    """rga3_gemm_tn_many: the four LoRA weight-gradient products of a decoder layer (dA_q, dB_q, dA_v, dB_v; autograd of PEFT's lora_A / lora_B, reference
+    train_joint.py:193-232) in one launch, bit-identical to rga3_gemm_tn_bf16 on each pair (same K split, same slab order), strided operands included."""
+    from rga3.hip import ops
+
+    T, H, r = 2112, 3584, 128
+    g = torch.Generator().manual_seed(5)
+    dqkv = (torch.randn(T, 4608, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    h1, hv = _rand((T, H), dev, seed=6), _rand((T, H), dev, seed=7)
+    tq, tv, dtq, dtv = _rand((T, r), dev, seed=8), _rand((T, r), dev, seed=9), _rand((T, r), dev, 0.1, seed=10), _rand((T, r), dev, 0.1, seed=11)
+    pairs = [(dtq, h1), (dqkv[:, :3584], tq), (dtv, hv), (dqkv[:, 4096:], tv)]
+    outs = ops.gemm_tn_many(pairs)
+    for (a, b), o in zip(pairs, outs):
+        assert torch.equal(o, ops.gemm_tn(a, b)), (a.shape, b.shape)
+        assert _rel_l2(o, a.float().cpu().t() @ b.float().cpu()) < 6e-3
+    o2 = ops.gemm_tn_many(pairs[:2], out_dtype=torch.float32)
+    assert torch.equal(o2[1], ops.gemm_tn(pairs[1][0], pairs[1][1], out_dtype=torch.float32))
+    o3 = ops.gemm_tn_many([(dtq[:, :20], h1)])          # ragged width: falls back to the single form
+    assert o3[0].shape == (20, H)
+
+
 def _all_bf16_finite(dev):
     bits = torch.arange(0, 65536, dtype=torch.int32)
     bits = bits[(bits & 0x7f80) != 0x7f80]                       # no Inf / NaN
