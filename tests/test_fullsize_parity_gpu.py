@@ -312,12 +312,13 @@ def _check_forward(r):
     assert abs(r["loss"][0] - r["loss"][1]) / r["loss"][1] < 1e-2
 
 
-def test_mask_decoder_sam2_l_forward_backward(dev):
+@pytest.mark.parametrize("pe_seed", [7, 3])
+def test_mask_decoder_sam2_l_forward_backward(dev, pe_seed):
     """Well-conditioned point: every ReLU of the token-side MLPs firmly on or off and a pinned positional matrix.  Every parameter gradient that
     carries more than 1e-5 of the total gradient norm is within the FLAT 3e-2 of fp32 autograd (measured: <= 0.9e-2 on 6 of 8 positional-matrix seeds,
     profiles/r03_decoder_grad_by_seed.log); the few below that share are analytically-near-zero products (image-to-token attention scores over 9 tokens) and are
     bounded in absolute size."""
-    r = _mask_decoder_case(dev, firm_relu=True, pe_seed=7)
+    r = _mask_decoder_case(dev, firm_relu=True, pe_seed=pe_seed)     # two of the six well-conditioned positional-matrix seeds (ADVICE r3: not one pinned seed)
     _check_forward(r)
     errs, norms = r["errs"], r["norms"]
     tot = sum(v * v for v in norms.values()) ** 0.5
@@ -340,7 +341,7 @@ def test_mask_decoder_sam2_l_backward_ill_conditioned_point(dev):
     tot = sum(v * v for v in norms.values()) ** 0.5
     sig = [n for n in errs if norms[n] > 1e-5 * tot]
     assert max(emu[n] for n in sig) > 3e-2, "bf16 storage alone is within 3e-2 here: tighten this test to the flat bound"
-    bad = {n: (round(errs[n], 4), round(emu[n], 4)) for n in sig if errs[n] > min(0.15, 1.5 * emu[n] + 1e-2)}
+    bad = {n: (round(errs[n], 4), round(emu[n], 4)) for n in sig if errs[n] > min(0.15, 1.2 * emu[n] + 1e-2)}     # (1.5 x until round 4; measured ratio <= 1.01 on the large tensors)
     assert not bad, bad
 
 
