@@ -74,6 +74,15 @@ int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* r
 int rga3_gemm_rms_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                        int64_t ldw, int64_t ldc, int64_t ldr, int act, int tile, void* workspace, int64_t workspace_bytes, const uint64_t* row_sumsq_in,
                        int64_t norm_width, float eps, uint64_t* row_sumsq_out, void* stream);
+/* Concatenated operands (round 4): LoRA's low-rank products folded into the frozen products of a decoder layer (PEFT LoRA layer, reference train_joint.py:193-232,
+ * run_torchrun.sh:30-31; y = W x + s B A dropout(x)).
+ *   K side (A2 [M, K2], W2 [N, K2]):  C [M, N] = [A | A2] . [W | W2]^T (+ bias)      forward:  qkv = h W^T + [t_q | t_v] [B_q 0; 0 0; 0 B_v]^T as ONE product
+ *   N side (Wn [N2, K], Cn [M, N2]):  also Cn = A . Wn^T from the same launch        backward: [dh | dt_q | dt_v] = dqkv [W | sB_q | sB_v]
+ * bf16, no activation; K, K2 multiples of 64; with an N side N must be a multiple of the tile width.  tile: -1 / 12 (128 x 128), 3 / 6 (128 x 256), 13 (64 x 64); K side
+ * only: also 4 (128 x 320), 5 (128 x 192).  Single-phase kernels (no workspace). */
+int rga3_gemm_cat_bf16(const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+                       const void* A2, const void* W2, int64_t K2, int64_t lda2, int64_t ldw2, const void* Wn, void* Cn, int64_t N2, int64_t ldwn, int64_t ldcn,
+                       int tile, void* stream);
 
 /* bytes of caller workspace tiles 22 / 25 want on the current device (4 KiB of flags + 256 KiB per CU; 0 on error).  The workspace is
  * zeroed ONCE by the caller and then kept for the calls of one stream (the kernels leave the flag words zero again); without it (NULL / too

@@ -50,6 +50,17 @@ struct GemmArgs {
     float rs_in_scale = 0.f;                     // 2^-20 / (width of the normalised rows)
     float rs_eps = 0.f;
     unsigned long long* rs_out = nullptr;        // [M]: the output rows' sums of squares (of the bf16 values written) are ADDED here; null = off
+    // Concatenated operands (rga3_gemm_cat_bf16, single-phase kernels only): LoRA's low-rank products folded into the frozen ones.
+    //   K side:  C = [A | A2] . [W | W2]^T   -- K-tiles [0, K / 64) come from (A, W), the next K2 / 64 from (A2, W2)          (y = x W^T + t (sB)^T in one product)
+    //   N side:  tile columns at or beyond N belong to a SECOND weight / output pair: Cn [M, N2] = A . Wn^T (no bias, residual or K side there)   ([dx | dt] = dy [W | sB])
+    const unsigned short* A2 = nullptr;
+    const unsigned short* W2 = nullptr;
+    long lda2 = 0, ldw2 = 0;
+    int K2 = 0;
+    const unsigned short* Wn = nullptr;
+    void* Cn = nullptr;
+    long ldwn = 0, ldcn = 0;
+    int N2 = 0;
 };
 
 constexpr float kRowSumFix = 1048576.0f;   // 2^20
@@ -488,7 +499,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     const unsigned gsz = min((unsigned)p.ntm - first_m, GROUP_M);
     const unsigned tm = first_m + (t % per_group) % gsz;
     const unsigned tn = (t % per_group) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM;
+    int n0 = tn * BN;
+    if (p.Cn && n0 >= p.N) {   // N-side concatenation: this tile column belongs to the second weight / output pair (workgroup-uniform)
+        n0 -= p.N;
+        p.W = p.Wn; p.ldw = p.ldwn; p.C = p.Cn; p.ldc = p.ldcn; p.N = p.N2;
+        p.bias = nullptr; p.res = nullptr; p.colscale = nullptr; p.A2 = nullptr; p.rs_in = nullptr; p.rs_out = nullptr;
+    }
 
     // ---- per-lane global source offsets (32-bit, in elements) for this wave's staging pieces (source-side swizzle)
     unsigned aoff[APW], boff[BPW];
@@ -507,10 +524,35 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         boff[i] = (unsigned)((long)gr * p.ldw + ch * 8);
     }
 
+    // K-side concatenation: offsets into the second operand pair (K and K2 multiples of 64 there: no partial tile)
+    unsigned aoff2[APW], boff2[BPW];
+    const int nk1 = (p.K + BK - 1) / BK;
+    if (p.A2) {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int r = (wid + i * NW) * 8 + (lane >> 3);
+            aoff2[i] = (unsigned)((long)min(m0 + r, p.M - 1) * p.lda2 + ((lane & 7) ^ ((r >> 1) & 7)) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int r = (wid + i * NW) * 8 + (lane >> 3);
+            boff2[i] = (unsigned)((long)min(n0 + r, p.N - 1) * p.ldw2 + ((lane & 7) ^ ((r >> 1) & 7)) * 8);
+        }
+    }
     const bool ktail = (p.K % BK) != 0;  // K is a multiple of 8: the last tile may be partial
     auto stage_tile = [&](int s, int kt, bool last) {
         char* sa = smem + s * STAGE;
         char* sb = sa + BM * ROWB;
+        if (p.A2 && kt >= nk1) {   // (workgroup-uniform) K-tiles of the second operand pair
+            const long k2 = (long)(kt - nk1) * BK;
+#pragma unroll
+            for (int i = 0; i < APW; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(p.A2 + aoff2[i] + k2), (lds_void*)(sa + (wid + i * NW) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < BPW; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(p.W2 + boff2[i] + k2), (lds_void*)(sb + (wid + i * NW) * 1024), 16, 0, 0);
+            return;
+        }
         const long koff = (long)kt * BK;
         if (last && ktail) {
             // chunks at or beyond K read 16 zero bytes instead (per-lane source address; LDS image unchanged)
@@ -549,7 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK + (p.A2 ? p.K2 / BK : 0);
     static_assert(PIPE == 0 || PIPE == 3, "PIPE: 0 = two LDS stages (one K-tile of prefetch), 3 = three stages (two K-tiles in flight)");
     // K split (tile 14, skinny products: M x 128 over K = 3584 is 66 tiles of 64 x 64): slice blockIdx.y takes ksl K-tiles and writes an f32 slab
     const int kt0 = p.ksl ? (int)blockIdx.y * p.ksl : 0;
@@ -1436,7 +1478,7 @@ template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE, bool 
 static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, BM);
-    a.ntn = (int)cdiv(a.N, BN);
+    a.ntn = (int)cdiv(a.N, BN) + (a.Cn ? (int)cdiv(a.N2, BN) : 0);   // N-side concatenation: the second pair's tile columns follow (N % BN == 0, checked by the entry point)
     a.group_m = pick_group_m(a.ntm, BM);
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int LDS = (PIPE == 3 ? 3 : 2) * STAGE;
@@ -2112,6 +2154,45 @@ extern "C" int rga3_gemm_rms_bf16(const void* A, const void* W, const void* bias
     RGA3_CHECK_ARG(M > 16, "gemm_rms: M %ld (token-row products take the unfused route)", (long)M);
     return gemm_bf16_impl(A, W, bias, residual, nullptr, C, M, N, K, lda, ldw, ldc, ldr, act, RGA3_BF16, tile, workspace, workspace_bytes,
                           (const unsigned long long*)row_sumsq_in, norm_width, eps, (unsigned long long*)row_sumsq_out, stream);
+}
+
+// Concatenated operands on the single-phase kernels (LoRA's low-rank products folded into the frozen products of a decoder layer; PEFT LoRA layer under reference
+// train_joint.py:193-232):
+//   K side (A2, W2, K2 != 0):  C [M, N] = [A | A2] . [W | W2]^T (+ bias): y = x W^T + t B^T as ONE product over K + K2 (K, K2 multiples of 64)
+//   N side (Wn, Cn, N2 != 0):  additionally Cn [M, N2] = A . Wn^T from the same launch (tile columns behind N; N must be a multiple of the tile width): [dx | dt] = dy [W | sB]
+// bf16 in / out, no activation, optional bias on the first pair.  tile: -1 / 12 (128 x 128), 3 (128 x 256), 6 (128 x 256, three stages), 13 (64 x 64); K side only: also 4, 5.
+extern "C" int rga3_gemm_cat_bf16(const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+                                  const void* A2, const void* W2, int64_t K2, int64_t lda2, int64_t ldw2, const void* Wn, void* Cn, int64_t N2, int64_t ldwn,
+                                  int64_t ldcn, int tile, void* stream) {
+    RGA3_CHECK_ARG(A && W && C && M > 16 && N > 0 && K > 0, "gemm_cat: bad args");
+    RGA3_CHECK_ARG((A2 != nullptr) == (W2 != nullptr) && (A2 != nullptr) == (K2 > 0), "gemm_cat: the K side takes A2, W2 and K2 together");
+    RGA3_CHECK_ARG((Wn != nullptr) == (Cn != nullptr) && (Wn != nullptr) == (N2 > 0), "gemm_cat: the N side takes Wn, Cn and N2 together");
+    RGA3_CHECK_ARG(A2 || Wn, "gemm_cat: nothing concatenated (use rga3_gemm_bf16)");
+    RGA3_CHECK_ARG(K % 64 == 0 && K2 % 64 == 0, "gemm_cat: K = %ld and K2 = %ld must be multiples of 64", (long)K, (long)K2);
+    RGA3_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0 && ldwn % 8 == 0 && N % 8 == 0 && N2 % 8 == 0, "gemm_cat: strides / widths must be multiples of 8 elements");
+    RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)A2 | (uintptr_t)W2 | (uintptr_t)Wn | (uintptr_t)Cn) & 15) == 0, "gemm_cat: pointer alignment");
+    RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32) && M * (lda2 ? lda2 : 1) < (1LL << 32) && N * (ldw2 ? ldw2 : 1) < (1LL << 32) && N2 * (ldwn ? ldwn : 1) < (1LL << 32),
+                   "gemm_cat: operands must be < 2^32 elements");
+    const int bn = (tile == 3 || tile == 6) ? 256 : (tile == 4) ? 320 : (tile == 5) ? 192 : (tile == 13) ? 64 : 128;
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 6 || tile == 12 || tile == 13 || (!Wn && (tile == 4 || tile == 5)), "gemm_cat: tile %d", tile);
+    RGA3_CHECK_ARG(!Wn || N % bn == 0, "gemm_cat: with an N side, N = %ld must be a multiple of the tile width %d", (long)N, bn);
+    GemmArgs a;
+    a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.C = C;
+    a.bias = (const unsigned short*)bias; a.res = nullptr; a.colscale = nullptr;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = 0;
+    a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
+    a.A2 = (const unsigned short*)A2; a.W2 = (const unsigned short*)W2; a.K2 = (int)K2; a.lda2 = lda2; a.ldw2 = ldw2;
+    a.Wn = (const unsigned short*)Wn; a.Cn = Cn; a.N2 = (int)N2; a.ldwn = ldwn; a.ldcn = ldcn;
+    hipStream_t st = (hipStream_t)stream;
+    switch (tile) {
+        case 3: return launch_cfg<128, 256, 2, 4, ACT_NONE, false, 0>(a, st);
+        case 4: return launch_cfg<128, 320, 2, 4, ACT_NONE, false, 0>(a, st);
+        case 5: return launch_cfg<128, 192, 2, 4, ACT_NONE, false, 0>(a, st);
+        case 6: return launch_cfg<128, 256, 2, 4, ACT_NONE, false, 3>(a, st);
+        case 13: return launch_cfg<64, 64, 2, 2, ACT_NONE, false, 0>(a, st);
+        default: return launch_cfg<128, 128, 2, 2, ACT_NONE, false, 0>(a, st);
+    }
 }
 
 static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,

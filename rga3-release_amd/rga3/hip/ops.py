@@ -144,6 +144,39 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     return out
 
 
+def gemm_cat(a, w, bias=None, a2=None, w2=None, wn=None, tile: int = -1):
+    """Concatenated operands (rga3_gemm_cat_bf16): out = [a | a2] @ [w | w2].T + bias  and, with wn [N2, K], out_n = a @ wn.T from the same launch.
+    a [M, K], w [N, K], a2 [M, K2], w2 [N, K2] bf16 (row strides free; K, K2 multiples of 64).  Returns out or (out, out_n)."""
+    _need_cuda(a, w, bias, a2, w2, wn)
+    assert a.dtype == w.dtype == torch.bfloat16 and a.dim() == w.dim() == 2 and a.shape[1] == w.shape[1] and a.stride(1) == w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    assert (a2 is None) == (w2 is None) and (a2 is not None or wn is not None)
+    K2 = 0
+    if a2 is not None:
+        assert a2.dtype == w2.dtype == torch.bfloat16 and a2.shape[0] == M and w2.shape[0] == N and a2.shape[1] == w2.shape[1] and a2.stride(1) == w2.stride(1) == 1
+        K2 = a2.shape[1]
+    N2 = 0
+    out_n = None
+    if wn is not None:
+        assert wn.dtype == torch.bfloat16 and wn.dim() == 2 and wn.shape[1] == K and wn.stride(1) == 1
+        N2 = wn.shape[0]
+        out_n = torch.empty((M, N2), dtype=torch.bfloat16, device=a.device)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    fn = _lib.load().rga3_gemm_cat_bf16
+
+    def run(t):
+        _lib.check(fn(a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, a.stride(0), w.stride(0), out.stride(0), _ptr(a2), _ptr(w2), K2,
+                      a2.stride(0) if a2 is not None else 0, w2.stride(0) if w2 is not None else 0, _ptr(wn), _ptr(out_n), N2, wn.stride(0) if wn is not None else 0,
+                      out_n.stride(0) if out_n is not None else 0, t, _stream()), "gemm_cat_bf16")
+
+    if tile == -1:
+        cands = tuple(t for t in ((12, 3, 6, 13) if wn is not None else (12, 3, 4, 5, 6, 13)) if wn is None or N % (256 if t in (3, 6) else 64 if t == 13 else 128) == 0)
+        tile = _tuner.pick(_tuner.key_of(M, N + N2, K + K2, "cat", BF16, bias is not None, False), run, candidates=cands)
+    run(tile)
+    return out if out_n is None else (out, out_n)
+
+
 def gemm_rows16_many(sets):
     """Up to 4 token-row products (M <= 16) in one launch (csrc/gemm_bf16.hip gemm_rows16_many_kernel).  sets: list of (a, a2 or None, weight, bias or None[, residual
     [, act]]): out_i = act((a + a2) @ weight.T + bias) (+ residual), a + a2 rounded to bf16 first.  -> list of [M, N] bf16."""

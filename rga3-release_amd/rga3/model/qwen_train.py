@@ -13,6 +13,7 @@ LoRA dA/dB products.  The LM head only evaluates the rows that carry a label (SU
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -168,6 +169,64 @@ def lora_refresh(layers):
     mods = [p for layer in layers for p in (layer.self_attn.q_proj, layer.self_attn.v_proj) if isinstance(p, LoRALinear)]
     if mods and any((e := _lora_cache.get(id(m))) is None or e[0] != _lora_versions(m) for m in (mods[0], mods[-1])):
         _lora_build(mods)
+    ats = [layer.self_attn for layer in layers if _lora_cat_ok(layer.self_attn)]
+    if ats and len({(a.num_heads, a.num_kv, a.head_dim, a.q_proj.lora_A["default"].weight.shape[0], float(a.q_proj.scaling), float(a.v_proj.scaling)) for a in ats}) == 1:
+        if any((e := _lora_cat.get(id(a))) is None or e[0] != _lora_versions(a.q_proj) + _lora_versions(a.v_proj) for a in (ats[0], ats[-1])):
+            _lora_cat_build(ats)
+
+
+# ---- LoRA's B-side products folded into the frozen q|k|v product and its transpose (rga3_gemm_cat_bf16):
+#   forward   qkv = h W^T + [t_q | t_v] W2^T,   W2 [(Hq + 2 Hk) D, 2 r] = [B_q 0; 0 0; 0 B_v]            (two skinny launches per layer less, one rounding less)
+#   backward  [dh | dt_q | dt_v] = dqkv [W | Wn^T],   Wn [2 r, (Hq + 2 Hk) D] = [(s B_q)^T 0 0; 0 0 (s B_v)^T]   (two more)
+# The block matrices of ALL layers are refreshed with the other derived operands, once per optimizer step (zeros stay; only the B blocks are rewritten).
+_LORA_FOLD = os.environ.get("RGA3_LORA_FOLD", "1") != "0"
+_lora_cat = {}     # id(attention module) -> (key, W2, Wn)
+_lora_cat_store = {}   # (n layers, Nqkv, r, dtype, device) -> (W2_all, Wn_all)
+
+
+def set_lora_fold(on: bool):
+    """A/B switch (tests, bench): fold LoRA's B-side products into the frozen q|k|v products."""
+    global _LORA_FOLD
+    _LORA_FOLD = bool(on)
+
+
+def _lora_cat_ok(at) -> bool:
+    q, v = at.q_proj, at.v_proj
+    if not (_LORA_FOLD and isinstance(q, LoRALinear) and isinstance(v, LoRALinear)) or isinstance(at.k_proj, LoRALinear):
+        return False
+    rq, rv = q.lora_A["default"].weight.shape[0], v.lora_A["default"].weight.shape[0]
+    return rq == rv and (2 * rq) % 64 == 0 and q.lora_A["default"].weight.dtype == torch.bfloat16 and q.weight.shape[1] % 64 == 0
+
+
+def _lora_cat_build(ats):
+    with torch.no_grad():
+        at0 = ats[0]
+        Hq, Hk, D = at0.num_heads, at0.num_kv, at0.head_dim
+        r = at0.q_proj.lora_A["default"].weight.shape[0]
+        Nq, Nall = Hq * D, (Hq + 2 * Hk) * D
+        Bq = torch.stack([a.q_proj.lora_B["default"].weight.detach() for a in ats])          # [L, Hq D, r]
+        Bv = torch.stack([a.v_proj.lora_B["default"].weight.detach() for a in ats])          # [L, Hk D, r]
+        key = (len(ats), Nall, r, Bq.dtype, Bq.device)
+        st = _lora_cat_store.get(key)
+        if st is None:
+            st = (torch.zeros((len(ats), Nall, 2 * r), dtype=Bq.dtype, device=Bq.device), torch.zeros((len(ats), 2 * r, Nall), dtype=Bq.dtype, device=Bq.device))
+            _lora_cat_store[key] = st
+        W2, Wn = st
+        W2[:, :Nq, :r] = Bq
+        W2[:, Nq + Hk * D:, r:] = Bv
+        Wn[:, :r, :Nq] = (Bq * float(at0.q_proj.scaling)).transpose(1, 2)
+        Wn[:, r:, Nq + Hk * D:] = (Bv * float(at0.v_proj.scaling)).transpose(1, 2)
+        for i, a in enumerate(ats):
+            _lora_cat[id(a)] = (_lora_versions(a.q_proj) + _lora_versions(a.v_proj), W2[i], Wn[i])
+
+
+def _lora_cat_ops(at):
+    """(W2, Wn) of one attention module, current with its LoRA parameters."""
+    e = _lora_cat.get(id(at))
+    if e is None or e[0] != _lora_versions(at.q_proj) + _lora_versions(at.v_proj):
+        _lora_cat_build([at])
+        e = _lora_cat[id(at)]
+    return e[1], e[2]
 
 
 def _lora_ops(lin):
@@ -213,15 +272,25 @@ def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
     inputs of lora_A, which the backward needs for dA."""
     Hq, Hk, D = at.num_heads, at.num_kv, at.head_dim
     wqkv, bqkv = at._packed()
-    if _fp8["on"] and h1.shape[1] % 128 == 0:
-        qkv2 = _fgemm(h1, at, "wqkv", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: wqkv, bias=bqkv)
-    else:
-        qkv2 = ops.gemm(h1, wqkv, bqkv)
     lq, lv = _lora_parts(at.q_proj), _lora_parts(at.v_proj)
     pq, pv = _lora_dropout(at)
     if seeds is None and (pq > 0.0 or pv > 0.0):
         lid = getattr(at, "layer_idx", 0) or 0
         seeds = (next_dropout_seed(lid, 0), next_dropout_seed(lid, 1, advance=False))
+    if not _fp8["on"] and h1.shape[0] > 16 and _lora_cat_ok(at):
+        # B side folded into the frozen product: t_q, t_v first (column halves of one buffer), then ONE product over K = H + 2 r
+        r = lq[0].shape[0]
+        hq = ops.dropout(h1, pq, seeds[0]) if pq > 0.0 else h1
+        hv = ops.dropout(h1, pv, seeds[1]) if pv > 0.0 else h1
+        tt = torch.empty((h1.shape[0], 2 * r), dtype=h1.dtype, device=h1.device)
+        tq = ops.gemm(hq, _lora_ops(at.q_proj)[0], out=tt[:, :r])          # t_s = drop(h) (sA)^T
+        tv = ops.gemm(hv, _lora_ops(at.v_proj)[0], out=tt[:, r:])
+        qkv2 = ops.gemm_cat(h1, wqkv, bqkv, a2=tt, w2=_lora_cat_ops(at)[0])
+        return (qkv2, tq, tv, hq, hv) if want_inputs else (qkv2, tq, tv)
+    if _fp8["on"] and h1.shape[1] % 128 == 0:
+        qkv2 = _fgemm(h1, at, "wqkv", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: wqkv, bias=bqkv)
+    else:
+        qkv2 = ops.gemm(h1, wqkv, bqkv)
     tq = tv = None
     hq = hv = h1
     if lq is not None:
@@ -386,7 +455,13 @@ class DecoderLayerFn(torch.autograd.Function):
                                 dv=dqkv[:, Hq + Hk:])
             ops.rope_(dqkv, cos, _neg_table(sin), 0, Hq + Hk)   # inverse rotation (cos/sin tables are symmetric in the two halves)
             dqkv2 = dqkv.view(T, (Hq + 2 * Hk) * D)
-            dh1 = _fgemm(dqkv2, at, "wqkv_t", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: ops.transpose(wqkv))   # [T, H]
+            fold = (not _fp8["on"]) and T > 16 and _lora_cat_ok(at)
+            dtt = None
+            if fold:    # [dh1 | dt_q | dt_v] = dqkv [W | sB_q | sB_v] from one launch
+                wqkv_t = _wt(at, "wqkv_t", at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, build=lambda: ops.transpose(wqkv))
+                dh1, dtt = ops.gemm_cat(dqkv2, wqkv_t, wn=_lora_cat_ops(at)[1])
+            else:
+                dh1 = _fgemm(dqkv2, at, "wqkv_t", (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight), lambda: ops.transpose(wqkv))   # [T, H]
             grads = [None, None, None, None]
             if lq is not None or lv is not None:
                 tn_pairs, tn_slots = [], []      # the layer's weight-gradient products (dB = dsl^T t_s, dA = dt^T dropout(h1) per LoRA module): ONE grouped launch below
@@ -396,7 +471,11 @@ class DecoderLayerFn(torch.autograd.Function):
                         continue
                     _, At, Bts = _lora_ops(lin)                                         # A^T [H, r], (sB)^T [r, out]: once per step for all layers
                     dsl = dqkv2[:, cols[0]:cols[1]]                                    # [T, out]
-                    dt = ops.gemm(dsl, Bts)                                             # [T, r] = dsl (sB)
+                    if dtt is not None:
+                        rr = dtt.shape[1] // 2
+                        dt = dtt[:, :rr] if slot == 0 else dtt[:, rr:]                  # [T, r] = dsl (sB), from the folded product
+                    else:
+                        dt = ops.gemm(dsl, Bts)                                         # [T, r] = dsl (sB)
                     tn_pairs += [(dt, h1 if pdrop == 0.0 else hin), (dsl, t_)]          # dA [r, H] (lora_A saw the dropped input), dB [out, r] (t_s carries s)
                     tn_slots += [slot, slot + 1]
                     if pdrop == 0.0:

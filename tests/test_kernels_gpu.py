@@ -234,6 +234,35 @@ def test_gemm_tn_many_equals_single_products(dev):
     assert o3[0].shape == (20, H)
 
 
+@pytest.mark.parametrize("tile", [-1, 3, 6, 12, 13])
+def test_gemm_concatenated_operands(dev, tile):
+    """rga3_gemm_cat_bf16 (LoRA's low-rank products folded into the frozen products; PEFT LoRA layer, reference train_joint.py:193-232): the K side
+    [a | a2] [w | w2]^T + bias against fp32 and against the two-launch form; the N side's second output bit-identical to a plain product of the same tiling, the first
+    output untouched by it; both sides at once; on a grid of several tiles per CU."""
+    from rga3.hip import ops
+
+    T, H, Nq, r2 = 2112, 3584, 4608, 256
+    h, tt = _rand((T, H), dev, seed=1), _rand((T, r2), dev, 0.3, seed=2)
+    w, w2, b = _rand((Nq, H), dev, 0.03, seed=3), _rand((Nq, r2), dev, 0.05, seed=4), _rand((Nq,), dev, 0.3, seed=5)
+    ref = h.float().cpu() @ w.float().cpu().t() + tt.float().cpu() @ w2.float().cpu().t() + b.float().cpu()
+    out = ops.gemm_cat(h, w, b, a2=tt, w2=w2, tile=tile)
+    assert _rel_l2(out, ref) < 6e-3
+    assert torch.equal(out, ops.gemm_cat(h, w, b, a2=tt, w2=w2, tile=tile))
+    two = ops.gemm(tt, w2, residual=ops.gemm(h, w, b))                       # the form it replaces (one more bf16 rounding)
+    assert _rel_l2(out, two.float().cpu()) < 6e-3
+    # N side: dX-type product with 256 extra output columns from a second weight
+    dy = _rand((T, Nq), dev, 0.2, seed=6)
+    wt, wn = _rand((H, Nq), dev, 0.03, seed=7), _rand((r2, Nq), dev, 0.05, seed=8)
+    dx, dt = ops.gemm_cat(dy, wt, wn=wn, tile=tile)
+    t_plain = tile if tile != -1 else 12
+    assert torch.equal(dx, ops.gemm(dy, wt, tile=t_plain)) and torch.equal(dt, ops.gemm(dy, wn, tile=t_plain))
+    # strided second operands (column halves of one buffer) and both sides at once
+    buf = _rand((T, 2 * r2), dev, 0.3, seed=9)
+    o1, o2 = ops.gemm_cat(h, w[:H], a2=buf[:, r2:], w2=w2[:H], wn=wn[:, :H].contiguous(), tile=tile)
+    assert _rel_l2(o1, h.float().cpu() @ w[:H].float().cpu().t() + buf[:, r2:].float().cpu() @ w2[:H].float().cpu().t()) < 6e-3
+    assert _rel_l2(o2, h.float().cpu() @ wn[:, :H].float().cpu().t()) < 6e-3
+
+
 def _all_bf16_finite(dev):
     bits = torch.arange(0, 65536, dtype=torch.int32)
     bits = bits[(bits & 0x7f80) != 0x7f80]                       # no Inf / NaN
