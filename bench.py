@@ -181,7 +181,7 @@ class GemmTimer:
         self._real = {}
         self.by_kind = {}     # "bf16" / "fp8" -> [events, flops]: the two families are priced against different peaks
 
-    def _wrap(self, name, shape_of, w_index=1):
+    def _wrap(self, name, shape_of, w_index=1, takes_kw=False):
         real = getattr(self.ops, name)
         self._real[name] = real
         kind = "fp8" if name == "gemm_fp8" else "bf16"
@@ -192,12 +192,15 @@ class GemmTimer:
             r = real(*a, **k)
             e.record()
             self.ev.append((s, e))
-            M, N, K = shape_of(a)
-            self.flops += 2.0 * M * N * K
+            sh = shape_of(a, k) if takes_kw else shape_of(a)
+            fl = float(sh) if not isinstance(sh, tuple) else 2.0 * sh[0] * sh[1] * sh[2]
+            self.flops += fl
             slot = self.by_kind.setdefault(kind, [[], 0.0])
             slot[0].append((s, e))
-            slot[1] += 2.0 * M * N * K
-            self.bytes += a[0].numel() * a[0].element_size() + a[w_index].numel() * a[w_index].element_size() + r.numel() * r.element_size()
+            slot[1] += fl
+            outs = r if isinstance(r, (tuple, list)) else (r,)
+            ins = [t for t in (a[0], a[w_index]) if torch.is_tensor(t)]
+            self.bytes += sum(t.numel() * t.element_size() for t in ins) + sum(t.numel() * t.element_size() for t in outs)
             return r
         setattr(self.ops, name, timed)
 
@@ -206,6 +209,11 @@ class GemmTimer:
         self._wrap("gemm_tn", lambda a: (a[0].shape[1], a[1].shape[1], a[0].shape[0]))
         self._wrap("gemm_fp8", lambda a: (a[0].shape[0], a[2].shape[0], a[0].shape[1]))
         self._wrap("gemm_ln", lambda a: (a[0].shape[0], a[2].shape[0], a[0].shape[1]), w_index=2)   # LayerNorm-folded products of the Hiera trunk
+        self._wrap("gemm_swiglu_pre", lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]))
+        # concatenated operands: [a | a2] [w | w2]^T and a wn^T from one launch (flop count of both sides)
+        self._wrap("gemm_cat", lambda a, k: 2.0 * a[0].shape[0] * (a[1].shape[0] * (a[0].shape[1] + (k["a2"].shape[1] if k.get("a2") is not None else 0)) +
+                                                                    (k["wn"].shape[0] * a[0].shape[1] if k.get("wn") is not None else 0)), takes_kw=True)
+        self._wrap("gemm_tn_many", lambda a: sum(2.0 * x.shape[1] * y.shape[1] * x.shape[0] for x, y in a[0]), w_index=0)
         return self
 
     def __exit__(self, *exc):

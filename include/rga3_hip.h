@@ -74,6 +74,11 @@ int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* r
 int rga3_gemm_rms_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                        int64_t ldw, int64_t ldc, int64_t ldr, int act, int tile, void* workspace, int64_t workspace_bytes, const uint64_t* row_sumsq_in,
                        int64_t norm_width, float eps, uint64_t* row_sumsq_out, void* stream);
+/* RGA3_ACT_SWIGLU product that also stores its pre-activations (round 4; training forward of the decoder MLP -- HF Qwen2MLP under autograd, reference
+ * train_joint.py:534): C [M, N / 2] = silu(gate) * up, pre [M, N] (row stride ldpre) = the interleaved gate | up linear outputs rounded to bf16, which the backward
+ * of the activation reads (rga3_swiglu_bwd).  Replaces rga3_gemm_bf16 (plain) + rga3_swiglu_fwd. */
+int rga3_gemm_swiglu_pre_bf16(const void* A, const void* W, const void* bias, void* C, void* pre, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                              int64_t ldc, int64_t ldpre, int tile, void* workspace, int64_t workspace_bytes, void* stream);
 /* Concatenated operands (round 4): LoRA's low-rank products folded into the frozen products of a decoder layer (PEFT LoRA layer, reference train_joint.py:193-232,
  * run_torchrun.sh:30-31; y = W x + s B A dropout(x)).
  *   K side (A2 [M, K2], W2 [N, K2]):  C [M, N] = [A | A2] . [W | W2]^T (+ bias)      forward:  qkv = h W^T + [t_q | t_v] [B_q 0; 0 0; 0 B_v]^T as ONE product

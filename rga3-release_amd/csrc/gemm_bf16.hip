@@ -57,6 +57,8 @@ struct GemmArgs {
     const unsigned short* W2 = nullptr;
     long lda2 = 0, ldw2 = 0;
     int K2 = 0;
+    unsigned short* pre = nullptr;   // SwiGLU epilogue (rga3_gemm_swiglu_pre_bf16): also store the bf16 gate | up pre-activations [M, N] (interleaved 16-column blocks, row stride ldpre)
+    long ldpre = 0;
     const unsigned short* Wn = nullptr;
     void* Cn = nullptr;
     long ldwn = 0, ldcn = 0;
@@ -317,10 +319,26 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 // packed weight layout: n-tile 2*jo = gate columns, 2*jo+1 = up columns of the same 16 outputs.  The reference rounds the gate / up linear outputs
                 // to bf16 before the activation (bf16 nn.Linear), and silu(gate) before the product
                 const f32x4 &gq = x[2 * jo], &uq = x[2 * jo + 1];
-                const f32x2 s01 = act_tab2(pack_bf2(gq[0], gq[1]), tb), s23 = act_tab2(pack_bf2(gq[2], gq[3]), tb);
-                const f32x2 v01 = widen_bf2(pack_bf2(s01[0], s01[1])) * widen_bf2(pack_bf2(uq[0], uq[1]));
-                const f32x2 v23 = widen_bf2(pack_bf2(s23[0], s23[1])) * widen_bf2(pack_bf2(uq[2], uq[3]));
+                const unsigned pg0 = pack_bf2(gq[0], gq[1]), pg1 = pack_bf2(gq[2], gq[3]), pu0 = pack_bf2(uq[0], uq[1]), pu1 = pack_bf2(uq[2], uq[3]);
+                const f32x2 s01 = act_tab2(pg0, tb), s23 = act_tab2(pg1, tb);
+                const f32x2 v01 = widen_bf2(pack_bf2(s01[0], s01[1])) * widen_bf2(pu0);
+                const f32x2 v23 = widen_bf2(pack_bf2(s23[0], s23[1])) * widen_bf2(pu1);
                 v[jo] = f32x4{v01[0], v01[1], v23[0], v23[1]};
+                if (p.pre) {   // training: the backward needs the rounded pre-activations (autograd of silu(gate) * up); same 16-byte row pieces as the output stores
+                    const auto q0 = __builtin_amdgcn_permlane16_swap(pg0, pu0, false, false);
+                    const auto q1 = __builtin_amdgcn_permlane16_swap(pg1, pu1, false, false);
+                    const u32x4 pv = {(unsigned)q0[0], (unsigned)q1[0], (unsigned)q0[1], (unsigned)q1[1]};
+                    const int prow = m0 + wm * WTM + i * 16 + (lane & 15);
+                    const int pcol = n0 + wn * WTN + ((g & 1) ? (2 * jo + 1) * 16 + 4 * (g - 1) : 2 * jo * 16 + 4 * g);
+                    if (prow < p.M && pcol < p.N) {
+                        unsigned short* dp = p.pre + (long)prow * p.ldpre + pcol;
+                        if (pcol + 8 <= p.N && (p.ldpre & 7) == 0) {
+                            *(u32x4*)dp = pv;
+                        } else {
+                            for (int e = 0; e < 8 && pcol + e < p.N; ++e) dp[e] = (unsigned short)(pv[e >> 1] >> (16 * (e & 1)));
+                        }
+                    }
+                }
             } else if constexpr (ACT == ACT_GELU) {
                 const f32x2 y01 = act_tab2(pack_bf2(x[jo][0], x[jo][1]), tb), y23 = act_tab2(pack_bf2(x[jo][2], x[jo][3]), tb);
                 v[jo] = f32x4{y01[0], y01[1], y23[0], y23[1]};
@@ -2130,7 +2148,7 @@ extern "C" int64_t rga3_gemm_timeout_counter_offset(void) {
 static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                           int act, int out_dtype, int tile, void* workspace, int64_t workspace_bytes, const unsigned long long* rs_in, int64_t rs_width, float rs_eps,
-                          unsigned long long* rs_out, void* stream);
+                          unsigned long long* rs_out, void* stream, void* pre = nullptr, int64_t ldpre = 0);
 
 extern "C" int rga3_gemm_bf16(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
                               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
@@ -2154,6 +2172,16 @@ extern "C" int rga3_gemm_rms_bf16(const void* A, const void* W, const void* bias
     RGA3_CHECK_ARG(M > 16, "gemm_rms: M %ld (token-row products take the unfused route)", (long)M);
     return gemm_bf16_impl(A, W, bias, residual, nullptr, C, M, N, K, lda, ldw, ldc, ldr, act, RGA3_BF16, tile, workspace, workspace_bytes,
                           (const unsigned long long*)row_sumsq_in, norm_width, eps, (unsigned long long*)row_sumsq_out, stream);
+}
+
+// SwiGLU product that ALSO stores its bf16 pre-activations (training forward of the decoder MLP: the backward of silu(gate) * up needs gate and up; HF Qwen2MLP,
+// autograd under reference train_joint.py:534): C [M, N / 2] = silu(gate) * up as rga3_gemm_bf16 with RGA3_ACT_SWIGLU, pre [M, N] = the interleaved gate | up values
+// rounded to bf16 (what a plain rga3_gemm_bf16 on the same packed weight writes) -- the stand-alone SwiGLU launch (read 2 x, write 1 x the widest activation) disappears.
+extern "C" int rga3_gemm_swiglu_pre_bf16(const void* A, const void* W, const void* bias, void* C, void* pre, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                         int64_t ldc, int64_t ldpre, int tile, void* workspace, int64_t workspace_bytes, void* stream) {
+    RGA3_CHECK_ARG(pre, "gemm_swiglu_pre: null pre-activation output");
+    return gemm_bf16_impl(A, W, bias, nullptr, nullptr, C, M, N, K, lda, ldw, ldc, 0, ACT_SWIGLU, RGA3_BF16, tile, workspace, workspace_bytes, nullptr, 0, 0.f, nullptr, stream, pre,
+                          ldpre);
 }
 
 // Concatenated operands on the single-phase kernels (LoRA's low-rank products folded into the frozen products of a decoder layer; PEFT LoRA layer under reference
@@ -2198,8 +2226,9 @@ extern "C" int rga3_gemm_cat_bf16(const void* A, const void* W, const void* bias
 static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const void* residual, const void* colscale, void* C,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr,
                           int act, int out_dtype, int tile, void* workspace, int64_t workspace_bytes, const unsigned long long* rs_in, int64_t rs_width, float rs_eps,
-                          unsigned long long* rs_out, void* stream) {
+                          unsigned long long* rs_out, void* stream, void* pre, int64_t ldpre) {
     RGA3_CHECK_ARG(A && W && C, "gemm: null pointer");
+    RGA3_CHECK_ARG(!pre || (act == ACT_SWIGLU && M > 4 && tile != 40 && tile != 41 && (((uintptr_t)pre) & 15) == 0 && ldpre >= N), "gemm: the pre-activation output goes with the SwiGLU tile epilogues (M > 4)");
     RGA3_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     RGA3_CHECK_ARG(K % 8 == 0, "gemm: K=%ld must be a multiple of 8 (16-byte staging chunks)", (long)K);
     RGA3_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
@@ -2221,6 +2250,7 @@ static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const 
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.ws = workspace; a.ws_bytes = workspace_bytes; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
     a.rs_in = rs_in; a.rs_in_scale = rs_in ? 1.0f / (kRowSumFix * (float)rs_width) : 0.f; a.rs_eps = rs_eps; a.rs_out = rs_out;
+    a.pre = (unsigned short*)pre; a.ldpre = ldpre;
     hipStream_t st = (hipStream_t)stream;
     RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
     const bool rows16_ok = M <= 16 && !colscale && out_dtype == RGA3_BF16 && act != ACT_SWIGLU;

@@ -23,6 +23,7 @@ SIGNATURES = {
     "rga3_gemm_workspace_bytes": [],
     "rga3_gemm_tn_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _p, _i64, _p, _p],
     "rga3_gemm_tn_many": [_p, _p, _i, _p, _i64, _p],
+    "rga3_gemm_swiglu_pre_bf16": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _p, _i64, _p],
     "rga3_gemm_cat_bf16": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _i, _p],
     "rga3_attn_varlen_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64,
                              _i64, _i64, _f, _i, _i, _p, _i64, _i, _i, _i, _p],

@@ -144,6 +144,29 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = 
     return out
 
 
+def gemm_swiglu_pre(a, w, bias=None, tile: int = -1):
+    """(silu(gate) * up [M, N / 2], pre-activations [M, N]) of a @ w.T + bias on the gate | up pack (16-row blocks interleaved) in ONE launch
+    (rga3_gemm_swiglu_pre_bf16): what gemm(a, w, bias) followed by swiglu_fwd produces, without writing and re-reading the pre-activations in between."""
+    _need_cuda(a, w, bias)
+    assert a.dtype == w.dtype == torch.bfloat16 and a.dim() == w.dim() == 2 and a.shape[1] == w.shape[1] and a.stride(1) == w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    assert N % 32 == 0 and M > 4
+    out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=a.device)
+    pre = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    ws = gemm_workspace(a.device)
+    fn = _lib.load().rga3_gemm_swiglu_pre_bf16
+
+    def run(t):
+        _lib.check(fn(a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), pre.data_ptr(), M, N, K, a.stride(0), w.stride(0), out.stride(0), pre.stride(0), t,
+                      ws.data_ptr(), ws.numel(), _stream()), "gemm_swiglu_pre_bf16")
+
+    if tile == -1 and M * N * K >= (1 << 24):
+        tile = _tuner.pick(_tuner.key_of(M, N, K, "swiglu+pre", BF16, bias is not None, False), run)
+    run(tile)
+    return out, pre
+
+
 def gemm_cat(a, w, bias=None, a2=None, w2=None, wn=None, tile: int = -1):
     """Concatenated operands (rga3_gemm_cat_bf16): out = [a | a2] @ [w | w2].T + bias  and, with wn [N2, K], out_n = a @ wn.T from the same launch.
     a [M, K], w [N, K], a2 [M, K2], w2 [N, K2] bf16 (row strides free; K, K2 multiples of 64).  Returns out or (out, out_n)."""

@@ -180,6 +180,7 @@ def lora_refresh(layers):
 #   backward  [dh | dt_q | dt_v] = dqkv [W | Wn^T],   Wn [2 r, (Hq + 2 Hk) D] = [(s B_q)^T 0 0; 0 0 (s B_v)^T]   (two more)
 # The block matrices of ALL layers are refreshed with the other derived operands, once per optimizer step (zeros stay; only the B blocks are rewritten).
 _LORA_FOLD = os.environ.get("RGA3_LORA_FOLD", "1") != "0"
+_SWIGLU_PRE = os.environ.get("RGA3_SWIGLU_PRE", "1") != "0"     # training forward: SwiGLU inside the gate | up product, pre-activations stored by the same launch
 _lora_cat = {}     # id(attention module) -> (key, W2, Wn)
 _lora_cat_store = {}   # (n layers, Nqkv, r, dtype, device) -> (W2_all, Wn_all)
 
@@ -361,8 +362,13 @@ def _layer_forward_store(layer, x, cos, sin, cu, max_len, seeds):
     x1 = _fgemm(att.view(T, Hq * D), at, "wo", (at.o_proj.weight,), lambda: at.o_proj.weight.detach(), residual=x)
     h2 = ops.rmsnorm(x1, w2.weight, w2.variance_epsilon)
     wgu, bgu, wd = mlp._packed()
-    gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)
-    y = _down_from_gu(mlp, gu, wd, x1)
+    if not _fp8["on"] and _SWIGLU_PRE and T > 4:
+        # the gate | up product applies SwiGLU in its epilogue AND leaves the pre-activations the backward needs: no stand-alone SwiGLU launch
+        a_, gu = ops.gemm_swiglu_pre(h2, wgu, bgu)
+        y = _fgemm(a_, mlp, "wd", (mlp.down_proj.weight,), lambda: wd, bias=mlp.down_proj.bias, residual=x1)
+    else:
+        gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)
+        y = _down_from_gu(mlp, gu, wd, x1)
     return y, (h1, qkv, att, lse, x1, h2, gu, tq, tv, hq_in, hv_in)
 
 

@@ -263,6 +263,23 @@ def test_gemm_concatenated_operands(dev, tile):
     assert _rel_l2(o2, h.float().cpu() @ wn[:, :H].float().cpu().t()) < 6e-3
 
 
+@pytest.mark.parametrize("tile", [-1, 3, 12, 20, 21, 22, 31])
+def test_gemm_swiglu_with_preactivations(dev, tile):
+    """rga3_gemm_swiglu_pre_bf16: the SwiGLU product that also stores the rounded gate | up pre-activations (training forward of HF Qwen2MLP): the pre-activations are
+    bit-identical to the plain product on the same packed weight, the activation output to the SwiGLU product without the second output and (up to the f32 rounding of
+    the activation) to swiglu_fwd on the pre-activations; ragged M."""
+    from rga3.hip import ops
+
+    M, N, K = 2100, 1024, 512
+    a, w, b = _rand((M, K), dev, seed=1), _rand((N, K), dev, 0.05, seed=2), _rand((N,), dev, 0.3, seed=3)
+    act, pre = ops.gemm_swiglu_pre(a, w, b, tile=tile)
+    t_plain = tile if tile != -1 else 12
+    assert torch.equal(pre, ops.gemm(a, w, b, tile=t_plain)) or _rel_l2(pre, ops.gemm(a, w, b, tile=t_plain).float().cpu()) < 1e-4      # stream-K tilings re-associate
+    assert torch.equal(act, ops.gemm(a, w, b, act="swiglu", tile=tile)) or tile == -1
+    ref = ops.swiglu_fwd(pre)
+    assert _rel_l2(act, ref.float().cpu()) < 2e-3 and float((act.float() - ref.float()).abs().max()) < 0.05
+
+
 def _all_bf16_finite(dev):
     bits = torch.arange(0, 65536, dtype=torch.int32)
     bits = bits[(bits & 0x7f80) != 0x7f80]                       # no Inf / NaN

@@ -62,21 +62,54 @@ def main():
         rec.append((("nt", a.shape[0], wf.shape[0], a.shape[1], "ln+" + act), s, e))
         return r
 
+    real_cat, real_many, real_pre = ops.gemm_cat, ops.gemm_tn_many, ops.gemm_swiglu_pre
+
+    def gemm_cat(a, w, bias=None, a2=None, w2=None, wn=None, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = real_cat(a, w, bias, a2=a2, w2=w2, wn=wn, **k)
+        e.record()
+        # one launch: [a | a2] [w | w2]^T (K + K2) and a wn^T (N2 more columns); the row reports the flop-equivalent N x K of both sides
+        K2, N2 = (a2.shape[1] if a2 is not None else 0), (wn.shape[0] if wn is not None else 0)
+        rec.append((("nt", a.shape[0], w.shape[0] + N2, a.shape[1] + K2, "cat" + ("+K%d" % K2 if K2 else "") + ("+N%d" % N2 if N2 else "")), s, e,
+                    2.0 * a.shape[0] * (w.shape[0] * (a.shape[1] + K2) + N2 * a.shape[1])))
+        return r
+
+    def gemm_tn_many(pairs, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = real_many(pairs, **k)
+        e.record()
+        rec.append((("tn", sum(x.shape[1] for x, _ in pairs), pairs[0][1].shape[1], pairs[0][0].shape[0], "x%d grouped" % len(pairs)), s, e,
+                    sum(2.0 * x.shape[1] * y.shape[1] * x.shape[0] for x, y in pairs)))
+        return r
+
+    def gemm_swiglu_pre(a, w, bias=None, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = real_pre(a, w, bias, **k)
+        e.record()
+        rec.append((("nt", a.shape[0], w.shape[0], a.shape[1], "swiglu+pre"), s, e))
+        return r
+
     ops.gemm, ops.gemm_tn, ops.gemm_ln = gemm, gemm_tn, gemm_ln
+    ops.gemm_cat, ops.gemm_tn_many, ops.gemm_swiglu_pre = gemm_cat, gemm_tn_many, gemm_swiglu_pre
     nst = 3
     try:
         for _ in range(nst):
             step()
     finally:
         ops.gemm, ops.gemm_tn, ops.gemm_ln = real_gemm, real_tn, real_ln
+        ops.gemm_cat, ops.gemm_tn_many, ops.gemm_swiglu_pre = real_cat, real_many, real_pre
     torch.cuda.synchronize()
-    agg = defaultdict(lambda: [0, 0.0])
-    for key, s, e in rec:
+    agg = defaultdict(lambda: [0, 0.0, 0.0])
+    for it in rec:
+        key, s, e = it[:3]
         agg[key][0] += 1
         agg[key][1] += s.elapsed_time(e)
+        agg[key][2] += it[3] if len(it) > 3 else 2.0 * key[1] * key[2] * key[3]
     rows = []
-    for (kind, M, N, K, epi), (c, ms) in agg.items():
-        fl = 2.0 * M * N * K * c
+    for (kind, M, N, K, epi), (c, ms, fl) in agg.items():
         rows.append({"kind": kind, "M": M, "N": N, "K": K, "epi": epi, "launches_per_step": c / nst, "ms_per_step": ms / nst, "tflops": fl / (ms * 1e-3) / 1e12})
     rows.sort(key=lambda r: -r["ms_per_step"])
     tot = sum(r["ms_per_step"] for r in rows)
