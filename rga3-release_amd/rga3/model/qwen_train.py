@@ -563,7 +563,10 @@ class NormHeadCEFn(torch.autograd.Function):
         n = ctx.n
         with torch.no_grad():
             dlogits = (dlogits.float() * gloss).to(dlogits.dtype)   # upstream gradient applied on the device ([labelled rows, V]: a few rows); no host read
-            dW = ops.gemm_tn(dlogits, hv) if lm_w.requires_grad else None    # [V, H] = dlogits^T hv
+            dW = None
+            if lm_w.requires_grad:     # [V, H] = dlogits^T hv, written straight into the reducer's bucket slice when there is one (no 1.09 GB copy afterwards)
+                from ..parallel.ddp import dense_grad_out_for
+                dW = ops.gemm_tn(dlogits, hv, out=dense_grad_out_for(lm_w))
             # dhv [n, H] = dlogits [n, V] @ lm_w [V, H] as a TN product over the vocabulary (A = dlogits^T [V, n], B = lm_w as it lies): the NT form needs
             # lm_w^T, i.e. a 1.09 GB transpose of a TRAINABLE matrix every step (0.89 ms + the skinny product); here the table is streamed once
             n8 = (n + 7) // 8 * 8

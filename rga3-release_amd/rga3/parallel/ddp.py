@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 import weakref
 from typing import Iterable, List
 
@@ -55,6 +56,23 @@ def _host_staged_collective():
 
 def sparse_sink_for(param):
     return _sparse_sinks.get(id(param))
+
+
+_dense_sinks: "weakref.WeakValueDictionary[int, GradBucketReducer]" = weakref.WeakValueDictionary()
+_DIRECT_GRAD = os.environ.get("RGA3_DIRECT_GRAD", "1") != "0"     # A/B switch
+
+
+def dense_grad_out_for(param):
+    """The bucket slice a producer may write ``param``'s gradient INTO (shaped like the parameter), or None.  The LM head's dW is 1.09 GB: produced as a fresh tensor
+    it was copied into its bucket afterwards (2.2 GB of traffic per step); written in place the copy disappears.  Only for the FIRST gradient of an optimizer step
+    (later micro-steps must add), and only when dtype and device match; the producer then returns that very tensor as the gradient, and _flush recognises it."""
+    red = _dense_sinks.get(id(param))
+    if red is None or not _DIRECT_GRAD or param in red._written or param not in red._view:
+        return None
+    v = red._view[param]
+    if v.dtype != param.dtype or v.device != param.device:
+        return None
+    return v.view(param.shape)
 
 
 def sparse_candidates(model):
@@ -105,6 +123,8 @@ class GradBucketReducer:
             self.pending.append(len(b))
         self._view = {p: self.flat[self.slices[p][0]][self.slices[p][1]:self.slices[p][1] + self.slices[p][2]] for p in self.params}   # built once: the hook runs ~300 times per step
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        for p in self.params:
+            _dense_sinks[id(p)] = self
         self._nccl = self.world > 1 and dist.get_backend(process_group) == "nccl"
         self._avg = self._nccl
         # ---- sparse parameters: a persistent dense gradient buffer (zero outside the rows touched this step) + the exchange state
@@ -176,7 +196,9 @@ class GradBucketReducer:
                 ad_g.append(g if g.dtype == view.dtype else g.to(view.dtype))
             else:
                 self._written.add(p)
-                if g.is_cuda and g.dtype == view.dtype:
+                if g.data_ptr() == view.data_ptr() and g.dtype == view.dtype:
+                    pass        # produced in place (dense_grad_out_for): nothing to move
+                elif g.is_cuda and g.dtype == view.dtype:
                     cp_v.append(view)
                     cp_g.append(g)
                 else:

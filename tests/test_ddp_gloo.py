@@ -220,3 +220,43 @@ def test_sparse_parameter_refuses_dense_gradient():
     assert sparse_candidates(M(True)) == []
     m = M(False)
     assert sparse_candidates(m) == [m.emb.weight] or sparse_candidates(m)[0] is m.emb.weight
+
+
+def test_gradient_produced_inside_its_bucket_slice():
+    """dense_grad_out_for: a producer (the LM head's dW = dlogits^T h, 1.09 GB at the 7B size) writes a parameter's gradient straight into the reducer's bucket slice and
+    returns that tensor; the reducer recognises it and moves nothing.  First gradient of an optimizer step only: a second micro-step gets None and is ADDED as usual
+    (reference: DeepSpeed's gradient accumulation over micro-steps, train_joint.py:325-346, 521-535)."""
+    from rga3.parallel.ddp import GradBucketReducer, dense_grad_out_for
+
+    p = torch.nn.Parameter(torch.zeros(6, 8))
+    q = torch.nn.Parameter(torch.zeros(5))
+    red = GradBucketReducer([p, q], bucket_mb=1.0)
+    g1, g2 = torch.arange(48.0).view(6, 8), torch.ones(6, 8) * 0.5
+    seen = []
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, g):
+            ctx.g = g
+            return w.sum() * 0.0
+
+        @staticmethod
+        def backward(ctx, _):
+            out = dense_grad_out_for(p)
+            seen.append(out is not None)
+            if out is None:
+                return ctx.g.clone(), None
+            out.copy_(ctx.g)
+            return out, None
+
+    red.begin_step()
+    (Fn.apply(p, g1) + q.sum()).backward()
+    assert seen == [True] and p.grad is None
+    assert torch.equal(red.grad_view(p), g1)
+    red.begin_micro_step()
+    (Fn.apply(p, g2) + q.sum()).backward()
+    assert seen == [True, False]
+    red.finish()
+    assert torch.equal(red.grad_view(p), g1 + g2) and torch.equal(red.grad_view(q), torch.full((5,), 2.0))
+    red.begin_step()
+    assert dense_grad_out_for(p) is not None        # a new optimizer step starts from an empty slice again
