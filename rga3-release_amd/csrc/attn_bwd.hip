@@ -8,7 +8,7 @@
 //   * dkv kernel  — one workgroup per (key block, kv head), looping over the q heads of the GQA group and over Q tiles:
 //                   roles swapped (K/V fragments live in registers, Q / dO tiles are staged in LDS), KEY on the lane;
 //                   dV^T += dO^T . P  and  dK^T += Q^T . dS  with transposed LDS reads of the dO / Q images.
-// delta[q] = rowsum(dO * O) comes from a small pre-pass kernel.
+// delta[q] = rowsum(dO * O) is computed by the dQ kernel for its rows (and left in memory for the dK / dV kernel).
 // Call sites replaced: the autograd of flash_attn_varlen_func / SDPA under train_joint.py:534 (model.backward).
 #include "common.h"
 
@@ -34,28 +34,6 @@ struct AttnBwdArgs {
 };
 
 constexpr int BT = 64;  // tile of the streamed (LDS-staged) dimension
-
-// ---------------------------------------------------------------------------------------------- delta = rowsum(dO * O)
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdArgs p) {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (token, head) pairs, one wave each
-    const int lane = threadIdx.x & 63;
-    const long total = p.total_q * p.Hq;
-    if (row >= total) return;
-    const long t = row / p.Hq;
-    const int h = (int)(row % p.Hq);
-    float s = 0.f;
-    for (int d = lane * 8; d < p.D; d += 512) {
-        u32x4 a = *(const u32x4*)(p.o + t * p.o_st + (long)h * p.o_sh + d);
-        u32x4 b = *(const u32x4*)(p.dout + t * p.do_st + (long)h * p.do_sh + d);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s += __uint_as_float(a[i] << 16) * __uint_as_float(b[i] << 16);
-            s += __uint_as_float(a[i] & 0xffff0000u) * __uint_as_float(b[i] & 0xffff0000u);
-        }
-    }
-    s = wave_sum(s);
-    if (lane == 0) p.delta[(long)h * p.total_q + t] = s;
-}
 
 // ---------------------------------------------------------------------------------------------- dQ
 template <int DP, int QT, int NWAVE, bool PAIR>
@@ -118,7 +96,32 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dq_kernel(AttnBwdArgs p) 
             dof[t][ds] = __builtin_bit_cast(bf16x8, y);
         }
         lse2[t] = ok ? p.lse[(long)hq * p.total_q + qs + qi] * 1.4426950408889634f : 0.f;
-        dl[t] = ok ? p.delta[(long)hq * p.total_q + qs + qi] : 0.f;
+    }
+    // delta[q] = rowsum(dO * O) of this workgroup's query rows, computed HERE (it was a pre-pass launch of its own: 22 us of launch and latency per layer for 15 MB):
+    // the dO fragments are in registers, the matching O chunks are loaded once, the four lanes (g) of a row add their quarters; the dK / dV kernel, launched after
+    // this one, reads the values this kernel leaves in p.delta.  Every (row, head) belongs to exactly one workgroup and pass.
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = qw0 + t * 16 + c;
+        const bool ok = qi < Lq;
+        float dp = 0.f;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+            const int d = ds * 32 + g * 8;
+            if (ok && d < p.D) {
+                const u32x4 ov = *(const u32x4*)(p.o + (long)(qs + qi) * p.o_st + (long)hq * p.o_sh + d);
+                const u32x4 dv = __builtin_bit_cast(u32x4, dof[t][ds]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dp += __uint_as_float(ov[i] << 16) * __uint_as_float(dv[i] << 16);
+                    dp += __uint_as_float(ov[i] & 0xffff0000u) * __uint_as_float(dv[i] & 0xffff0000u);
+                }
+            }
+        }
+        dp += __shfl_xor(dp, 16, 64);
+        dp += __shfl_xor(dp, 32, 64);
+        dl[t] = ok ? dp : 0.f;
+        if (ok && g == 0) p.delta[(long)hq * p.total_q + qs + qi] = dp;
     }
 
     f32x4 dqacc[QT][DT];
@@ -465,8 +468,7 @@ static int launch_bwd(const AttnBwdArgs& a0, int nseg, int max_q, int max_k, hip
         done.insert({k, dev});
         return 0;
     };
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(a.total_q * a.Hq, 4)), dim3(256), 0, st, a);
-    RGA3_CHECK_LAUNCH("attn_delta_kernel");
+    // (delta = rowsum(dO * O) is computed inside the dQ kernel, which runs first and leaves it in a.delta for the dK / dV kernel)
     const unsigned nqb = (unsigned)cdiv(max_q, BLOCK_M), nkb = (unsigned)cdiv(max_k, 16 * NW);
     const bool pair = a.causal && nqb >= 4 && nkb >= 4;   // balanced causal rows (see the kernels)
     if (pair) {
