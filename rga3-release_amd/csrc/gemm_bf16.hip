@@ -92,7 +92,8 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 //      activation is a function of 15 magnitude bits:   act(t) = relu(t) - |t| T(|t|),   T_gelu(a) = Phi(-a),  T_silu(a) = sigmoid(-a)   (tools/gen_act_tables.py:
 //      f32 T for every bf16 magnitude in [2^-14, 2^6), 10 KiB; outside the range the clamped entry is exact to < 3e-5 relative / 1e-26 absolute).  Five VALU
 //      slots and one ds_read_b32 per element instead of a quarter-rate v_rcp + v_exp and ten more (A-S erf) or 2 + 3 (sigmoid): the K = 576 GELU product of Hiera
-//      stage 3 was 70 % VALU-busy (profiles/r04_k576_pmc.json).  Exact to f32 rounding, including the negative tail's relative accuracy.
+//      stage 3 was 70 % VALU-busy (profiles/r04_k576_pmc_before.json).  Exact to f32 rounding, including the negative tail's relative accuracy; NaN stays NaN; an
+//      infinite input (an activation that has already overflowed bf16) gives NaN where the closed form gives +inf / -0 (|inf| x the table's final 0).
 #include "act_tables.inc"
 constexpr int kActTabBytes = kActTabN * 4;
 static_assert(kActTabBytes % 1024 == 0, "the table is staged in 1-KiB LDS-DMA pieces");
