@@ -9,6 +9,8 @@ Targets (kernel name needle -> the call that launches it at the shape of the hea
   gemm_nt_sk_kernel<0,       LLM down projection + residual, 2112 x 3584 x 18944 (tile 22)
   gemm_nt_kernel<128, 192    Hiera-L stage-3 qkv, 32768 x 1728 x 576 (8 frames; tile 5)
   gemm_nt_kernel<128, 256    LLM o-proj + residual, 2112 x 3584 x 3584 (tile 3)
+  gemm_nt_pp_kernel<0, false, false, true>   Hiera stage-3 fc2 + residual, 65536 x 576 x 2304 on 256 x 192 tiles (tile 23)
+  gemm_nt_pp_kernel<1, false, true, false>   Hiera stage-3 fc1 + GELU, LayerNorm folded, 65536 x 2304 x 576 (tile 20)
   attn_fwd_kernel<128        causal decoder attention, S = 2112, 28 / 4 heads x 128
   attn_bwd_dkv / attn_bwd_dq its backward
   attn_win_kernel<96, 8      Hiera stage-3 windows: 128 windows x 256 tokens, 8 heads x 72
@@ -30,7 +32,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-TARGETS = ["gemm_nt_sk_kernel<2,", "gemm_nt_sk_kernel<0,", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel", "attn_fwd_kernel<128", "attn_causal32_kernel",
+TARGETS = ["gemm_nt_sk_kernel<2,", "gemm_nt_sk_kernel<0,", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel<0, false, false, true>", "gemm_nt_pp_kernel<1, false, true, false>", "attn_fwd_kernel<128", "attn_causal32_kernel",
            "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_win_kernel<96, 8", "memattn_cross_kernel", "hiera_mlp576_kernel"]
 
 
@@ -80,6 +82,16 @@ def run():
     cuw = torch.arange(0, T + 1, 256, dtype=torch.int32, device=dev)
     for i in range(R):
         ops.attn_varlen(qkvh[:, :Hh], qkvh[:, Hh:2 * Hh], qkvh[:, 2 * Hh:], cuw, cuw, 256, Dh ** -0.5, max_k=256)
+    # ---- Hiera stage-3 fc2 + residual on the 256 x 192 ping-pong tiles (tile 23) and fc1 + GELU (LayerNorm folded) on the 256 x 256 ping-pong tiles (16 frames)
+    xh, xr = rn(65536, 2304), rn(65536, 576)
+    w2h = [rn(576, 2304, scale=0.04) for _ in range(2)]
+    for i in range(R):
+        ops.gemm(xh, w2h[i % 2], bias=rn(576), residual=xr, tile=23)
+    st = ops.layernorm_stats(xr, 1e-6)
+    wf, colc, bfold = ops.fold_layernorm(rn(2304, 576, scale=0.04), rn(2304), rn(576) + 1, rn(576, scale=0.1))
+    for i in range(R):
+        ops.gemm_ln(xr, st, wf, colc, bfold, act="gelu", tile=20)
+    del xh, w2h
     # ---- SAM2 memory cross-attention at the full bank
     mq, mk, mm = rn(4096, 256), rn(28736, 256), rn(28736, 64)
     for i in range(R):
