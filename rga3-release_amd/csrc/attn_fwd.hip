@@ -737,7 +737,9 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     }
     hipStream_t st = (hipStream_t)stream;
     // long causal rows at D = 128 (the decoder's prefill / training rows): 32-row waves balanced over the key range (attn_causal32.hip)
-    if (impl == 0 && g_attn_variant == 0 && !no_causal32 && causal && D == 128 && max_q >= 256 && block_q == 0) return launch_causal32(a, nseg, max_q, st);
+    // (its output rows leave by 16-byte stores: an 8-byte-aligned `o` view, legal for the general kernel, stays there)
+    const bool o16 = (((uintptr_t)o) & 15) == 0 && o_st % 8 == 0 && o_sh % 8 == 0;
+    if (impl == 0 && g_attn_variant == 0 && !no_causal32 && o16 && causal && D == 128 && max_q >= 256 && block_q == 0) return launch_causal32(a, nseg, max_q, st);
     // whole-segment-in-LDS window kernel: non-causal, key range known and <= 256, D <= 96, 16-byte rows (impl bit 1 keeps the pipelined kernel: A/B)
     if (impl == 0 && g_attn_variant == 0 && !causal && a.nsplit == 1 && max_k > 0 && max_k <= 256 && D <= 96 && D % 8 == 0 &&
         (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0) {
@@ -764,6 +766,7 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
     RGA3_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)cos_q | (uintptr_t)sin_q | (uintptr_t)cos_k | (uintptr_t)sin_k) & 15) == 0 &&
                        (((uintptr_t)o) & 7) == 0, "attn_varlen_fwd_rope: pointer alignment");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn_varlen_fwd_rope: k/v row stride too large");
+    RGA3_CHECK_ARG(!c32 || ((((uintptr_t)o) & 15) == 0 && o_st % 8 == 0 && o_sh % 8 == 0), "attn_varlen_fwd_rope: the causal D = 128 rows write 16-byte pieces: o must be 16-byte aligned, strides multiples of 8");
     AttnArgs a;
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
     a.o = (unsigned short*)o; a.lse = lse; a.cu_q = cu_q; a.cu_k = cu_k;

@@ -2256,7 +2256,7 @@ static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const 
     RGA3_CHECK_ARG(tile != 40 || (M <= 4 && !colscale), "gemm: the skinny kernel (tile 40) takes M <= 4 rows and no column scale");
     const bool rows16_ok = M <= 16 && !colscale && out_dtype == RGA3_BF16 && act != ACT_SWIGLU;
     RGA3_CHECK_ARG(tile != 41 || rows16_ok, "gemm: the token-row kernel (tile 41) takes M <= 16 rows, bf16 output, no column scale, no SwiGLU");
-    int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : (tile == -1 && rows16_ok) ? 41 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale, tile);
+    int tl = (tile == -1 && M <= 4 && !colscale) ? 40 : (tile == -1 && rows16_ok) ? 41 : pick_tile((int)M, (int)N, (int)K, act == ACT_NONE && !residual && !colscale && !rs_in && !rs_out, tile);   // row sums live in the shared epilogue: never the split-K tile
     if (out_dtype == RGA3_F32) return launch_act<ACT_NONE, true>(a, tl, st);
     switch (act) {
         case ACT_NONE: return launch_act<ACT_NONE, false>(a, tl, st);

@@ -163,6 +163,8 @@ def gemm_swiglu_pre(a, w, bias=None, tile: int = -1):
 
     if tile == -1 and M * N * K >= (1 << 24):
         tile = _tuner.pick(_tuner.key_of(M, N, K, "swiglu+pre", BF16, bias is not None, False), run)
+        if tile in (14, 25, 40, 41):    # forced (tuner.force) tilings with an epilogue of their own: no pre-activation store there
+            tile = -1
     run(tile)
     return out, pre
 
@@ -196,6 +198,8 @@ def gemm_cat(a, w, bias=None, a2=None, w2=None, wn=None, tile: int = -1):
     if tile == -1:
         cands = tuple(t for t in ((12, 3, 6, 13) if wn is not None else (12, 3, 4, 5, 6, 13)) if wn is None or N % (256 if t in (3, 6) else 64 if t == 13 else 128) == 0)
         tile = _tuner.pick(_tuner.key_of(M, N + N2, K + K2, "cat", BF16, bias is not None, False), run, candidates=cands)
+        if tile not in cands:    # a tiling forced for the plain GEMMs (tuner.force) that this entry point does not have
+            tile = -1
     run(tile)
     return out if out_n is None else (out, out_n)
 

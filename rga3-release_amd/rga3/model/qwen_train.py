@@ -182,7 +182,7 @@ def lora_refresh(layers):
 _LORA_FOLD = os.environ.get("RGA3_LORA_FOLD", "1") != "0"
 _SWIGLU_PRE = os.environ.get("RGA3_SWIGLU_PRE", "1") != "0"     # training forward: SwiGLU inside the gate | up product, pre-activations stored by the same launch
 _lora_cat = {}     # id(attention module) -> (key, W2, Wn)
-_lora_cat_store = {}   # (n layers, Nqkv, r, dtype, device) -> (W2_all, Wn_all)
+_lora_cat_store = {}   # (ids of the module set, Nqkv, r, dtype, device) -> (W2_all, Wn_all)
 
 
 def set_lora_fold(on: bool):
@@ -207,9 +207,14 @@ def _lora_cat_build(ats):
         Nq, Nall = Hq * D, (Hq + 2 * Hk) * D
         Bq = torch.stack([a.q_proj.lora_B["default"].weight.detach() for a in ats])          # [L, Hq D, r]
         Bv = torch.stack([a.v_proj.lora_B["default"].weight.detach() for a in ats])          # [L, Hk D, r]
-        key = (len(ats), Nall, r, Bq.dtype, Bq.device)
+        # keyed by the IDENTITY of the module set: keyed by shape alone, the per-module fallback of _lora_cat_ops gave every layer the same (1, ...)
+        # buffer, each build overwriting the previous layer's B blocks -- the backward of all layers but the last then read the last layer's (sB)^T
+        ids = tuple(id(a) for a in ats)
+        key = (ids, Nall, r, Bq.dtype, Bq.device)
         st = _lora_cat_store.get(key)
         if st is None:
+            for k in [k for k in _lora_cat_store if k != key and not set(k[0]).isdisjoint(ids)]:    # a module belongs to ONE live set: drop the sets it leaves
+                del _lora_cat_store[k]
             st = (torch.zeros((len(ats), Nall, 2 * r), dtype=Bq.dtype, device=Bq.device), torch.zeros((len(ats), 2 * r, Nall), dtype=Bq.dtype, device=Bq.device))
             _lora_cat_store[key] = st
         W2, Wn = st

@@ -67,7 +67,7 @@ def dense_grad_out_for(param):
     it was copied into its bucket afterwards (2.2 GB of traffic per step); written in place the copy disappears.  Only for the FIRST gradient of an optimizer step
     (later micro-steps must add), and only when dtype and device match; the producer then returns that very tensor as the gradient, and _flush recognises it."""
     red = _dense_sinks.get(id(param))
-    if red is None or not _DIRECT_GRAD or param in red._written or param not in red._view:
+    if red is None or red._removed or not _DIRECT_GRAD or param in red._written or param not in red._view:
         return None
     v = red._view[param]
     if v.dtype != param.dtype or v.device != param.device:
@@ -89,6 +89,7 @@ class GradBucketReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, process_group=None, sparse_params=(), sparse: bool = True,
                  announce_cap: int = 8192):
         self.pg = process_group
+        self._removed = False
         # rows per rank that the forward-time announcement carries (ids, not only their number): with them every rank knows ALL ranks' row ids on the host
         # before backward ends, so finish() needs neither a second id all-gather nor a device-side unique (a data-dependent shape = a device -> host wait
         # with the optimizer's launches still to be issued).  A step whose union outgrows it falls back to the exchange-at-finish path.  Multiple of 8.
@@ -402,11 +403,19 @@ class GradBucketReducer:
             st["last_ids"] = torch.unique(torch.cat(touched)) if touched else None
 
     def remove(self):
+        """Detach from the parameters: hooks off, and neither sink table points here any more (a producer that asked dense_grad_out_for() after this would
+        otherwise keep writing dW into a bucket nobody tracks: with the hooks gone ``_written`` never changes, so every backward would return the SAME memory
+        as a fresh gradient and autograd's accumulation would add a tensor to itself)."""
+        self._removed = True
         for h in self._hooks:
             h.remove()
+        self._hooks = []
         for p in self.sparse_params:
             if _sparse_sinks.get(id(p)) is self:
                 del _sparse_sinks[id(p)]
+        for p in self.params:
+            if _dense_sinks.get(id(p)) is self:
+                del _dense_sinks[id(p)]
 
 
 def _gather(d, ids):

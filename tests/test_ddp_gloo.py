@@ -260,3 +260,16 @@ def test_gradient_produced_inside_its_bucket_slice():
     assert torch.equal(red.grad_view(p), g1 + g2) and torch.equal(red.grad_view(q), torch.full((5,), 2.0))
     red.begin_step()
     assert dense_grad_out_for(p) is not None        # a new optimizer step starts from an empty slice again
+    # a REMOVED reducer no longer offers its bucket (the producer would write every later dW into the same dead slice and autograd's accumulation would
+    # add that tensor to itself: p.grad = 2 * dW_new instead of dW_old + dW_new)
+    red.remove()
+    assert dense_grad_out_for(p) is None
+    (Fn.apply(p, g1) + q.sum()).backward()
+    (Fn.apply(p, g2) + q.sum()).backward()
+    assert seen[-2:] == [False, False]
+    assert torch.equal(p.grad, g1 + g2)
+    # a second reducer over the same parameters takes the sink over; removing it leaves no entry behind
+    red2 = GradBucketReducer([p, q], bucket_mb=1.0)
+    assert dense_grad_out_for(p) is not None and dense_grad_out_for(p).data_ptr() == red2.grad_view(p).data_ptr()
+    red2.remove()
+    assert dense_grad_out_for(p) is None

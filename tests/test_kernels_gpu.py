@@ -468,6 +468,29 @@ def test_attn_causal32(dev, case):
     assert torch.equal(out, again) and torch.equal(lse, lse2)
 
 
+def test_attn_causal32_output_view_alignment(dev):
+    """attn_causal32_kernel stores 16-byte row pieces; an output view that is only 8-byte aligned (legal for rga3_attn_varlen_fwd: o & 7 == 0, strides
+    multiples of 4) must stay on the general kernel -- same values as that kernel on an aligned output, bit for bit -- and the rope entry, which has no other kernel for
+    these rows, must refuse it."""
+    from rga3.hip import ops
+
+    S, Hq, Hkv, D = 512, 4, 2, 128
+    q, kv = _rand((S, Hq, D), dev, seed=31), _rand((S, 2, Hkv, D), dev, seed=32)
+    k, v = kv[:, 0], kv[:, 1]
+    cu = torch.tensor([0, S], dtype=torch.int32, device=dev)
+    want = ops.attn_varlen(q, k, v, cu, cu, S, D ** -0.5, True, impl=4)                   # general kernel, aligned output
+    buf = torch.zeros(S * Hq * D + 8, dtype=torch.bfloat16, device=dev)
+    view = buf[4:4 + S * Hq * D].view(S, Hq, D)                                           # 8-byte aligned, not 16
+    assert view.data_ptr() % 16 == 8
+    got = ops.attn_varlen(q, k, v, cu, cu, S, D ** -0.5, True, out=view)
+    assert torch.equal(got, want)
+    assert float(buf[:4].float().abs().sum()) == 0.0 and float(buf[-4:].float().abs().sum()) == 0.0
+    pos = torch.arange(S, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, D // 2, dtype=torch.float32) / (D // 2)))[None, :]
+    cos, sin = torch.cat([pos.cos(), pos.cos()], 1).contiguous().to(dev), torch.cat([pos.sin(), pos.sin()], 1).contiguous().to(dev)
+    with pytest.raises(RuntimeError, match="16-byte"):
+        ops.attn_varlen_rope(q, k, v, cu, cu, S, D ** -0.5, cos, sin, causal=True, out=view)
+
+
 def test_attn_causal32_rescale_branch(dev):
     """The online-softmax rescale fires only when a later tile raises a row's maximum (cdna_hip_programming.md 5.4 rule 26: a rare data-dependent branch needs an
     input that FORCES it).  Keys far down the row are aligned with their queries and scaled up, so the maximum of most rows jumps in the LAST tiles -- in group A's

@@ -171,6 +171,54 @@ def test_lora_step_cache_follows_parameter_updates(dev):
         assert torch.equal(g1[n], g2[n]), n
 
 
+def test_lora_fold_per_module_fallback_matches_unfolded_route(dev):
+    """the folded-LoRA block matrices (W2 / Wn of rga3_gemm_cat_bf16) of a module set were cached by SHAPE; when the all-layers build is not taken
+    (per-layer scaling differs here, so lora_refresh's uniform-configuration check fails and every layer builds its own pair) all layers shared one buffer and the
+    backward of every layer but the last read the last layer's (sB)^T.  A 3-layer text-only model, r = 32 (2r = 64: the fold's granule), hidden 128: loss and
+    gradients of the folded route against the unfolded one (set_lora_fold(False): B-side products as their own launches) -- they differ by one bf16 rounding of
+    the q / v rows, a wrong B block would be an O(1) error."""
+    from rga3.model import qwen_train as QT
+    from rga3.model.qwen2_5_vl import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+
+    kw = dict(product_cfg_kwargs(), hidden_size=128, num_attention_heads=8, num_key_value_heads=2, intermediate_size=256, num_hidden_layers=3)
+    torch.manual_seed(5)
+    m = Qwen2_5_VLForConditionalGeneration(Qwen2_5_VLConfig(**kw))
+    assert len(QT.add_lora(m, r=32, alpha=64)) == 6
+    for n, p in m.named_parameters():
+        if "lora_" in n:
+            p.data = det_tensor(n, tuple(p.shape), 0.2, seed=13)
+    m = m.to(torch.bfloat16).to(dev)
+    for n, p in m.named_parameters():
+        p.requires_grad_("lora_" in n)
+    for li, layer in enumerate(m.model.layers):          # per-layer scaling: the all-layers build refuses, each module builds alone
+        layer.self_attn.q_proj.scaling = 2.0 + li
+        layer.self_attn.v_proj.scaling = 1.0 + 0.5 * li
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, 300, (1, 96), generator=g)
+    am = torch.ones_like(ids)
+    labels = ids.clone()
+    labels[:, :40] = -100
+
+    def run(fold):
+        QT.set_lora_fold(fold)
+        try:
+            for p in m.parameters():
+                p.grad = None
+            out = m(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev))
+            out.loss.backward()
+            return out.loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}
+        finally:
+            QT.set_lora_fold(True)
+
+    assert QT._lora_cat_ok(m.model.layers[0].self_attn)
+    l1, g1 = run(True)
+    assert len({QT._lora_cat[id(layer.self_attn)][1].data_ptr() for layer in m.model.layers}) == 3        # one block matrix per layer
+    l0, g0 = run(False)
+    assert abs(l1 - l0) <= 5e-3 * abs(l0), (l1, l0)
+    errs = {n: rel_l2(g1[n], g0[n]) for n in g0}
+    assert max(errs.values()) < 4e-2, errs
+
+
 def test_dropout_kernel_matches_oracle_mask(dev):
     from rga3.hip import ops
 
