@@ -305,11 +305,14 @@ int rga3_memlayer_rows(const void* a, int64_t a_stride, int K1, const float* par
  * A + A2 is rounded to bf16 before the product.  HOST arrays. */
 int rga3_gemm_rows16_many(const void* const* ptrs, const int64_t* dims, int n, void* stream);
 /* diagnostic for tile 22 (stream-K): how many bounded waits on a partial-sum slab gave up in launches that used this workspace (expected 0;
- * < 0 = error); synchronises the device */
+ * < 0 = error); synchronises the device.  A give-up never yields a finite wrong product: the owner adds +inf to every sum of the tile it could not complete, so
+ * that tile of C (and everything computed from it) is non-finite, and this counter says why. */
 int rga3_gemm_stream_k_timeouts(const void* workspace);
 /* byte offset of that 32-bit counter inside a workspace of the current device (< 0 = error): lets the caller fetch it with its own asynchronous copy, so a
  * training loop can watch it every few steps without a device synchronisation (no reference counterpart: the reference's GEMMs are vendor BLAS calls) */
 int64_t rga3_gemm_timeout_counter_offset(void);
+/* (the 32-bit word BEHIND that counter is a fault-injection switch for tests: 0 in every real run -- the caller zeroes the flag page; 0xffffffff makes every stream-K
+ * owner behave as if its contributors never publish; any other value is the spin limit) */
 /* dx = d rmsnorm(x; weight)/dx . dy (+ add): backward of HF Qwen2_5_VLRMSNorm (modeling_qwen2_5_vl.py:74-79) w.r.t. x */
 int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* add, void* dx, int64_t rows, int64_t dim, float eps,
                      void* stream);

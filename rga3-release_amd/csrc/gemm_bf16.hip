@@ -182,7 +182,8 @@ __device__ __forceinline__ bool residual_stageable(const GemmArgs& p, int col0, 
 // PARTS: part1 / part2 are read (stream-K owner slices); tab: this kernel's activation table in LDS (act_tab; GELU / SwiGLU epilogues only).
 template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32, bool LNF = false, bool PARTS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmArgs& p, char* est, const char* tab, int lane, int m0, int n0,
-                                              int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr, const char* resl = nullptr) {
+                                              int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr, const char* resl = nullptr,
+                                              float poison = 0.f) {
     static_assert(!(LNF && ACT == ACT_SWIGLU), "the LayerNorm-folded epilogue has no SwiGLU form");
     // part1 / part2 (stream-K owner slices only): this lane's view of up to two f32 partial-sum slabs in accumulator order
     // (quad (i, j) at [(i * NTL + j) * 64]).  They are added to the accumulators as those are READ, one m-tile ahead of use,
@@ -195,6 +196,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
         for (int j = 0; j < NTL; ++j) {
             f32x4 v = part1[(i * NTL + j) * 64];
             if (part2) v += part2[(i * NTL + j) * 64];
+            // poison = +inf when the owner gave up waiting for a contributor (0 otherwise): the tile leaves as non-finite values (every epilogue form keeps +inf
+            // non-finite, ReLU included) instead of a finite sum that lacks a slice -- a wrong product must not look like a right one
+            v += f32x4{poison, poison, poison, poison};
             pn[i % PD][j] = v;
         }
     };
@@ -932,10 +936,19 @@ __device__ __forceinline__ void mfma_inplace(f32x4& c, const bf16x8& a, const bf
 //   relaxed agent flag store (no release fence); owner: one lane polls relaxed, agent-scope acquire fence,
 //   wait, barrier, then plain vector loads.  Flags are zero at allocation and reset by their single consumer.
 //   The split is a pure function of (M, N, K, P): results are reproducible run to run.
+// dynamic LDS of the persistent kernel: two K-tile buffers (+ the activation table), or the residual staging image when that is larger; one more 16-byte slot
+// behind it carries the owner's give-up flag from lane 0 to the workgroup
+template <int ACT, bool OUT_F32, int MH>
+constexpr int sk_lds_bytes() {
+    constexpr int LDS_MAIN = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
+    constexpr int LDS_RES = pp_res_lds<ACT, OUT_F32>() ? 8 * 1024 + 8 * res_stage_bytes<2 * MH, 64>() : 0;
+    return LDS_MAIN > LDS_RES ? LDS_MAIN : LDS_RES;
+}
+
 struct SkArgs {
     float* slabs;     // [P][512 lanes][32] f32x4 in register order (256 KiB per workgroup)
     unsigned* flags;  // [P] 1 = slab written
-    unsigned* tmo;    // bounded-spin give-up counter (diagnostic)
+    unsigned* tmo;    // tmo[0]: bounded-spin give-up counter; tmo[1]: fault injection (tests), 0 in real runs
     int P;            // workgroups launched
     int P_sk;         // workgroups that take part in the stream-K tail
     int t_dp;         // tiles [0, t_dp) are data-parallel (t_dp % P == 0 or sk_tiles == 0)
@@ -1234,31 +1247,42 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 }
             }
             const f32x4 *part1 = nullptr, *part2 = nullptr;
+            float poison = 0.f;
             if (cur_kind == 2) {
                 // ---- owner slice: add the partial sums of the (at most two: P_sk <= 2 * sk_tiles) lower-numbered
                 //      workgroups that computed this tile's earlier K-iterations
                 const long tot = (long)sk.sk_tiles * nk;
                 const long x0 = (long)(ow_tile - sk.t_dp) * nk;  // first iteration of this tile in stream-K numbering
                 const bool two = w >= 2 && ((long)(w - 1) * tot / sk.P_sk) > x0;
+                volatile unsigned* gave_up = (volatile unsigned*)(smem + sk_lds_bytes<ACT, OUT_F32, MH>());   // 16 bytes behind everything else in LDS
                 if (tid == 0) {
+                    // sk.tmo[1]: fault injection for tests (0 in every real run: the caller zeroes the flag page): 0xffffffff = behave as if a contributor never
+                    // publishes; any other non-zero value = spin limit
+                    const unsigned inject = __hip_atomic_load(sk.tmo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned limit = (inject != 0u && inject != 0xffffffffu) ? inject : (1u << 22);
+                    unsigned gave = 0;
                     for (int c = 0; c < (two ? 2 : 1); ++c) {
                         unsigned spins = 0;
-                        while (__hip_atomic_load(sk.flags + (w - 1 - c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+                        while (inject == 0xffffffffu || __hip_atomic_load(sk.flags + (w - 1 - c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
                             __builtin_amdgcn_s_sleep(8);
-                            if (++spins > (1u << 22)) {
+                            if (inject == 0xffffffffu || ++spins > limit) {
                                 __hip_atomic_fetch_add(sk.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                gave = 1;
                                 break;
                             }
                         }
                     }
+                    *gave_up = gave;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __syncthreads();
+                // a give-up used to fall through and sum whatever was in the slab: a finite, wrong tile.  Now the tile is poisoned (+inf into every sum)
+                poison = __builtin_amdgcn_readfirstlane((int)*gave_up) ? __builtin_inff() : 0.f;   // wave-uniform: lives in a scalar register
                 part1 = (const f32x4*)sk.slabs + (size_t)(w - 1) * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
                 if (two) part2 = part1 - 512 * 32;
             }
-            if (cur_kind == 2) gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, true>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2, resl);
+            if (cur_kind == 2) gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, true>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2, resl, poison);
             else gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, false>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, nullptr, nullptr, resl);
             if (cur_kind == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1431,9 +1455,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.dbg = (dbg && !split && !sk_workspace(ws_ptr, ws_bytes, w2)) ? (unsigned long long*)w2.slabs : nullptr;
     }
 #endif
-    constexpr int LDS_MAIN = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
-    constexpr int LDS_RES = pp_res_lds<ACT, OUT_F32>() ? 8 * 1024 + 8 * res_stage_bytes<2 * MH, 64>() : 0;
-    constexpr int LDS = LDS_MAIN > LDS_RES ? LDS_MAIN : LDS_RES;
+    constexpr int LDS = sk_lds_bytes<ACT, OUT_F32, MH>() + 16;
     static_assert(LDS <= 160 * 1024, "persistent kernel: LDS");
     auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, MH>;
     static LdsGrant lds_grant;

@@ -1110,6 +1110,17 @@ class GemmHealthWatch:
                                      "trustworthy (workspace flags re-zeroed)")
 
 
+_inference_watch = GemmHealthWatch(every=1)
+
+
+def poll_gemm_health():
+    """End of evaluate() / generate(): issue a non-blocking fetch of every GEMM workspace's give-up counter and examine the fetch of the PREVIOUS call (no device
+    synchronisation).  A stream-K owner that gave up has already poisoned its output tile with +inf (csrc/gemm_bf16.hip), so the product itself is never a finite wrong
+    one; this turns the poisoned result into a raised Rga3Error at the next call at the latest."""
+    if _gemm_ws:
+        _inference_watch.poll()
+
+
 # ------------------------------------------------------------------------------------------------ mask-path backward kernels
 def layernorm_bwd(x, weight, dy, eps: float, want_param_grads=True):
     _need_cuda(x, weight, dy)

@@ -1002,6 +1002,7 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
             logits = self.lm_head(h)
         flags = torch.stack(all_done).cpu().numpy() if all_done else np.zeros(0, dtype=bool)
         keep = int(np.argmax(flags)) + 1 if flags.any() else len(new_cols)   # columns up to and including the step at which the last sequence finished
+        ops.poll_gemm_health()
         return torch.cat([seqs] + new_cols[:keep], dim=1)
 
 

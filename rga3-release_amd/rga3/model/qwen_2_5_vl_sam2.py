@@ -261,4 +261,5 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
                 h, w = original_size_list[i]
                 masks = ops.bilinear(masks[:, 0].contiguous(), (int(h), int(w)))
                 pred_masks.append(masks > 0)
+        ops.poll_gemm_health()
         return output, pred_masks

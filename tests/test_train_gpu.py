@@ -647,3 +647,49 @@ def test_gemm_health_watch_polls_without_sync_and_reports_a_give_up(dev):
         watch.poll()
     ws[off:off + 4].view(torch.int32).zero_()
     assert ops.gemm_stream_k_timeouts(a.device) == 0
+
+
+def test_stream_k_give_up_poisons_its_tile_and_is_reported(dev):
+    """a stream-K owner whose contributor never publishes used to break out of its bounded spin and sum whatever lay in the slab -- a finite, wrong
+    product, noticed only by an asynchronously polled counter.  Now the owner adds +inf to every sum of that tile: with the fault-injection word set (the word behind
+    the give-up counter; 0 in real runs) the split tiles of C are non-finite for EVERY epilogue form, the data-parallel tiles are untouched, the counter counts, and the
+    inference-side poll (evaluate() / generate() call it) raises at the next call -- never a finite wrong value."""
+    from rga3.hip import lib, ops
+
+    M, N, K = 2112, 3584, 3584          # 9 x 14 = 126 tiles of 256 x 256 on 256 CUs: every tile is a stream-K tile
+    a, w = rnd((M, K), dev, 0.1, 1), rnd((N, K), dev, 0.1, 2)
+    res = rnd((M, N), dev, 0.1, 3)
+    good = ops.gemm(a, w, tile=22)
+    ws = ops.gemm_workspace(a.device)
+    off = int(lib.load().rga3_gemm_timeout_counter_offset())
+    assert ops.gemm_stream_k_timeouts(a.device) == 0
+    inj = ws[off + 4:off + 8].view(torch.int32)
+    try:
+        for kw in (dict(), dict(act="relu"), dict(act="gelu"), dict(residual=res), dict(act="swiglu")):
+            inj.fill_(-1)                                # 0xffffffff: contributors "never publish"
+            bad = ops.gemm(a, w, tile=22, **kw)
+            torch.cuda.synchronize()
+            inj.zero_()
+            n = ops.gemm_stream_k_timeouts(a.device)
+            assert n > 0, kw
+            fin = torch.isfinite(bad.float())
+            assert not bool(fin.all()), kw               # the tiles an owner could not complete are non-finite ...
+            if not kw:
+                assert torch.equal(bad[fin], good[fin])  # ... and whatever IS finite is the right value (tiles owned by a workgroup with no contributor)
+            ws[:4096].zero_()                            # re-arm: flags of slabs that were published but never consumed, the counter
+            again = ops.gemm(a, w, tile=22, **kw)
+            assert bool(torch.isfinite(again.float()).all()), kw
+        assert torch.equal(ops.gemm(a, w, tile=22), good)
+        # the inference-side poll: first call fetches, second call examines
+        inj.fill_(-1)
+        ops.gemm(a, w, tile=22)
+        torch.cuda.synchronize()
+        inj.zero_()
+        ops._inference_watch.pending.clear()
+        ops.poll_gemm_health()
+        with pytest.raises(lib.Rga3Error, match="timed out"):
+            ops.poll_gemm_health()
+    finally:
+        ws[:4096].zero_()
+        ops._inference_watch.pending.clear()
+    assert ops.gemm_stream_k_timeouts(a.device) == 0
