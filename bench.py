@@ -236,29 +236,48 @@ class GemmTimer:
         return out
 
 
+def _tree():
+    from rga3.utils.fingerprint import tree_fingerprint
+    return tree_fingerprint()
+
+
 def _traffic(tag, family="gemm"):
     """HBM-side traffic per launch of a kernel family cannot be sampled inside the timed run (PMC needs rocprofv3): it comes from the committed two-pass
-    FETCH_SIZE / WRITE_SIZE collection of this same command, summarised by tools/pmc_traffic.py."""
-    for r in ("r04", "r03", "r02"):
-        path = os.path.join(ROOT, "profiles", f"{r}_bench_{tag}_{family}_traffic.json")
-        if os.path.exists(path):
-            tj = json.load(open(path))
-            return round(tj["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)"
-    return None, None
+    FETCH_SIZE / WRITE_SIZE collection of this same command, summarised by tools/pmc_traffic.py -- and ONLY from a collection made on THIS tree: the profile records
+    the fingerprint of the kernel sources + package it was measured on (rga3.utils.fingerprint), and a profile of another tree is refused.
+    -> (bytes per launch or None, source text, stale flag)."""
+    path = os.path.join(ROOT, "profiles", f"r05_bench_{tag}_{family}_traffic.json")
+    if not os.path.exists(path):
+        return None, None, False
+    tj = json.load(open(path))
+    if tj.get("tree") != _tree():
+        return None, f"profiles/{os.path.basename(path)} REFUSED: collected on tree {tj.get('tree')}, running tree is {_tree()}", True
+    return round(tj["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on tree {tj['tree']}, bytes per launch)", False
+
+
+def _put_traffic(roof, tag, family="gemm"):
+    tr, src, stale = _traffic(tag, family)
+    roof["traffic"] = tr
+    if src:
+        roof["traffic_source"] = src
+    if stale:
+        roof["traffic_stale"] = True
 
 
 def _mfma_busy(*needles):
     """Matrix-pipe utilisation of the shipped kernels (SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs)) cannot be sampled inside the timed run either: it
-    comes from the committed rocprofv3 --pmc passes over tools/pmc_pipe_util.py (each kernel at its bench shape), profiles/r04_pmc_pipe_util.json."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_pipe_util.json")
+    comes from the committed rocprofv3 --pmc passes over tools/pmc_pipe_util.py (each kernel at its bench shape), profiles/r05_pmc_pipe_util.json -- same tree only."""
+    path = os.path.join(ROOT, "profiles", "r05_pmc_pipe_util.json")
     if not os.path.exists(path):
         return None, None
     pj = json.load(open(path))
+    if pj.get("_tree") != _tree():
+        return None, f"profiles/r05_pmc_pipe_util.json REFUSED: collected on tree {pj.get('_tree')}, running tree is {_tree()}"
     out = {}
     for k, v in pj.items():
         if isinstance(v, dict) and "mfma_busy" in v and (not needles or any(n in k for n in needles)):
             out[k] = v["mfma_busy"]
-    return (out or None), "profiles/r04_pmc_pipe_util.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE passes over tools/pmc_pipe_util.py, per kernel at its bench shape)"
+    return (out or None), f"profiles/r05_pmc_pipe_util.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE passes over tools/pmc_pipe_util.py on tree {pj['_tree']}, per kernel at its bench shape)"
 
 
 # ------------------------------------------------------------------------------------------------ cpu baseline (oracle "port")
@@ -595,13 +614,13 @@ def sam2_stream(args, dev, rank, world, dist):
             _ops.memattn_cross = real
         tot = sum(a.elapsed_time(b) for a, b in evs)
         n = len(evs)
-        tr, src = _traffic("sam2_stream", "memattn")
         dom = {"bound": "mfma", "kernel": ("memattn_cross_kernel + memattn_combine_kernel" if args.no_rowchain else "memattn_cross_kernel (its key slices are merged by the consumer, memlayer_rows_kernel)")
                + " (csrc/memattn.hip: 32x32x16 bf16 MFMA, values kept in the 64-wide memory space)",
                "launches_per_stream": n, "avg_launch_ms": round(tot / max(n, 1), 5), "achieved": round(acc[0] / (tot * 1e-3) / 1e12, 1), "peak": PEAK_BF16 / 1e12,
                "unit": "TFLOP/s", "frac": round(acc[0] / (tot * 1e-3) / PEAK_BF16, 4), "algorithmic_flops_per_launch": acc[0] / max(n, 1),
-               "algorithmic_bytes_per_launch": acc[1] / max(n, 1), "traffic": tr, "traffic_source": src,
+               "algorithmic_bytes_per_launch": acc[1] / max(n, 1),
                "note": "flops as THIS kernel computes them (2 Nq Nk (256 + 64)); the reference's formulation (values projected to 256 first) would be 2 Nq Nk 512"}
+        _put_traffic(dom, "sam2_stream", "memattn")
     if dist is not None:
         t = torch.tensor([elapsed, elapsed_enc, elapsed_prompt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -703,11 +722,9 @@ def measure_forward(model_fwd, inputs, args, rank, refine=True):
             "forward_ms_per_step": round(ms, 3), "forward_samples_per_s": round(1e3 / ms, 3),
             "whole_forward_frac": round(TOTAL_FLOPS / (ms * 1e-3) / PEAK_BF16, 4), "flops_per_forward": TOTAL_FLOPS,
             "algorithmic_bytes_per_launch": round(gt.bytes / max(len(gt.ev), 1)), "variants_ms": variants_fwd}
-    tr, src = _traffic("forward")
-    if tr is not None:
-        roof["traffic"], roof["traffic_source"] = tr, src
+    _put_traffic(roof, "forward")
     mb, msrc = _mfma_busy("gemm_nt", "attn_causal32", "attn_win")
-    if mb is not None:
+    if msrc is not None:
         roof["mfma_busy"], roof["mfma_busy_source"] = mb, msrc
     # ---- the timed output is checked.  (a) every distinct GEMM shape of the timed forward is re-run, on the same operands, on the first-generation
     #      single-phase 256x256 tiling (id 10) and must agree to bf16 rounding (stream-K / split-K tilings only reorder the f32 sums);
@@ -1029,17 +1046,13 @@ def main():
                              "traffic": None, "gemm_family": roof_tr, "note": "whole-step algorithmic FLOPs / step time against the dense fp8 (5 PF) or bf16 (2.5 PF) MFMA peak"},
                 "loss_first_last": [round(float(lv[0]), 5), round(float(lv[-1]), 5)], "comm": comm,
                 "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(train=True, sam_frames=0, seq=4160, grid_t=16, micro_steps=accum)}
-        tr8, src8 = _traffic("lora_fp8", "gemm")
-        if tr8 is not None:
-            line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr8, src8
+        _put_traffic(line["roofline"], "lora_fp8", "gemm")
         print(json.dumps(line), flush=True)
     elif rank == 0:
         fl = train_flops(args.sam_frames) if full else (10.8 + 30.8 - 2.3 + 28.5) * 1e12
         rfb = {"bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / PEAK_BF16, 4),
                "traffic": None, "flops_per_step": fl, "gemm_family": roof_tr, "note": "whole-step algorithmic FLOPs (SURVEY.md 8(d); activations kept, nothing recomputed) / step time"}
-        tr, src = _traffic("train_full")
-        if tr is not None:
-            rfb["traffic"], rfb["traffic_source"] = tr, src
+        _put_traffic(rfb, "train_full")
         cpu = None
         if full and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(train=True, sam_frames=args.sam_frames)

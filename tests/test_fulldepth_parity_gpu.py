@@ -1,0 +1,211 @@
+"""GPU, BASELINE.json configs[1] at FULL DEPTH against the oracle: the whole Qwen2.5-VL-7B forward -- 32 ViT blocks + merger, embedding scatter,
+28 decoder layers with mRoPE, final norm, LM head over the 152 064-row vocabulary -- on 16 frames of 448 x 448 (grid [8,32,32], S = 2112) in ONE call of the product
+model (reference model/qwen_2_5_vl_sam2.py:182-200 -> HF modeling_qwen2_5_vl.py:1185-1253, 1367-1402), against oracle/qwen25vl.py in fp32 on the host cores on the
+same bf16 weights.  north_star's acceptance: "bit-exact token indices, fp logits within stated tolerance" (logits rel-L2 <= 2e-2).
+
+The weights are random (no checkpoint offline) but CONDITIONED: residual-branch output projections are scaled by 1 / sqrt(2 L) (the GPT-2 initialisation), so the
+60-block stack does not amplify perturbations the way an N(0, 0.02) stack does (bench.py's random-init forward drifts 9 % between two tilings of the SAME product
+path -- that measures chaos, not arithmetic).  The oracle never holds more than one weight matrix in fp32: its parameter dictionary fetches each tensor from the
+device model on demand (the host memory of the GPU box is not ours to fill with 33 GB).
+
+Token indices: greedy argmax must equal the oracle's on every row whose top-1 margin exceeds 8 x the measured RMS logit error (rows the comparison can decide);
+the agreement over ALL rows is reported.
+
+Second leg, configs[4] (fp8 LoRA step, 32 frames -> grid [16,32,32], S = 4160) on one 7B decoder layer: forward, loss and gradients with the frozen contractions
+in e4m3 against the oracle's e4m3 restatement (oracle/fp8step.py) at M = 4160; the e4m3 products at that M are pinned in tests/test_kernels_gpu.py, the ViT at
+16 384 patches in tests/test_fullsize_parity_gpu.py."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qwen25vl as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _threads():
+    torch.set_num_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
+
+
+class DeviceParams(dict):
+    """The oracle's parameter dictionary over the DEVICE model's bf16 tensors: a tensor is copied to the host and widened to fp32 when the oracle asks for it, and
+    freed when the oracle drops it -- same rounded weights on both sides, one matrix resident at a time."""
+
+    def __init__(self, sd):
+        super().__init__()
+        self._sd = sd
+
+    def __getitem__(self, k):
+        return self._sd[k].detach().float().cpu()
+
+    def get(self, k, default=None):
+        return self[k] if k in self._sd else default
+
+    def __contains__(self, k):
+        return k in self._sd
+
+
+def _conditioned_init(model, seed):
+    """N(0, 0.02) matrices, embedding rows N(0, 1) (a unit-scale residual stream from the first layer on), norm weights 1 + 0.1 N(0, 1), and every residual-branch
+    output projection (attention out, MLP down; ViT and decoder) divided by sqrt(2 L) of its tower."""
+    c = model.config
+    Lv, Lt = c.vision_config.depth, c.num_hidden_layers
+    g = torch.Generator(device=model.device).manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n == "model.embed_tokens.weight":
+                p.normal_(0.0, 1.0, generator=g)
+            elif p.dim() >= 2:
+                p.normal_(0.0, 0.02, generator=g)
+                if n.endswith(("attn.proj.weight", "mlp.down_proj.weight")) and n.startswith("visual.blocks."):
+                    p.mul_((2 * Lv) ** -0.5)
+                elif n.endswith(("self_attn.o_proj.weight", "mlp.down_proj.weight")) and n.startswith("model.layers."):
+                    p.mul_((2 * Lt) ** -0.5)
+            elif "norm" in n or "ln_q" in n:
+                p.normal_(0.0, 0.1, generator=g).add_(1.0)
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+
+
+def _record(name, rec):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(rec, f, indent=1)
+
+
+def test_full_depth_7b_forward_16_frames(dev):
+    from rga3.model.qwen2_5_vl import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+
+    _threads()
+    cfg = Qwen2_5_VLConfig()                       # the public Qwen2.5-VL-7B dimensions are the defaults
+    assert cfg.num_hidden_layers == 28 and cfg.vision_config.depth == 32 and cfg.vocab_size == 152064
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            model = Qwen2_5_VLForConditionalGeneration(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    _conditioned_init(model, 71)
+    model.eval()
+    g = torch.Generator().manual_seed(72)
+    grid = np.array([[8, 32, 32]])
+    px = torch.randn(8192, 1176, generator=g).clamp_(-1.8, 2.2).to(torch.bfloat16)
+    text = torch.randint(0, 151643, (64,), generator=g)
+    ids = torch.cat([text[:14], torch.tensor([cfg.vision_start_token_id]), torch.full((2048,), cfg.video_token_id), torch.tensor([cfg.vision_end_token_id]), text[16:]])[None]
+    assert ids.shape[1] == 2112
+    am = torch.ones_like(ids)
+    with torch.no_grad():
+        out = model(input_ids=ids.to(dev), attention_mask=am.to(dev), pixel_values_videos=px.to(dev), video_grid_thw=torch.from_numpy(grid),
+                    second_per_grid_ts=torch.tensor([1.0]), output_hidden_states=True)
+        vit_dev = model.visual(px.to(dev), grid)
+    logits = out.logits[0].float().cpu()
+    hidden = out.hidden_states[-1][0].float().cpu()
+    assert tuple(logits.shape) == (2112, 152064)
+
+    # ---- the oracle, piece by piece as Q.forward runs them (HF:1185-1253, 1367-1402), so that the towers' errors are reported separately
+    P = DeviceParams(model.state_dict())
+    ocfg = Q.QwenCfg()
+    t0 = time.time()
+    with torch.no_grad():
+        e = Q.vit_forward(P, px.float(), grid, ocfg)
+        t_vit = time.time() - t0
+        x = P["model.embed_tokens.weight"][ids]
+        x[ids == ocfg.video_token_id] = e
+        pos, _ = Q.rope_index(ids.numpy(), ocfg, None, grid, np.array([1.0]), am.numpy(), "hf449")
+        hid_ref = Q.llm_forward(P, x, torch.from_numpy(pos), am, ocfg)[0]
+        log_ref = hid_ref @ P["lm_head.weight"].t()
+    t_all = time.time() - t0
+
+    e_vit, e_hid, e_log = rel(vit_dev, e), rel(hidden, hid_ref), rel(logits, log_ref)
+    sigma = float((logits - log_ref).pow(2).mean().sqrt())           # RMS logit error: "the measured error"
+    top2 = log_ref.topk(2, dim=1)
+    margin = top2.values[:, 0] - top2.values[:, 1]
+    am_ref, am_dev = top2.indices[:, 0], logits.argmax(1)
+    decisive = margin > 8.0 * sigma
+    agree_all = float((am_ref == am_dev).float().mean())
+    agree_dec = float((am_ref[decisive] == am_dev[decisive]).float().mean()) if bool(decisive.any()) else 1.0
+    rec = {"vit_rel_l2": e_vit, "hidden_rel_l2": e_hid, "logits_rel_l2": e_log, "logit_rms": float(log_ref.pow(2).mean().sqrt()), "logit_rms_err": sigma,
+           "rows": 2112, "rows_decisive": int(decisive.sum()), "argmax_agree_decisive": agree_dec, "argmax_agree_all_rows": agree_all,
+           "median_top1_margin": float(margin.median()), "oracle_seconds": round(t_all, 1), "oracle_vit_seconds": round(t_vit, 1), "oracle_threads": torch.get_num_threads()}
+    print("FULL_DEPTH_7B", json.dumps(rec))
+    _record("fulldepth_parity_7b.json", rec)
+    assert e_vit < 2e-2, rec
+    assert e_log < 2e-2 and e_hid < 2e-2, rec
+    assert int(decisive.sum()) >= 200, rec                            # the token-index check must not be vacuous
+    assert agree_dec == 1.0, rec                                      # bit-exact token indices wherever the comparison can decide
+    assert agree_all >= 0.9, rec
+
+
+def test_decoder_layer_7b_fp8_frozen_lora_r128_s4160(dev):
+    """configs[4] at its own size: one 7B decoder layer, LoRA r = 128 / alpha = 256 on q and v, frozen q|k|v / o / gate|up / down contractions in e4m3 (reference
+    run_torchrun.sh:28-40 fp8 fine-tune; PEFT LoRA under train_joint.py:193-251), S = 4160 = 4096 video tokens of grid [16,32,32] + 64 text tokens: loss and the six
+    trainable gradients against fp32 autograd through the oracle's e4m3 restatement (oracle/fp8step.py: same quantiser, same scales, products summed in fp32).
+    Tolerance 5e-2: an activation that differs by one bf16 ulp between the two sides lands on the neighbouring e4m3 code in ~7 % of its elements (step 2^-3 vs
+    2^-8), i.e. ~1 - 2 % noise per contraction output that a bf16-only path does not have; measured values are printed."""
+    from rga3.model import qwen_index as QI
+    from rga3.model import qwen_train as QT
+    from rga3.model.qwen2_5_vl import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    from oracle.fp8step import fp8_frozen_linears
+
+    _threads()
+    V, S_ = 8192, 4160
+    c = Qwen2_5_VLConfig(num_hidden_layers=1, vocab_size=V, vision_config={"depth": 1, "fullatt_block_indexes": (0,)})
+    m = Qwen2_5_VLForConditionalGeneration(c)
+    g = torch.Generator().manual_seed(81)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif "norm" in n or "ln_q" in n:
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    assert QT.add_lora(m, r=128, alpha=256, dropout=0.0, exclude=("visual",)) == ["model.layers.0.self_attn.q_proj", "model.layers.0.self_attn.v_proj"]
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "lora_" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    P = {k.replace(".base_layer.", "."): v.detach().to(torch.bfloat16).float() for k, v in m.state_dict().items() if not k.startswith("visual.")}
+    P["lora_scaling"] = 2.0
+    ids_pos = np.concatenate([np.arange(14), [c.vision_start_token_id], np.full(4096, c.video_token_id), [c.vision_end_token_id], np.arange(100, 148)])[None]
+    pos_np, _ = QI.rope_index(ids_pos, c.image_token_id, c.video_token_id, 2, 2, None, np.array([[16, 32, 32]]), np.array([1.0]), None, c.mrope_temporal_rule)
+    ids = torch.randperm(V, generator=g)[:S_][None]
+    labels = torch.full_like(ids, -100)
+    labels[:, -64:] = ids[:, -64:]
+    am = torch.ones_like(ids)
+    md = m.to(torch.bfloat16).to(dev).train()
+    train = [n for n, p in md.named_parameters() if ("lora_" in n) or n in ("lm_head.weight", "model.embed_tokens.weight")]
+    for n, p in md.named_parameters():
+        p.requires_grad_(n in train)
+    QT.set_fp8_frozen_gemms(True)
+    try:
+        out = md(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev), position_ids=torch.from_numpy(pos_np).to(dev))
+        out.loss.backward()
+    finally:
+        QT.set_fp8_frozen_gemms(False)
+    assert any(k.startswith("fp8:") for k in md.model.layers[0].mlp.__dict__.get("_wt_cache", {})), "the e4m3 weight packs were not built: the bf16 route ran"
+    cfg = Q.QwenCfg(vision=Q.VisionCfg(depth=0, fullatt_block_indexes=()), text=Q.TextCfg(num_hidden_layers=1, vocab_size=V))
+    okeys = [n.replace(".base_layer.", ".") for n in train]
+    for k in okeys:
+        P[k].requires_grad_(True)
+    with fp8_frozen_linears():
+        ref = Q.forward(P, cfg, ids, am, position_ids=torch.from_numpy(pos_np), labels=labels)
+        ref["loss"].backward()
+    got = dict(md.named_parameters())
+    errs = {n: rel(got[n].grad, P[k].grad) for n, k in zip(train, okeys)}
+    rec = {"loss": out.loss.item(), "oracle_fp8_loss": ref["loss"].item(), "grad_rel_l2": errs}
+    print("FP8_LAYER_S4160", json.dumps(rec))
+    _record("fp8_layer_s4160_parity.json", rec)
+    assert abs(out.loss.item() - ref["loss"].item()) / ref["loss"].item() < 1e-2, rec
+    assert len(errs) == 6 and all(e < 5e-2 for e in errs.values()), rec

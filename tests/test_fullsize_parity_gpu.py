@@ -64,20 +64,22 @@ def test_decoder_layer_7b_s2112(dev):
     assert rel(y, ref) < 2e-2
 
 
-def test_vit_blocks_7b_grid_8_32_32(dev):
+@pytest.mark.parametrize("frames", [8, 16])
+def test_vit_blocks_7b_grid_8_32_32(dev, frames):
+    """grid [8,32,32] = configs[1] / [2] (16 frames of 448 x 448); grid [16,32,32] = configs[4] (32 frames: 16 384 patches, 16 full-attention segments of 1024)."""
     from rga3.model.qwen2_5_vl import Qwen2_5_VLVisionConfig, VisionTransformer
 
     _threads()
     vc = Qwen2_5_VLVisionConfig(depth=2, fullatt_block_indexes=(1,))
     vt = _init(VisionTransformer(vc), 12)
-    px = torch.randn(8192, 1176, generator=torch.Generator().manual_seed(4)).clamp_(-1.8, 2.2).to(torch.bfloat16)
-    grid = np.array([[8, 32, 32]])
+    px = torch.randn(frames * 1024, 1176, generator=torch.Generator().manual_seed(4)).clamp_(-1.8, 2.2).to(torch.bfloat16)
+    grid = np.array([[frames, 32, 32]])
     P = {"visual." + k: v.detach().to(torch.bfloat16).float() for k, v in vt.state_dict().items()}
     vtd = vt.to(torch.bfloat16).to(dev).eval()
     with torch.no_grad():
         y = vtd(px.to(dev), grid)
         ref = Q.vit_forward(P, px.float(), grid, Q.QwenCfg(vision=Q.VisionCfg(depth=2, fullatt_block_indexes=(1,)), text=Q.TextCfg(num_hidden_layers=1)))
-    assert tuple(y.shape) == (2048, 3584)
+    assert tuple(y.shape) == (frames * 256, 3584)
     assert rel(y, ref) < 2e-2
 
 

@@ -160,3 +160,36 @@ def Image_alpha(tgt, disk, rgba):
     ov = np.zeros(tgt.shape[:2] + (4,), np.uint8)
     ov[disk] = rgba
     return Image.alpha_composite(Image.fromarray(tgt, "RGB").convert("RGBA"), Image.fromarray(ov, "RGBA")).convert("RGB")
+
+
+def test_bench_refuses_counter_profiles_of_another_tree(tmp_path, monkeypatch):
+    """bench.py quotes a PMC traffic / pipe-utilisation profile only when it was collected on the running tree (fingerprint of the HIP sources + the
+    package's Python, stamped by tools/pmc_traffic.py / pmc_pipe_util.py); anything else is reported as `traffic: null, traffic_stale: true`, never as a number."""
+    import importlib
+    import json
+
+    bench = importlib.import_module("bench")
+    from rga3.utils.fingerprint import tree_fingerprint
+
+    fp = tree_fingerprint()
+    assert len(fp) == 16 and fp == tree_fingerprint()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    roof = {}
+    bench._put_traffic(roof, "forward")
+    assert roof == {"traffic": None}                                     # nothing collected: null, not stale
+    (prof / "r05_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 123456789.4, "tree": "0123456789abcdef"}))
+    roof = {}
+    bench._put_traffic(roof, "forward")
+    assert roof["traffic"] is None and roof["traffic_stale"] is True and "REFUSED" in roof["traffic_source"]
+    (prof / "r05_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 123456789.4, "tree": fp}))
+    roof = {}
+    bench._put_traffic(roof, "forward")
+    assert roof["traffic"] == 123456789 and "traffic_stale" not in roof and fp in roof["traffic_source"]
+    (prof / "r05_pmc_pipe_util.json").write_text(json.dumps({"gemm_nt_sk_kernel<2,": {"mfma_busy": 0.56}, "_tree": "feedfeedfeedfeed"}))
+    mb, src = bench._mfma_busy("gemm_nt")
+    assert mb is None and "REFUSED" in src
+    (prof / "r05_pmc_pipe_util.json").write_text(json.dumps({"gemm_nt_sk_kernel<2,": {"mfma_busy": 0.56}, "_tree": fp}))
+    mb, src = bench._mfma_busy("gemm_nt")
+    assert mb == {"gemm_nt_sk_kernel<2,": 0.56}

@@ -694,7 +694,8 @@ def test_cross_entropy(dev, dtype, V):
     assert _rel_l2(dl, lf.grad) < 1e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (2112, 4608, 3584), (2112, 3584, 18944), (17, 24, 128)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 384), (2112, 4608, 3584), (2112, 3584, 18944), (17, 24, 128),
+                                   (4160, 4608, 3584), (4160, 3584, 18944), (4160, 37888, 3584)])   # M = 4160: configs[4] (32 frames, S = 4096 + 64): q|k|v, down, gate|up
 def test_fp8_quant_and_gemm(dev, M, N, K):
     """e4m3 row quantiser bit-exact against torch's float8_e4m3fn cast; fp8 GEMM equal to the fp32 product of the quantised operands up to
     summation order; and the end-to-end error against the unquantised bf16 GEMM at the level per-row e4m3 quantisation implies."""

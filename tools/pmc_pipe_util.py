@@ -130,6 +130,8 @@ def summarise(d, out):
         res[t] = e
     res["_derivation"] = ("mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); wave_* = share of SQ_WAVE_CYCLES; lds_array_busy = SQ_LDS_IDX_ACTIVE / "
                           "(kernel cycles x 256 CUs); separate rocprofv3 --pmc passes per counter set, program directly after '--'")
+    from rga3.utils.fingerprint import tree_fingerprint
+    res["_tree"] = tree_fingerprint()     # bench.py quotes this file only while the running tree has the same fingerprint
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("mfma_busy", "wave_parked", "wave_issue_stalled", "wave_issuing", "lds_array_busy", "lds_conflict_share")}
                       for k, v in res.items() if isinstance(v, dict)}, indent=1))

@@ -12,6 +12,9 @@ import csv
 import glob
 import json
 import sys
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "rga3-release_amd"))
+from rga3.utils.fingerprint import tree_fingerprint
 
 
 def per_kernel(d, counter, needle):
@@ -33,6 +36,7 @@ def main():
            "fetch_bytes_per_launch": 2.0 * 1024.0 * f / max(nf, 1), "write_bytes_per_launch": 1024.0 * w / max(nw, 1),
            "corrections": "KB->B; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); WRITE_SIZE exact; Infinity-Cache hits included"}
     res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
+    res["tree"] = tree_fingerprint()     # bench.py quotes this file only while the running tree has the same fingerprint
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
