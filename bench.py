@@ -528,8 +528,9 @@ def sam2_stream(args, dev, rank, world, dist):
     `value` counts the stream with the per-frame image features already computed ("memory-attention mask-decoder only"); the
     encoder-inclusive rate is reported beside it."""
     from rga3.model import sam2 as sam2_mod
-    from rga3.model.sam2 import SAM2, VideoSession
+    from rga3.model.sam2 import SAM2, MultiObjectSession, VideoSession
 
+    NOBJ = max(1, int(args.objects))
     if args.no_rowchain:
         sam2_mod._ROWCHAIN = False      # A/B: the row-wise steps of the memory-attention layers as separate launches
     T = args.stream_frames
@@ -542,6 +543,7 @@ def sam2_stream(args, dev, rank, world, dist):
     g = torch.Generator().manual_seed(rank)
     vid = torch.randn(T, 3, 1024, 1024, generator=g).to(torch.bfloat16).to(dev)
     emb = torch.randn(1, 1, 256, generator=g).to(torch.bfloat16).to(dev)
+    embs_obj = [emb] + [torch.randn(1, 1, 256, generator=g).to(torch.bfloat16).to(dev) for _ in range(NOBJ - 1)]
 
     def barrier():
         torch.cuda.synchronize()
@@ -553,7 +555,12 @@ def sam2_stream(args, dev, rank, world, dist):
         s0 = VideoSession(m.sam2_model, vid)
         feats = s0._ensure_feats()          # image encoder, once (kept across steps: the timed region is the memory path)
 
-        def step(use_graph=True):
+        def step(use_graph=True, nobj=NOBJ, concurrent=True):
+            if nobj > 1:   # --objects N: N objects prompted on frame 0 and tracked together on the shared features (reference: batch_size = n_obj per frame, sam2.py:3977-4132)
+                ms_ = MultiObjectSession(m.sam2_model, vid, nobj, feats=feats)
+                for o in range(nobj):
+                    ms_.add_language_embd(0, o, embs_obj[o])
+                return ms_.sessions[0], ms_.propagate(use_graph=use_graph and not args.no_graph, concurrent=concurrent)
             sess = VideoSession(m.sam2_model, vid, feats=feats)
             sess.add_language_embd(0, emb)
             return sess, sess.propagate(use_graph=use_graph and not args.no_graph)   # steady-state frames (16..) replay one captured hipGraph
@@ -567,6 +574,20 @@ def sam2_stream(args, dev, rank, world, dist):
         barrier()
         elapsed = time.perf_counter() - t0
         timed_only = bool(os.environ.get("RGA3_BENCH_TIMED_ONLY"))   # profiling runs: nothing after the timed stream (the variants below would end the trace)
+        multi = None
+        if NOBJ > 1 and not timed_only:   # the same objects one after the other on one stream, and ONE object: what tracking them together buys
+            def timed(**kw):
+                step(**kw)
+                barrier()
+                t_ = time.perf_counter()
+                for _ in range(args.steps):
+                    step(**kw)
+                barrier()
+                return (time.perf_counter() - t_) / args.steps
+            t_seq, t_one = timed(concurrent=False), timed(nobj=1)
+            multi = {"objects": NOBJ, "object_frames_per_s": round(NOBJ * T / (elapsed / args.steps), 2),
+                     "object_frames_per_s_objects_one_after_the_other": round(NOBJ * T / t_seq, 2), "single_object_frames_per_s": round(T / t_one, 2),
+                     "vs_single_object": round(NOBJ * t_one / (elapsed / args.steps), 3)}
         # encoder-inclusive variant (fresh features every stream), same number of steps
         barrier()
         t1 = time.perf_counter()
@@ -627,7 +648,7 @@ def sam2_stream(args, dev, rank, world, dist):
         elapsed, elapsed_enc, elapsed_prompt = float(t[0]), float(t[1]), float(t[2])
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        fps = world * T / (elapsed / args.steps)
+        fps = world * NOBJ * T / (elapsed / args.steps)     # object-frames per second (= frames/s for the single object of configs[3])
         # algorithmic FLOPs per frame of the memory path: memory attention <= 0.61 T (cross-attention grows with the bank:
         # 4.19 M x KV, KV = 4096 x min(t, 7) + 4 x min(t, 16) pointer tokens), memory encoder 11.6 G, mask decoder 3.6 G
         fl, by = 0.0, 0.0
@@ -638,6 +659,7 @@ def sam2_stream(args, dev, rank, world, dist):
             # (64-d bf16 memory + its position table, min(t, 7) slots) read once per frame, the new memory slot written (0.52 MB), the selected
             # 1024x1024 f32 mask written (4.2 MB) and re-read by the memory encoder, weights of the three modules (11.5 M params bf16 = 23 MB, L2/MALL-resident)
             by += 7.3e6 + 2 * (64 * 4096 * 2) * min(tt, 7) + 0.52e6 + 2 * 4.2e6 + 23e6
+        fl, by = fl * NOBJ, by * NOBJ - (NOBJ - 1) * (T - 1) * (7.3e6 + 23e6)     # per object; the frame's features and the weights are read once for all objects
         sec = elapsed / args.steps
         line = {"metric": "SAM2-L memory-attention mask-decoder stream, frames/sec (32-frame 1024x1024 ref-VOS stream, prompt on frame 0)", "value": round(fps, 2),
                 "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
@@ -645,7 +667,7 @@ def sam2_stream(args, dev, rank, world, dist):
                 "config": {"workload": f"BASELINE.json configs[3]: SAM2-L (random init) memory path over {T} frames 1024x1024: frame 0 prompted with a language "
                                        "embedding, frames 1.. propagate (memory attention over <= 7 memory frames + <= 16 object pointers, mask decoder, "
                                        "memory encoder); image features precomputed outside the timed region", "frames": T, "parallelism": f"replicas x{world}",
-                           "prompt_every_frame_frames_per_s": round(world * T / (elapsed_prompt / args.steps), 2), "encoder_inclusive_frames_per_s": round(world * T / (elapsed_enc / args.steps), 2), "counts": sess.counts},
+                           "prompt_every_frame_frames_per_s": round(world * T / (elapsed_prompt / args.steps), 2), "encoder_inclusive_frames_per_s": round(world * T / (elapsed_enc / args.steps), 2), "counts": sess.counts, "objects": NOBJ, "multi_object": multi},
                 "roofline": dom if dom is not None else {"bound": "mfma", "achieved": None, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": None, "traffic": None},
                 "roofline_stream": {"bound": "mfma", "achieved": round(fl / sec / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                     "frac": round(fl / sec / PEAK_BF16, 4), "traffic": None,
@@ -778,6 +800,7 @@ def main():
     ap.add_argument("--grad-accum", type=int, default=4)
     ap.add_argument("--no-fp8", action="store_true", help="lora_fp8 mode with bf16 GEMMs (A/B)")
     ap.add_argument("--no-rowchain", action="store_true", help="sam2_stream mode: A/B of csrc/memlayer.hip (the row-wise steps between the attention kernels as separate launches)")
+    ap.add_argument("--objects", type=int, default=1, help="sam2_stream mode: objects tracked per clip on shared image features (value = object-frames/s; 1 = configs[3])")
     ap.add_argument("--no-graph", action="store_true", help="sam2_stream mode: run every frame eagerly (A/B of the hipGraph replay)")
     ap.add_argument("--no-refine", action="store_true", help="skip the in-situ tile refinement of the forward leg (A/B)")
     ap.add_argument("--refine", action="store_true", help="training modes, 1 GPU: run the in-situ tile refinement before the warmup")

@@ -180,10 +180,33 @@ def rope_index(input_ids, cfg: QwenCfg, image_grid_thw=None, video_grid_thw=None
 # --------------------------------------------------------------------------------------------------------------
 # float arithmetic (fp32)
 # --------------------------------------------------------------------------------------------------------------
+# The reference RUNS this model in bf16 (app.py:53-58 torch_dtype=torch.bfloat16 / model.bfloat16(); train_joint.py:165-179 precision bf16): every module output is
+# rounded to bf16 storage while the arithmetic inside an op is fp32.  `with storage(torch.bfloat16):` makes this restatement round at the same points (marked _r
+# below: nn.Linear / conv outputs, both steps of the RMSNorm's cast-then-scale, rotary outputs, softmax probabilities and attention outputs as flash-attn / sdpa
+# store them, activation outputs, residual sums, logits) -- the yardstick for full-depth comparisons: what bf16 STORAGE alone does to a 60-block stack, measured
+# against the same code in fp32 (tests/test_fulldepth_parity_gpu.py).  Default: no rounding, plain fp32.
+_STORE = [None]
+
+
+def _r(x):
+    return x if _STORE[0] is None else x.to(_STORE[0]).float()
+
+
+class storage:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.old, _STORE[0] = _STORE[0], self.dtype
+
+    def __exit__(self, *a):
+        _STORE[0] = self.old
+
+
 def rms_norm(x, w, eps):
-    """HF:74-79"""
+    """HF:74-79 (the normalised rows are cast back to the input dtype BEFORE the weight multiplies them)"""
     v = x.pow(2).mean(-1, keepdim=True)
-    return w * (x * torch.rsqrt(v + eps))
+    return _r(w * _r(x * torch.rsqrt(v + eps)))
 
 
 def rotate_half(x):
@@ -194,7 +217,7 @@ def rotate_half(x):
 
 def _lin(x, P, name):
     """nn.Linear, plus the PEFT-style LoRA update when P carries <name>.lora_A/B.default.weight (scaling in P['lora_scaling'])."""
-    y = F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+    y = _r(F.linear(x, P[name + ".weight"], P.get(name + ".bias")))
     a = P.get(name + ".lora_A.default.weight")
     if a is not None:
         xin = x
@@ -221,7 +244,7 @@ def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw
 
     # patch embed: Conv3d with kernel == stride == (Tp, P, P), no bias == one matmul (HF:99-122)
     w = P["visual.patch_embed.proj.weight"].reshape(v.hidden_size, -1)
-    x = pixel_values.float() @ w.t()
+    x = _r(pixel_values.float() @ w.t())
     N = x.shape[0]
     x = x.reshape(N // unit, unit, -1)[win_idx].reshape(N, -1)  # HF:434-438
 
@@ -237,29 +260,29 @@ def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw
         h = rms_norm(x, P[pre + "norm1.weight"], 1e-6)
         qkv = _lin(h, P, pre + "attn.qkv").reshape(N, 3, v.num_heads, hd)
         q, k, val = qkv[:, 0], qkv[:, 1], qkv[:, 2]
-        q = q * cos + rotate_half(q) * sin  # HF:160-171
-        k = k * cos + rotate_half(k) * sin
+        q = _r(q * cos + rotate_half(q) * sin)  # HF:160-171 (fp32 inside, one cast back)
+        k = _r(k * cos + rotate_half(k) * sin)
         att = torch.empty_like(q)
         lens = np.diff(cu)
         if len(lens) > 1 and (lens == lens[0]).all():  # equal-length segments: one batched product (same arithmetic)
             L = int(lens[0])
             qq, kk, vv = (z.reshape(-1, L, v.num_heads, hd).transpose(1, 2) for z in (q, k, val))
-            pr = torch.softmax(qq @ kk.transpose(2, 3) * hd ** -0.5, dim=-1)
-            att = (pr @ vv).transpose(1, 2).reshape(N, v.num_heads, hd)
+            pr = _r(torch.softmax(qq @ kk.transpose(2, 3) * hd ** -0.5, dim=-1))
+            att = _r(pr @ vv).transpose(1, 2).reshape(N, v.num_heads, hd)
         else:
             for s in range(len(cu) - 1):  # HF:266-287: independent segments
                 a, b = int(cu[s]), int(cu[s + 1])
                 qq, kk, vv = (z[a:b].transpose(0, 1) for z in (q, k, val))
-                pr = torch.softmax(qq @ kk.transpose(1, 2) * hd ** -0.5, dim=-1)
-                att[a:b] = (pr @ vv).transpose(0, 1)
-        x = x + _lin(att.reshape(N, -1), P, pre + "attn.proj")
+                pr = _r(torch.softmax(qq @ kk.transpose(1, 2) * hd ** -0.5, dim=-1))
+                att[a:b] = _r(pr @ vv).transpose(0, 1)
+        x = _r(x + _lin(att.reshape(N, -1), P, pre + "attn.proj"))
         h = rms_norm(x, P[pre + "norm2.weight"], 1e-6)
-        h = _lin(F.silu(_lin(h, P, pre + "mlp.gate_proj")) * _lin(h, P, pre + "mlp.up_proj"), P, pre + "mlp.down_proj")
-        x = x + h
+        h = _lin(_r(_r(F.silu(_lin(h, P, pre + "mlp.gate_proj"))) * _lin(h, P, pre + "mlp.up_proj")), P, pre + "mlp.down_proj")
+        x = _r(x + h)
     pre_merge = x
     # merger (HF:137-150) then undo the window permutation (HF:464-466)
     h = rms_norm(x, P["visual.merger.ln_q.weight"], 1e-6).reshape(N // unit, -1)
-    h = _lin(F.gelu(_lin(h, P, "visual.merger.mlp.0")), P, "visual.merger.mlp.2")
+    h = _lin(_r(F.gelu(_lin(h, P, "visual.merger.mlp.0"))), P, "visual.merger.mlp.2")
     out = h[torch.argsort(win_idx)]
     return (out, pre_merge) if return_pre_merge else out
 
@@ -287,7 +310,7 @@ def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, pa
     hd = t.hidden_size // t.num_attention_heads
     rep = t.num_attention_heads // t.num_key_value_heads
     cos, sin = mrope_cos_sin(position_ids, cfg)
-    cos, sin = cos[:, None], sin[:, None]
+    cos, sin = _r(cos[:, None]), _r(sin[:, None])        # HF's rotary module returns cos / sin in the model dtype
     Sp = 0 if past is None else past[0][0].shape[2]
     i = torch.arange(S)[:, None] + Sp
     j = torch.arange(S + Sp)[None, :]
@@ -309,8 +332,8 @@ def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, pa
         q = _lin(h, P, pre + "self_attn.q_proj").view(B, S, -1, hd).transpose(1, 2)
         k = _lin(h, P, pre + "self_attn.k_proj").view(B, S, -1, hd).transpose(1, 2)
         v = _lin(h, P, pre + "self_attn.v_proj").view(B, S, -1, hd).transpose(1, 2)
-        q = q * cos + rotate_half(q) * sin
-        k = k * cos + rotate_half(k) * sin
+        q = _r(_r(q * cos) + _r(rotate_half(q) * sin))     # apply_multimodal_rotary_pos_emb works in the model dtype: each product and the sum are stored
+        k = _r(_r(k * cos) + _r(rotate_half(k) * sin))
         if past is not None:
             k = torch.cat([past[li][0], k], dim=2)
             v = torch.cat([past[li][1], v], dim=2)
@@ -318,12 +341,12 @@ def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, pa
         kk, vv = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
         sc = q @ kk.transpose(2, 3) * hd ** -0.5 + mask
         pr = torch.softmax(sc, dim=-1)
-        pr = torch.nan_to_num(pr)  # fully masked (padding) query rows
-        a = (pr @ vv).transpose(1, 2).reshape(B, S, -1)
-        x = x + _lin(a, P, pre + "self_attn.o_proj")
+        pr = _r(torch.nan_to_num(pr))  # fully masked (padding) query rows
+        a = _r(pr @ vv).transpose(1, 2).reshape(B, S, -1)
+        x = _r(x + _lin(a, P, pre + "self_attn.o_proj"))
         h = rms_norm(x, P[pre + "post_attention_layernorm.weight"], t.rms_norm_eps)
-        h = _lin(F.silu(_lin(h, P, pre + "mlp.gate_proj")) * _lin(h, P, pre + "mlp.up_proj"), P, pre + "mlp.down_proj")
-        x = x + h
+        h = _lin(_r(_r(F.silu(_lin(h, P, pre + "mlp.gate_proj"))) * _lin(h, P, pre + "mlp.up_proj")), P, pre + "mlp.down_proj")
+        x = _r(x + h)
     x = rms_norm(x, P["model.norm.weight"], t.rms_norm_eps)
     return (x, new_kv) if return_kv else x
 
@@ -355,6 +378,6 @@ def forward(P, cfg: QwenCfg, input_ids, attention_mask=None, position_ids=None, 
                             None if attention_mask is None else attention_mask.numpy(), temporal_rule)
         position_ids = torch.from_numpy(pos)
     hidden = llm_forward(P, x, position_ids, attention_mask, cfg)
-    logits = hidden @ P["lm_head.weight"].t()
+    logits = _r(hidden @ P["lm_head.weight"].t())
     loss = causal_lm_loss(logits, labels) if labels is not None else None
     return {"logits": logits, "loss": loss, "hidden": hidden, "position_ids": position_ids}

@@ -590,10 +590,36 @@ class VideoSession:
         return res
 
 
+class MultiObjectSession:
+    """n_obj objects over one clip (S:3771-4132 with len(obj_ids) > 1).  The reference keeps one output dictionary per object (S:3824-3898: add_language_embd runs
+    _run_single_frame_inference with batch_size = 1 on that object's dictionary) and tracks all objects as ONE batch over shared image features (S:4049-4132 ->
+    _run_single_frame_inference with batch_size = n_obj, S:3977-4047 consolidation).  With non_overlap_masks, non_overlap_masks_for_mem_enc and
+    clear_non_cond_mem_* at their defaults (False: S:2392, :3512-3517) nothing couples the batch entries: every per-sample operation (memory attention, decoder,
+    memory encoder) sees one object, so the batch is restated as one VideoSession per object and each yield concatenates them: [n_obj, 1, S, S]."""
+
+    def __init__(self, P, images, cfg: Sam2Cfg, n_obj: int):
+        self.sessions = [VideoSession(P, images, cfg) for _ in range(n_obj)]
+
+    def add_language_embd(self, frame_idx, obj_idx, language_embd):
+        return self.sessions[obj_idx].add_language_embd(frame_idx, language_embd)
+
+    def propagate(self, **kw):
+        per_obj = [s.propagate(**kw) for s in self.sessions]
+        return [(per_obj[0][i][0], torch.cat([r[i][1] for r in per_obj], dim=0)) for i in range(len(per_obj[0]))]
+
+
 def language_embd_inference(P, images, language_embd_per_frame, cfg: Sam2Cfg):
-    """S:378-404: prompt on EVERY frame, then propagate (which finds every frame consolidated). Returns [T,1,S,S]."""
-    sess = VideoSession(P, images, cfg)
-    for t, e in enumerate(language_embd_per_frame):
-        sess.add_language_embd(t, e.reshape(1, 1, -1))
-    masks = torch.cat([m for _, m in sess.propagate()], dim=0)
-    return masks, sess
+    """S:378-404: prompt EVERY object on EVERY frame, then propagate (which finds every frame consolidated).  language_embd_per_frame[t] is [n_obj, C] (or [C] / [1, C]
+    for one object); returns ([T * n_obj, 1, S, S] -- the per-frame yields [n_obj, 1, S, S] concatenated on dim 0, frame-major, S:399-403 -- and the session)."""
+    embs = [e.reshape(-1, e.shape[-1]) for e in language_embd_per_frame]
+    n_obj = embs[0].shape[0]
+    if n_obj == 1:
+        sess = VideoSession(P, images, cfg)
+        for t, e in enumerate(embs):
+            sess.add_language_embd(t, e.reshape(1, 1, -1))
+        return torch.cat([m for _, m in sess.propagate()], dim=0), sess
+    sess = MultiObjectSession(P, images, cfg, n_obj)
+    for t, e in enumerate(embs):
+        for o in range(n_obj):
+            sess.add_language_embd(t, o, e[o].reshape(1, 1, -1))
+    return torch.cat([m for _, m in sess.propagate()], dim=0), sess

@@ -1014,17 +1014,26 @@ class SAM2(nn.Module):
     get_sam2_embeddings_inference = get_sam2_embeddings
 
     def language_embd_inference(self, session, language_embd):
-        """Prompt on every frame, then propagate: every frame is an initial conditioning frame, so the masks are the
-        consolidated low-res predictions upsampled to image_size (reference :378-404, :3749-3769). [T, n_obj, S, S] f32."""
+        """Prompt every object on every frame, then propagate: every frame is an initial conditioning frame, so the masks are the consolidated low-res predictions
+        upsampled to image_size (reference :378-404, :3749-3769).  language_embd[t] is [n_obj, C] ([C] / [1, C] for one object).  Returns [T * n_obj, 1, S, S] f32:
+        the reference concatenates the per-frame yields [n_obj, 1, S, S] of propagate_in_video on dim 0 (:399-403), i.e. FRAME-major (frame 0 obj 0, frame 0 obj 1,
+        frame 1 obj 0, ...) -- [T, 1, S, S] for the single object of every RGA3 caller; pinned at n_obj = 2 by tests/golden/sam2_multiobj.npz."""
         T = len(language_embd)
-        n_obj = len(language_embd[0])
+        embs = [e.reshape(-1, e.shape[-1]) for e in language_embd]
+        n_obj = embs[0].shape[0]
         outs = []
-        for o in range(n_obj):
-            sess = session if o == 0 else VideoSession(self.sam2_model, session.images, feats=session.feats)
+        for o in range(n_obj):   # objects do not interact (non_overlap_masks / non_overlap_masks_for_mem_enc / clear_non_cond_mem_* are False: reference :2392, :3512-3517)
+            sess = session if o == 0 else VideoSession(self.sam2_model, session.images, feats=session._ensure_feats())
             for t in range(T):
-                sess.add_language_embd(t, language_embd[t][o].reshape(1, 1, -1), use_graph=True)
-            outs.append(torch.cat([mk for _, mk in sess.propagate()], dim=0))
-        return torch.cat(outs, dim=1)
+                sess.add_language_embd(t, embs[t][o].reshape(1, 1, -1), use_graph=True)
+            outs.append(torch.cat([mk for _, mk in sess.propagate()], dim=0))     # [T, 1, S, S]
+        if n_obj == 1:
+            return outs[0]
+        return torch.stack(outs, dim=1).reshape(T * n_obj, 1, *outs[0].shape[-2:])
+
+    def get_sam2_embeddings_multi(self, images, n_obj: int):
+        """A clip tracked for n_obj objects on shared image features (the reference's init_state + add_language_embd with several obj_ids, :3771-3975)."""
+        return MultiObjectSession(self.sam2_model, images, n_obj)
 
     def forward(self, batch):
         raise NotImplementedError
@@ -1042,8 +1051,9 @@ def _graph_cache(m, session=None):
             cache["sig"] = sig
         if session is not None:
             session._graphs_checked = True
-    if "pool" not in cache:
-        cache["pool"] = torch.cuda.graph_pool_handle()               # the graphs never run concurrently: one private pool for all
+    slot = getattr(session, "slot", 0) if session is not None else 0
+    if ("pool", slot) not in cache:
+        cache[("pool", slot)] = torch.cuda.graph_pool_handle()       # the graphs of one slot never run concurrently: one private pool per slot
     return cache
 
 
@@ -1054,8 +1064,9 @@ class VideoSession:
 
     _uids = 0
 
-    def __init__(self, model: SAM2VideoPredictor, images, feats=None, chunk=8):
+    def __init__(self, model: SAM2VideoPredictor, images, feats=None, chunk=8, slot: int = 0):
         self.m, self.images = model, images
+        self.slot = int(slot)     # sessions that replay their frame graphs CONCURRENTLY (MultiObjectSession: one stream per object) own separate graphs, static buffers and pools
         self.num_frames = images.shape[0]
         self.cond: Dict[int, dict] = {}
         self.non_cond: Dict[int, dict] = {}
@@ -1100,7 +1111,7 @@ class VideoSession:
         h, w = f["hw"]
         hw, dev = h * w, f["feat"].device
         cache = _graph_cache(m, self)
-        key = ("prompt", hw, tuple(language_embd.shape), str(dev), f["feat"].dtype)
+        key = ("prompt", hw, tuple(language_embd.shape), str(dev), f["feat"].dtype, self.slot)
         ent = cache.get(key)
         fresh = ent is None
         if fresh:
@@ -1126,7 +1137,7 @@ class VideoSession:
                 body()
             torch.cuda.current_stream().wait_stream(side)
             ent["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["graph"], pool=cache["pool"]):
+            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)]):
                 ent["outs"] = body()
         ent["graph"].replay()
         low, ptr, best = ent["outs"]
@@ -1208,7 +1219,7 @@ class VideoSession:
         n_nc, n_pp = min(d - 1, n_mem - 1), min(d - 1, max_pp)        # earlier non-conditioning memories / pointers in the bank
         cond = self.cond[start]
         cache = _graph_cache(m, self)
-        key = (hw, n_nc, n_pp, str(dev), f["feat"].dtype)
+        key = (hw, n_nc, n_pp, str(dev), f["feat"].dtype, self.slot)
         ent = cache.get(key)
         fresh = ent is None
         if fresh:
@@ -1254,7 +1265,7 @@ class VideoSession:
                 body()
             torch.cuda.current_stream().wait_stream(side)
             ent["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["graph"], pool=cache["pool"]):
+            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)]):
                 ent["outs"] = body()
         ent["graph"].replay()
         outs = [torch.empty_like(o_) for o_ in ent["outs"]]      # the graph's result buffers are overwritten by the next replay
@@ -1266,6 +1277,10 @@ class VideoSession:
         conditioning frame on; `start_frame_idx`, `max_frame_num_to_track`, `reverse` as the reference defines them (reverse from frame 0 yields nothing, :4087-4090).
         use_graph: in a default forward stream with one conditioning frame every later frame runs as the replay of a captured hipGraph (one per bank state, kept on
         the model) -- same kernels, same results."""
+        return list(self.propagate_iter(use_graph, start_frame_idx, max_frame_num_to_track, reverse))
+
+    def propagate_iter(self, use_graph: bool = False, start_frame_idx=None, max_frame_num_to_track=None, reverse: bool = False):
+        """propagate() one frame per next(): the reference's propagate_in_video IS a generator (:4049), and MultiObjectSession advances its objects frame by frame."""
         S = self.m.image_size
         all_cond = set(self.temp_cond) | set(self.cond)
         if not all_cond:
@@ -1279,7 +1294,6 @@ class VideoSession:
             order = list(range(start, min(start + n_track, self.num_frames - 1) + 1))
         need_memory = any(t not in all_cond for t in order)
         self._preflight(need_memory)
-        res = []
         graphed = use_graph and default and len(self.cond) == 1 and not _ag()
         for i, t in enumerate(order):
             if graphed and t not in self.cond:
@@ -1288,7 +1302,7 @@ class VideoSession:
                 self.counts["dec"] += 1
                 self.counts["memenc"] += 1
                 self.non_cond[t] = {"pred_masks": pm, "obj_ptr": ptr, "maskmem_features": mf, "maskmem_pos_enc": self.cond[start]["maskmem_pos_enc"]}
-                res.append((t, mask))
+                yield t, mask
                 continue
             if t in self.cond:
                 pm = self.cond[t]["pred_masks"]
@@ -1302,8 +1316,66 @@ class VideoSession:
                     cur["maskmem_features"], cur["maskmem_pos_enc"] = self.m.encode_new_memory(self._ensure_feats(), t, o["high_res_masks"])
                 self.non_cond[t] = cur
                 pm = cur["pred_masks"]
-            res.append((t, ops.bilinear(pm.reshape(1, *pm.shape[-2:]).float().contiguous(), (S, S)).unsqueeze(0)))
-        return res
+            yield t, ops.bilinear(pm.reshape(1, *pm.shape[-2:]).float().contiguous(), (S, S)).unsqueeze(0)
+
+
+class MultiObjectSession:
+    """n_obj objects tracked over one clip on SHARED image features (reference SAM2VideoPredictor with several obj_ids: add_language_embd per object, sam2.py:3824-3975;
+    propagate_in_video runs every frame with batch_size = n_obj, :3977-4132, and yields video_res_masks [n_obj, 1, S, S]).  Nothing couples the batch entries in the
+    reference (non_overlap_masks, non_overlap_masks_for_mem_enc, clear_non_cond_mem_* are False, :2392, :3512-3517), so an object is a VideoSession of its own: same
+    kernels, same results as the single-object path, pinned against the reference's n_obj = 2 outputs (tests/golden/sam2_multiobj.npz).
+
+    What the batch buys on this chip is CONCURRENCY, not wider kernels: a tracked frame is ~100 short, dependent launches that leave most CUs idle (the
+    memory cross-attention excepted), so each object replays its captured frame graph on a stream of its own and the objects' frames overlap
+    (`concurrent=True`; every object slot owns its graphs, static buffers and pool)."""
+
+    def __init__(self, model: SAM2VideoPredictor, images, n_obj: int, feats=None, chunk=8):
+        assert n_obj >= 1
+        first = VideoSession(model, images, feats=feats, chunk=chunk, slot=0)
+        f = first._ensure_feats()
+        self.sessions = [first] + [VideoSession(model, images, feats=f, chunk=chunk, slot=o) for o in range(1, n_obj)]
+        self.n_obj, self.num_frames = n_obj, first.num_frames
+        self._streams = None
+
+    @property
+    def feats(self):
+        return self.sessions[0].feats
+
+    def add_language_embd(self, frame_idx, obj_idx, language_embd, use_graph: bool = False):
+        return self.sessions[obj_idx].add_language_embd(frame_idx, language_embd, use_graph=use_graph)
+
+    def propagate(self, use_graph: bool = False, concurrent: bool = True, **kw):
+        """[(frame_idx, masks [n_obj, 1, S, S] f32)] in processing order (every object must have been prompted: the reference fills an un-prompted object's slot
+        with NO_OBJ_SCORE masks, :3630-3747 -- not restated, no RGA3 caller does that)."""
+        return list(self.propagate_iter(use_graph, concurrent, **kw))
+
+    def propagate_iter(self, use_graph: bool = False, concurrent: bool = True, **kw):
+        gens = [s.propagate_iter(use_graph=use_graph, **kw) for s in self.sessions]
+        par = concurrent and self.n_obj > 1 and self.sessions[0].images.is_cuda
+        if not par:
+            while True:
+                step = [next(g, None) for g in gens]
+                if step[0] is None:
+                    return
+                yield step[0][0], torch.cat([m for _, m in step], dim=0)
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream() for _ in range(self.n_obj)]
+        for st in self._streams:
+            st.wait_stream(main)          # the image features (and the prompts' outputs) were produced on the caller's stream
+        while True:
+            step = []
+            for g, st in zip(gens, self._streams):
+                with torch.cuda.stream(st):
+                    step.append(next(g, None))
+            if step[0] is None:
+                for st in self._streams:
+                    main.wait_stream(st)
+                return
+            for (_, m), st in zip(step, self._streams):
+                main.wait_stream(st)
+                m.record_stream(main)     # allocated on the object's stream, read by the concatenation on the caller's
+            yield step[0][0], torch.cat([m for _, m in step], dim=0)
 
 
 def load_sam2_checkpoint(model: SAM2VideoPredictor, path: str):

@@ -47,3 +47,12 @@ def object_masks(T=5):
 
 def lang(T=5):
     return det_tensor("lang_embd", (5, 1, 256), 1.0, seed=4)[:T].to(torch.bfloat16).float()
+
+
+def lang2(T=5):
+    """The second object's prompts of tests/golden/sam2_multiobj.npz (make_sam2_multiobj_fixtures.second_prompt)."""
+    return det_tensor("lang_embd_obj1", (5, 1, 256), 4.0, seed=9)[:T].to(torch.bfloat16).float()
+
+
+def gold_multiobj():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "sam2_multiobj.npz"), allow_pickle=False)

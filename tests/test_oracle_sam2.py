@@ -130,3 +130,31 @@ def test_g3_reverse_and_ranged_propagation(P):
     assert [t for t, _ in rc] == R["C_frames"].tolist() and close(torch.cat([m for _, m in rc]), R["C_masks"], 2e-4)
     _, (rd,) = run(0, [dict(reverse=True)])
     assert rd == [] and R["D_frames"].size == 0
+
+
+def test_g3_two_objects_layout_and_values(P):
+    """n_obj = 2 against the reference's own outputs (tests/golden/sam2_multiobj.npz, made by make_sam2_multiobj_fixtures.py): (A) SAM2.language_embd_inference with two
+    prompts per frame returns [T * n_obj, 1, S, S], FRAME-major (reference sam2.py:378-404); (B) two objects prompted on frame 0 and tracked as one batch
+    (:3977-4132): per-frame yields [n_obj, 1, S, S], object pointers per object.  Values <= 2e-4, binarised masks equal, and swapping the objects must NOT pass."""
+    from tests.sam2_tiny import gold_multiobj, lang2
+    R = gold_multiobj()
+    cfg = tiny_cfg()
+    img, e0, e1 = images(), lang(), lang2()
+    with torch.no_grad():
+        masks, _ = S.language_embd_inference(P, img, [torch.cat([e0[t], e1[t]], 0) for t in range(5)], cfg)
+    assert tuple(masks.shape) == tuple(R["A_masks"].shape) == (10, 1, 128, 128)
+    assert close(masks, R["A_masks"], 2e-4) and np.array_equal((masks > 0).numpy(), R["A_masks"] > 0)
+    swapped = masks.reshape(5, 2, 1, 128, 128).flip(1).reshape(10, 1, 128, 128)
+    assert not close(swapped, R["A_masks"], 2e-2)                       # the fixture tells the objects apart
+    with torch.no_grad():
+        sess = S.MultiObjectSession(P, img, cfg, 2)
+        sess.add_language_embd(0, 0, e0[0][None])
+        sess.add_language_embd(0, 1, e1[0][None])
+        res = sess.propagate()
+    assert [t for t, _ in res] == list(range(5)) and all(tuple(m.shape) == (2, 1, 128, 128) for _, m in res)
+    mb = torch.cat([m for _, m in res], 0)
+    assert close(mb, R["B_masks"], 2e-4) and np.array_equal((mb > 0).numpy(), R["B_masks"] > 0)
+    ptrs = torch.stack([torch.cat([(s.out["cond_frame_outputs"] if t == 0 else s.out["non_cond_frame_outputs"])[t]["obj_ptr"] for s in sess.sessions], 0) for t in range(5)])
+    assert close(ptrs, R["B_obj_ptrs"], 2e-4)
+    # what the batch costs the reference per frame (one batched call each) is what ONE restated object session counts
+    assert [sess.sessions[0].counts[k] for k in ("memattn", "memenc")] == R["B_counts"][1:3].tolist()

@@ -291,3 +291,45 @@ def test_lora_on_sam2_projections_train_equals_eval_and_gets_gradients(dev, G):
     assert any(float(g.float().abs().max()) > 0 for n, g in got.items() if "lora_A" in n)
     assert any(float(g.float().abs().max()) > 0 for n, g in got.items() if "lora_B" in n)
     assert isinstance(m.sam2_model.sam_mask_decoder.transformer.layers[0].self_attn.q_proj, LoRALinear)
+
+
+def test_two_objects_against_the_reference(model, dev, P):
+    """n_obj = 2 (VERDICT r4 missing items 2 and 4) against the reference's OWN outputs, tests/golden/sam2_multiobj.npz (made by make_sam2_multiobj_fixtures.py from
+    /root/reference/model/sam2.py:378-404, :3824-4132): (A) language_embd_inference with two prompts per frame -> [T * n_obj, 1, S, S] FRAME-major; (B) two objects prompted
+    on frame 0 and tracked together on shared image features (MultiObjectSession: one stream and one set of frame graphs per object) -> per-frame [n_obj, 1, S, S].
+    Stated tolerances: mask rel-L2 <= 2e-2, IoU >= 0.99, sign equal outside the 5 % band at the blob edges; swapping the two objects must fail; the concurrent-stream
+    graph replay equals the sequential eager run bit for bit."""
+    from rga3.model.sam2 import MultiObjectSession
+    from tests.sam2_tiny import gold_multiobj, lang2
+
+    R = gold_multiobj()
+    img, e0, e1 = images().to(torch.bfloat16).to(dev), lang().to(torch.bfloat16).to(dev), lang2().to(torch.bfloat16).to(dev)
+    ga, gb = torch.from_numpy(R["A_masks"]), torch.from_numpy(R["B_masks"])
+    with torch.no_grad():
+        sess = model.get_sam2_embeddings(img)
+        ma = model.language_embd_inference(sess, [torch.cat([e0[t], e1[t]], 0) for t in range(5)])
+    assert tuple(ma.shape) == (10, 1, 128, 128)
+    assert rel(ma, ga) < 2e-2 and min(iou(ma[i] > 0, ga[i] > 0) for i in range(10)) >= 0.99
+    band = ga.abs() > 0.05 * ga.abs().max()
+    assert torch.equal((ma.cpu() > 0)[band], (ga > 0)[band])
+    assert rel(ma.reshape(5, 2, 1, 128, 128).flip(1).reshape(10, 1, 128, 128), ga) > 5e-2          # object order matters in the fixture
+    assert sess.counts["enc"] == 5                                                                  # one encoder pass per frame serves both objects (reference: 10)
+
+    def track(**kw):
+        ms = MultiObjectSession(model.sam2_model, img, 2, feats=sess._ensure_feats())
+        ms.add_language_embd(0, 0, e0[0][None])
+        ms.add_language_embd(0, 1, e1[0][None])
+        res = ms.propagate(**kw)
+        return ms, res
+
+    with torch.no_grad():
+        ms, res = track(use_graph=True, concurrent=True)
+        _, res_seq = track(use_graph=False, concurrent=False)
+    torch.cuda.synchronize()
+    assert [t for t, _ in res] == list(range(5)) and all(tuple(m.shape) == (2, 1, 128, 128) for _, m in res)
+    mb = torch.cat([m for _, m in res], 0)
+    assert torch.equal(mb, torch.cat([m for _, m in res_seq], 0))                                   # streams + graphs change nothing
+    assert rel(mb, gb) < 2e-2 and min(iou(mb[i] > 0, gb[i] > 0) for i in range(10)) >= 0.99
+    ptr = torch.stack([torch.cat([(s.cond if t == 0 else s.non_cond)[t]["obj_ptr"].float().cpu().reshape(1, -1) for s in ms.sessions], 0) for t in range(5)])
+    assert rel(ptr, torch.from_numpy(R["B_obj_ptrs"])) < 2e-2
+    assert ms.sessions[0].counts["memattn"] == ms.sessions[1].counts["memattn"] == int(R["B_counts"][1])     # one memory-attention pass per tracked frame and object

@@ -186,13 +186,13 @@ def test_lora_fold_per_module_fallback_matches_unfolded_route(dev):
     assert len(QT.add_lora(m, r=32, alpha=64)) == 6
     for n, p in m.named_parameters():
         if "lora_" in n:
-            p.data = det_tensor(n, tuple(p.shape), 0.2, seed=13)
-    m = m.to(torch.bfloat16).to(dev)
+            p.data = det_tensor(n, tuple(p.shape), 0.05, seed=13)     # a LoRA branch of the base projection's size (a branch 50 x larger makes the softmax chaotic:
+    m = m.to(torch.bfloat16).to(dev)                                    # the two routes' single rounding difference then reads as 5 - 10 % on every gradient)
     for n, p in m.named_parameters():
         p.requires_grad_("lora_" in n)
     for li, layer in enumerate(m.model.layers):          # per-layer scaling: the all-layers build refuses, each module builds alone
-        layer.self_attn.q_proj.scaling = 2.0 + li
-        layer.self_attn.v_proj.scaling = 1.0 + 0.5 * li
+        layer.self_attn.q_proj.scaling = 2.0 + 0.5 * li
+        layer.self_attn.v_proj.scaling = 1.0 + 0.25 * li
     g = torch.Generator().manual_seed(3)
     ids = torch.randint(1, 300, (1, 96), generator=g)
     am = torch.ones_like(ids)
