@@ -18,13 +18,13 @@
 //    16 B/lane, 128 B contiguous per row; the residual add is fused there with coalesced loads.
 //  * 1-D grid with a bijective XCD remap + grouped tile order so neighbouring tiles share an L2.
 #include "common.h"
+#include "act_table.h"
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
 
 namespace rga3 {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SWIGLU = 2, ACT_RELU = 3 };
 
@@ -88,36 +88,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // while it runs
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// ---- activations of the tile epilogues: table-driven.  The value t fed to GELU / SiLU has just been rounded to bf16 (the reference's bf16 nn.Linear output), so the
-//      activation is a function of 15 magnitude bits:   act(t) = relu(t) - |t| T(|t|),   T_gelu(a) = Phi(-a),  T_silu(a) = sigmoid(-a)   (tools/gen_act_tables.py:
-//      f32 T for every bf16 magnitude in [2^-14, 2^6), 10 KiB; outside the range the clamped entry is exact to < 3e-5 relative / 1e-26 absolute).  Five VALU
-//      slots and one ds_read_b32 per element instead of a quarter-rate v_rcp + v_exp and ten more (A-S erf) or 2 + 3 (sigmoid): the K = 576 GELU product of Hiera
-//      stage 3 was 70 % VALU-busy (profiles/r04_k576_pmc_before.json).  Exact to f32 rounding, including the negative tail's relative accuracy; NaN stays NaN; an
-//      infinite input (an activation that has already overflowed bf16) gives NaN where the closed form gives +inf / -0 (|inf| x the table's final 0).
-#include "act_tables.inc"
-constexpr int kActTabBytes = kActTabN * 4;
-static_assert(kActTabBytes % 1024 == 0, "the table is staged in 1-KiB LDS-DMA pieces");
 template <int ACT> constexpr bool act_uses_table() { return ACT == ACT_GELU || ACT == ACT_SWIGLU; }
 
-typedef const __attribute__((address_space(3))) float lds_cfloat;
-// LDS byte address of the table minus the bytes of the magnitudes below its first entry (wave-uniform; computed once per epilogue)
-__device__ __forceinline__ unsigned act_tab_base(const char* tab) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)tab - kActTabLoBits * 4u; }
-// two activations from a PACKED bf16 pair (what v_cvt_pk_bf16_f32 just produced).  Per element: magnitude (v_and / v_bfe), clamp to the table (v_med3_u32), byte address
-// (v_lshl_add_u32), ds_read_b32, relu as a signed-integer max (no canonicalising v_max_f32 pair), one v_fma_f32 with |t| and the negation as source modifiers (asm:
-// left to itself the compiler pairs two elements into v_pk_fma_f32, which has no |x| modifier, and pays two extra v_and).
-__device__ __forceinline__ f32x2 act_tab2(unsigned pk, unsigned tb) {
-    float y0, y1;
-    constexpr unsigned LO = kActTabLoBits, HI = kActTabLoBits + kActTabN - 1;
-    asm("" : "+v"(pk));   // opaque: the compiler otherwise re-derives the low half by a second, single v_cvt_pk_bf16_f32
-    const unsigned m0 = pk & 0x7fffu, m1 = __builtin_amdgcn_ubfe(pk, 16, 15);
-    const unsigned a0 = (min(max(m0, LO), HI) << 2) + tb, a1 = (min(max(m1, LO), HI) << 2) + tb;
-    const float q0 = *(lds_cfloat*)(size_t)a0, q1 = *(lds_cfloat*)(size_t)a1;
-    const unsigned t0 = pk << 16, t1 = pk & 0xffff0000u;
-    const int r0 = max((int)t0, 0), r1 = max((int)t1, 0);
-    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y0) : "v"(t0), "v"(q0), "v"(r0));
-    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y1) : "v"(t1), "v"(q1), "v"(r1));
-    return f32x2{y0, y1};
-}
 // (s, s) in a REAL register pair.  Left to itself the compiler broadcasts a scalar into packed-f32 operations through op_sel (one half of a pair feeding both lanes of
 // the operation); the epilogue form  v_pk_mul_f32 t, c, v[n:n+1] op_sel_hi:[1,0]  +  v_pk_fma_f32 d, acc, v[m:m+1], t op_sel:[0,1,0]  returned d.lo WITHOUT the product term in
 // lanes 48-63 of a few percent of the waves when two workgroups shared a CU (MI355X, ROCm 7.2; timing-dependent, never with one workgroup per CU; the element-wise and

@@ -1,13 +1,14 @@
-// Fused MLP of a Hiera stage-1 block (reference model/sam2.py:1035-1117 MultiScaleBlock.forward: x = x + mlp(norm2(x)); MLP :2305-2329, dim 144 -> 576 -> 144, exact-erf
-// GELU) for the frozen SAM2-L trunk:   y = x + W2 gelu(W1 LayerNorm(x) + b1) + b2   in ONE launch.
+// Fused MLP of a Hiera block (reference model/sam2.py:1035-1117 MultiScaleBlock.forward: x = x + mlp(norm2(x)); MLP :2305-2329, dim C -> 4 C -> C, exact-erf GELU) for
+// the frozen SAM2-L trunk:   y = x + W2 gelu(W1 LayerNorm(x) + b1) + b2   in ONE launch, for stage 1 (C = 144, 65 536 tokens per 1024^2 frame) and stage 2 (C = 288,
+// 16 384 tokens per frame, blocks 2 - 7).
 //
-// Why: at stage 1 a 1024^2 frame is 65 536 tokens x 144 channels; as two GEMMs the 576-wide hidden activation of 16 frames (1.2 GB) is written and read back, and
-// both products run HBM-bound at 2 - 3.8 TB/s (fc1 + GELU 0.73 ms, fc2 0.48 ms per block and 16 frames, profiles/r02_train_gemm_shapes.txt).  Fused, the hidden
-// activation never leaves the CU: HBM traffic is x in + y out (0.6 GB), and the LayerNorm statistics pass disappears as well (a workgroup holds whole rows).
+// Why: as two GEMMs the 4 C-wide hidden activation (1.2 GB at stage 1, 604 MB per stage-2 block and 16 frames) is written and read back and both products run
+// HBM-bound at 2 - 3.8 TB/s (stage 1) or at a third of the matrix peak on K = 288 tiles (stage 2).  Fused, the hidden activation never leaves the CU: HBM traffic is
+// x in + y out, and the LayerNorm statistics pass disappears as well (a wave holds whole rows).
 //
 // Dataflow -- "tokens on the lanes": every product is computed TRANSPOSED with v_mfma_f32_32x32x16_bf16 so that the activations are always the B operand and the
 // weights the A operand read from LDS:
-//     H^T[hidden, tok] = W1'[hidden, ch] . X^T[ch, tok]        X^T fragments live in registers for the whole kernel (9 k-steps x 4 VGPRs per 32 tokens)
+//     H^T[hidden, tok] = W1'[hidden, ch] . X^T[ch, tok]        X^T fragments live in registers for the whole kernel (C / 16 k-steps x 4 VGPRs per 32 tokens)
 //     Y^T[ch, tok]    += W2[ch, hidden]  . G^T[hidden, tok]     G = gelu(LN-fold(H)) taken STRAIGHT from H's accumulator registers: a 32 x 32 result has its
 //                                                               column (token) on the lane and its rows (hidden) in the 16 registers, so registers 8s .. 8s+7,
 //                                                               rounded to bf16, are k-step s of the next B operand with the k order permuted (cdna_hip_programming.md
@@ -15,234 +16,382 @@
 //                                                               (two ds_read_b64 per fragment).  No LDS round trip, no barrier between the two products.
 // LayerNorm is folded as in rga3_gemm_ln_bf16: W1' = W1 diag(gamma) (bf16), h = rinv (acc - mean c_n) + d_n with c = row sums of W1', d = beta W1^T + b1; mean / rinv
 // of a token are lane-local (each half-wave holds half of its row, one exchange).
-// Workgroup = 8 waves x 32 tokens; the 576 hidden units stream through LDS in 9 chunks of 64 (W1' chunk 64 x 144, W2 chunk 144 x 64, their c / d), register-staged
-// double buffer, one barrier per chunk; per chunk and wave 18 + 20 MFMAs against 38 KiB of LDS fragment reads (LDS array at ~50 %).  LDS images: W1' rows padded to
-// 304 B (19 x 16 B, odd: conflict-free ds_read_b128), W2 rows to 136 B (34 dwords: the 32 rows of a half-wave's ds_read_b64 tile all 64 banks).  The output tile is
-// transposed through LDS so that y leaves in whole 288-byte rows.
+// GELU is the tile epilogues' table form (act_table.h: the linear output has just been rounded to bf16, so gelu(t) = relu(t) - |t| Phi(-|t|) with Phi read from a
+// 10-KiB LDS table: five full-rate vector instructions and one ds_read_b32 per element; the closed form -- v_rcp, v_exp and ten more -- made the kernel vector-ALU
+// bound: 32 values x ~80 cycles per chunk and wave against 1 216 cycles of MFMA).
+//
+// C = 144: workgroup = 8 waves x 32 tokens (two waves per SIMD cover each other's vector phases); the 576 hidden units stream through LDS in 9 chunks of 64.
+// C = 288: X^T (72) + Y^T (144) + H (2 x 16) registers per lane do not fit 256: 4 waves x 32 tokens, ONE wave per SIMD on the 512-register budget, hidden chunks of 32;
+//          the first product of chunk n + 1 is issued before the GELU of chunk n (software pipeline over two accumulator sets), so that the lone wave's vector work
+//          sits between independent MFMAs.
+// Weight chunks (W1' chunk HC x C, W2 chunk C x HC, their c / d) are register-staged into a double buffer, one barrier per chunk.  LDS images: W1' rows padded to
+// 2 C + 16 B (an odd number of 16-byte slots: conflict-free ds_read_b128), W2 rows to 2 HC + 8 B (34 / 18 dwords: the 32 rows of a half-wave's ds_read_b64 tile
+// all 64 banks).  The output tile is transposed through LDS so that y leaves in whole rows.
 #include "common.h"
+#include "act_table.h"
 
 namespace rga3 {
 
-constexpr int HM_C = 144, HM_H = 576, HM_TOK = 256, HM_HC = 64;
-constexpr int HM_KS = HM_C / 16;                       // 9 k-steps of the first product
-constexpr int HM_CB = 5;                               // channel blocks of 32 (144 -> 160: rows 144..159 are never stored)
-constexpr int HM_W1STR = HM_C * 2 + 16;                // 304 B
-constexpr int HM_W2STR = HM_HC * 2 + 8;                // 136 B
-constexpr int HM_W1B = HM_HC * HM_W1STR;               // 19 456
-constexpr int HM_W2B = HM_CB * 32 * HM_W2STR;          // 21 760
-constexpr int HM_STAGE = HM_W1B + HM_W2B + HM_HC * 8;  // + c (f32) and d (f32) of the chunk = 41 728
-constexpr int HM_OSTR = HM_C * 2 + 16;                 // output tile rows (304 B)
-constexpr int HM_LDS = 2 * HM_STAGE;                   // 83 456 >= 256 * 304 = 77 824 (the output tile reuses it)
-
-__device__ __forceinline__ float hm_gelu_erf(float x) {   // the GEMM epilogue's arithmetic (gemm_bf16.hip gelu_erf): Abramowitz-Stegun 7.1.26
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float e = 1.0f - poly * t * __expf(-z * z);
-    return 0.5f * x + 0.5f * fabsf(x) * e;
-}
+template <int C_, int NW_, int HC_, int NSTG_>
+struct HmCfg {
+    static constexpr int C = C_, NW = NW_, HC = HC_, NSTG = NSTG_;   // NSTG: LDS stages of weight chunks (2: double buffer; 3: the pipelined form's ring)
+    static constexpr int H = 4 * C, NT = 64 * NW, TOK = 32 * NW;
+    static constexpr int KS = C / 16;                          // k-steps of the first product
+    static constexpr int CB = (C + 31) / 32;                   // channel blocks of 32 (144 -> 160: rows 144..159 are never stored)
+    static constexpr int NHB = HC / 32;                        // hidden blocks of 32 per chunk
+    static constexpr int W1STR = C * 2 + 16, W2STR = HC * 2 + 8;
+    static constexpr int W1B = HC * W1STR, W2B = CB * 32 * W2STR;
+    static constexpr int STAGE = W1B + W2B + HC * 8;           // + c (f32) and d (f32) of the chunk
+    static constexpr int OSTR = C * 2 + 16;                    // output tile rows
+    static constexpr int TAB = NSTG * STAGE;                   // activation table behind the stages
+    static constexpr int LDS = NSTG * STAGE + kActTabBytes;
+    static constexpr int W1P = HC * (C / 8), W2P = C * (HC / 8);   // 16-byte pieces of a chunk
+    static constexpr int NJ1 = (W1P + NT - 1) / NT, NJ2 = (W2P + NT - 1) / NT;
+    static constexpr int NCH = H / HC;
+    static_assert(C % 16 == 0 && HC % 32 == 0 && H % HC == 0 && STAGE % 16 == 0 && NSTG * STAGE >= TOK * OSTR && 2 * HC <= NT && LDS <= 160 * 1024, "hiera_mlp: configuration");
+};
 
 struct HmArgs {
-    const unsigned short* x;     // [M, 144] bf16
-    const unsigned short* w1f;   // [576, 144] bf16 = W1 diag(gamma)
-    const float* c1;             // [576] row sums of w1f
-    const unsigned short* d1;    // [576] bf16 folded bias
-    const unsigned short* w2;    // [144, 576] bf16
-    const unsigned short* b2;    // [144] bf16
-    unsigned short* y;           // [M, 144] bf16
+    const unsigned short* x;     // [M, C] bf16
+    const unsigned short* w1f;   // [4C, C] bf16 = W1 diag(gamma)
+    const float* c1;             // [4C] row sums of w1f
+    const unsigned short* d1;    // [4C] bf16 folded bias
+    const unsigned short* w2;    // [C, 4C] bf16
+    const unsigned short* b2;    // [C] bf16
+    unsigned short* y;           // [M, C] bf16
     long M;
     float eps;
 };
 
-__global__ __launch_bounds__(512) void hiera_mlp144_kernel(HmArgs p) {
+template <class K, bool PIPE>
+__global__ __launch_bounds__(K::NT) void hiera_mlp_kernel(HmArgs p) {
+    constexpr int C = K::C, HC = K::HC, KS = K::KS, CB = K::CB, NHB = K::NHB, NT = K::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const long tok0 = (long)blockIdx.x * HM_TOK;
+    const long tok0 = (long)blockIdx.x * K::TOK;
     const long tok = tok0 + wave * 32 + r;
     const long tokc = tok < p.M ? tok : p.M - 1;
 
     // ---- this wave's 32 tokens as B operands: lane (r, h) holds x[tok][16 ks + 8 h .. + 8]
-    bf16x8 xf[HM_KS];
+    bf16x8 xf[KS];
     {
-        const unsigned short* xr = p.x + tokc * HM_C + 8 * h;
+        const unsigned short* xr = p.x + tokc * C + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < HM_KS; ++ks) xf[ks] = *(const bf16x8*)(xr + 16 * ks);
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const bf16x8*)(xr + 16 * ks);
     }
     // ---- LayerNorm statistics of the token (two passes over the register-resident half row, halves exchanged)
-    float mean, rinv;
+    float rinv, nmr;     // h = rinv acc + (d - mean rinv c)
     {
         float s = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < HM_KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += (float)xf[ks][e];
         s += __shfl_xor(s, 32, 64);
-        mean = s * (1.0f / HM_C);
+        const float mean = s * (1.0f / C);
         float q = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < HM_KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float d = (float)xf[ks][e] - mean;
                 q += d * d;
             }
         q += __shfl_xor(q, 32, 64);
-        rinv = __builtin_amdgcn_rsqf(q * (1.0f / HM_C) + p.eps);
+        rinv = __builtin_amdgcn_rsqf(q * (1.0f / C) + p.eps);
+        nmr = -mean * rinv;
     }
 
     // ---- weight chunk staging: HBM / L2 -> registers -> LDS
-    u32x4 w1r[3], w2r[3];
+    u32x4 w1r[K::NJ1], w2r[K::NJ2];
     float cr = 0.f;
     auto load_chunk = [&](int ch) {
-        const int n0 = ch * HM_HC;
+        const int n0 = ch * HC;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int idx = tid + j * 512;
-            if (idx < HM_HC * 18) {            // W1' rows n0 .. n0 + 63, 18 chunks of 16 B each
-                const int row = idx / 18, c16 = idx % 18;
-                w1r[j] = *(const u32x4*)(p.w1f + (long)(n0 + row) * HM_C + c16 * 8);
-            }
-            if (idx < HM_C * 8) {              // W2 rows 0 .. 143, columns n0 .. n0 + 63: 8 chunks of 16 B each
-                const int row = idx >> 3, c16 = idx & 7;
-                w2r[j] = *(const u32x4*)(p.w2 + (long)row * HM_H + n0 + c16 * 8);
+        for (int j = 0; j < K::NJ1; ++j) {
+            const int idx = tid + j * NT;
+            if (idx < K::W1P) {                // W1' rows n0 .. n0 + HC - 1, C / 8 chunks of 16 B each
+                const int row = idx / (C / 8), c16 = idx % (C / 8);
+                w1r[j] = *(const u32x4*)(p.w1f + (long)(n0 + row) * C + c16 * 8);
             }
         }
-        if (tid < HM_HC) cr = p.c1[n0 + tid];
-        else if (tid < 2 * HM_HC) cr = bf2f(p.d1[n0 + tid - HM_HC]);
+#pragma unroll
+        for (int j = 0; j < K::NJ2; ++j) {
+            const int idx = tid + j * NT;
+            if (idx < K::W2P) {                // W2 rows 0 .. C - 1, columns n0 .. n0 + HC - 1: HC / 8 chunks of 16 B each
+                const int row = idx / (HC / 8), c16 = idx % (HC / 8);
+                w2r[j] = *(const u32x4*)(p.w2 + (long)row * K::H + n0 + c16 * 8);
+            }
+        }
+        if (tid < HC) cr = p.c1[n0 + tid];
+        else if (tid < 2 * HC) cr = bf2f(p.d1[n0 + tid - HC]);
     };
     auto store_chunk = [&](int buf) {
-        char* base = smem + buf * HM_STAGE;
+        char* base = smem + buf * K::STAGE;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int idx = tid + j * 512;
-            if (idx < HM_HC * 18) *(u32x4*)(base + (idx / 18) * HM_W1STR + (idx % 18) * 16) = w1r[j];
-            if (idx < HM_C * 8) {
-                // a 16-byte chunk of a 136-byte row is only 8-byte aligned: two 8-byte stores
-                char* d = base + HM_W1B + (idx >> 3) * HM_W2STR + (idx & 7) * 16;
+        for (int j = 0; j < K::NJ1; ++j) {
+            const int idx = tid + j * NT;
+            if (idx < K::W1P) *(u32x4*)(base + (idx / (C / 8)) * K::W1STR + (idx % (C / 8)) * 16) = w1r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < K::NJ2; ++j) {
+            const int idx = tid + j * NT;
+            if (idx < K::W2P) {
+                // a 16-byte chunk of a (2 HC + 8)-byte row is only 8-byte aligned: two 8-byte stores
+                char* d = base + K::W1B + (idx / (HC / 8)) * K::W2STR + (idx % (HC / 8)) * 16;
                 *(u32x2*)d = u32x2{w2r[j][0], w2r[j][1]};
                 *(u32x2*)(d + 8) = u32x2{w2r[j][2], w2r[j][3]};
             }
         }
-        if (tid < 2 * HM_HC) *(float*)(base + HM_W1B + HM_W2B + tid * 4) = cr;
+        if (tid < 2 * HC) *(float*)(base + K::W1B + K::W2B + tid * 4) = cr;
     };
 
-    f32x16 y[HM_CB];
+    f32x16 y[CB];
 #pragma unroll
-    for (int cb = 0; cb < HM_CB; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) y[cb][i] = 0.f;
 
-    // rows 144 .. 159 of the W2 image feed output rows that are never stored: give them zeros once (both buffers) so no NaN pattern wanders through the MFMAs
-    for (int i = tid; i < 2 * 16 * HM_W2STR / 8; i += 512) {
-        const int buf = i / (16 * HM_W2STR / 8), o = i % (16 * HM_W2STR / 8);
-        *(u32x2*)(smem + buf * HM_STAGE + HM_W1B + HM_C * HM_W2STR + o * 8) = u32x2{0u, 0u};
+    if constexpr (CB * 32 > C) {
+        // rows C .. 32 CB - 1 of the W2 image feed output rows that are never stored: give them zeros once (both buffers) so no NaN pattern wanders through the MFMAs
+        constexpr int PADQ = (CB * 32 - C) * K::W2STR / 8;
+        for (int i = tid; i < K::NSTG * PADQ; i += NT) {
+            const int buf = i / PADQ, o = i % PADQ;
+            *(u32x2*)(smem + buf * K::STAGE + K::W1B + C * K::W2STR + o * 8) = u32x2{0u, 0u};
+        }
     }
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    constexpr int NCH = HM_H / HM_HC;
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < NCH) load_chunk(ch + 1);
-        const char* w1s = smem + buf * HM_STAGE;
-        const char* w2s = w1s + HM_W1B;
-        const float* cs = (const float*)(w2s + HM_W2B);      // [64] c, then [64] d
-        // ---- H^T chunk = W1' X^T for both 32-hidden blocks first (18 MFMAs back to back), then per block: LayerNorm fold + GELU + bf16 (vector ALU) followed by its
-        //      share of Y^T += W2 chunk . G^T (10 MFMAs) -- block 1's GELU has no dependence on block 0's MFMAs, so the two pipes can overlap
-        f32x16 acc[2];
+    // the GELU table (10 KiB) behind the two stages
+    for (int i = tid; i < kActTabN; i += NT) *(unsigned*)(smem + K::TAB + i * 4) = g_act_tab[0][i];
+    const unsigned tb = act_tab_base(smem + K::TAB);
+
+    // H^T block hb of the chunk staged in `st`: W1' chunk . X^T
+    auto first_product = [&](f32x16& acc, const char* st, int hb) {
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const char* a0 = st + (hb * 32 + r) * K::W1STR + h * 16;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[hb][i] = 0.f;
-            const char* a0 = w1s + (hb * 32 + r) * HM_W1STR + h * 16;
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(a0 + ks * 32), xf[ks], acc, 0, 0, 0);
+    };
+    // LayerNorm fold + GELU + bf16 on block hb's accumulators (vector ALU), then its share of Y^T += W2 chunk . G^T
+    auto second_product = [&](const f32x16& acc, const char* st, int hb) {
+        const char* w2s = st + K::W1B;
+        const float* cs = (const float*)(w2s + K::W2B);      // [HC] c, then [HC] d
+        bf16x8 gb[2];
+        unsigned pk[8];
 #pragma unroll
-            for (int ks = 0; ks < HM_KS; ++ks) acc[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(a0 + ks * 32), xf[ks], acc[hb], 0, 0, 0);
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 cc = *(const f32x4*)(cs + hb * 32 + 8 * i4 + 4 * h);
+            const f32x4 dd = *(const f32x4*)(cs + HC + hb * 32 + 8 * i4 + 4 * h);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rinv, acc[4 * i4 + e], __builtin_fmaf(nmr, cc[e], dd[e]));
+            // bf16 rounding of the linear output before the activation, as the unfused pair does; gelu from the table on the packed pair
+            const f32x2 g01 = act_tab2(pack_bf2(v[0], v[1]), tb), g23 = act_tab2(pack_bf2(v[2], v[3]), tb);
+            pk[2 * i4] = pack_bf2(g01[0], g01[1]);
+            pk[2 * i4 + 1] = pack_bf2(g23[0], g23[1]);
         }
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            bf16x8 gb[2];
-            float g[16];
+        for (int ss = 0; ss < 2; ++ss) gb[ss] = __builtin_bit_cast(bf16x8, u32x4{pk[4 * ss], pk[4 * ss + 1], pk[4 * ss + 2], pk[4 * ss + 3]});
+        // fragment element j of half h is hidden 16 ss + 8 (j >> 2) + 4 h + (j & 3) of block hb
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const f32x4 cc = *(const f32x4*)(cs + hb * 32 + 8 * i4 + 4 * h);
-                const f32x4 dd = *(const f32x4*)(cs + HM_HC + hb * 32 + 8 * i4 + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = rinv * (acc[hb][4 * i4 + e] - mean * cc[e]) + dd[e];
-                    g[4 * i4 + e] = hm_gelu_erf(bf2f(f2bf(v)));      // bf16 rounding of the linear output before the activation, as the unfused pair does
-                }
-            }
+        for (int cb = 0; cb < CB; ++cb) {
+            const char* a0 = w2s + (cb * 32 + r) * K::W2STR + 8 * h + hb * 64;
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
-                u32x4 pk;
-                pk[0] = pack_bf2(g[8 * ss + 0], g[8 * ss + 1]);
-                pk[1] = pack_bf2(g[8 * ss + 2], g[8 * ss + 3]);
-                pk[2] = pack_bf2(g[8 * ss + 4], g[8 * ss + 5]);
-                pk[3] = pack_bf2(g[8 * ss + 6], g[8 * ss + 7]);
-                gb[ss] = __builtin_bit_cast(bf16x8, pk);
-            }
-            // Y^T += W2 chunk . G^T: fragment element j of half h is hidden 16 ss + 8 (j >> 2) + 4 h + (j & 3) of block hb
-#pragma unroll
-            for (int cb = 0; cb < HM_CB; ++cb) {
-                const char* a0 = w2s + (cb * 32 + r) * HM_W2STR + 8 * h + hb * 64;
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    const char* a = a0 + 32 * ss;
-                    const u32x2 lo = *(const u32x2*)a, hi = *(const u32x2*)(a + 16);
-                    const u32x4 af = {lo[0], lo[1], hi[0], hi[1]};
-                    y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), gb[ss], y[cb], 0, 0, 0);
-                }
+                const char* a = a0 + 32 * ss;
+                const u32x2 lo = *(const u32x2*)a, hi = *(const u32x2*)(a + 16);
+                const u32x4 af = {lo[0], lo[1], hi[0], hi[1]};
+                y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), gb[ss], y[cb], 0, 0, 0);
             }
         }
-        if (ch + 1 < NCH) store_chunk(buf ^ 1);
+    };
+
+    if constexpr (!PIPE) {
+        load_chunk(0);
+        store_chunk(0);
         __syncthreads();
+        for (int ch = 0; ch < K::NCH; ++ch) {
+            const int buf = ch & 1;
+            if (ch + 1 < K::NCH) load_chunk(ch + 1);
+            const char* st = smem + buf * K::STAGE;
+            // ---- all H^T blocks of the chunk first (MFMAs back to back), then per block the vector work followed by its Y^T MFMAs -- block 1's GELU has no dependence
+            //      on block 0's MFMAs, so the two pipes can overlap
+            f32x16 acc[NHB];
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb) first_product(acc[hb], st, hb);
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb) second_product(acc[hb], st, hb);
+            if (ch + 1 < K::NCH) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // ---- one wave per SIMD: chunk n + 1's first product runs UNDER chunk n's GELU.  A lone in-order wave overlaps its matrix and vector work only when the two
+        //      are interleaved in its instruction stream (an MFMA holds the issue port for 8 of its 32 cycles; ~6 vector instructions fit in the rest), so a
+        //      half-trip is:  every weight fragment of both products read up front (18 ds_read_b128 + 36 ds_read_b64, all in flight together: one LDS latency instead
+        //      of one per MFMA) -> { 1 MFMA of H(n + 1), ~9 vector instructions of GELU(n) } x 18 (sched_group_barrier pins the pattern) -> 18 MFMAs of Y += W2(n) G(n),
+        //      under which the next chunk's staging (global loads issued at the top, LDS stores at the end) proceeds.
+        //      Three LDS stages: in the half-trip of chunk n the first product reads W1' of stage (n + 1) % 3, the second product W2 / c / d of stage n % 3, and chunk
+        //      n + 2 (fetched to registers at the top) is stored into stage (n + 2) % 3, last read one barrier ago -- one barrier per chunk.  Two chunks per trip so that
+        //      the two accumulator sets keep their names (no runtime-indexed register arrays); stage offsets are scalar arithmetic.
+        static_assert(!PIPE || (NHB == 1 && K::NSTG == 3 && K::NCH % 2 == 0), "the pipelined form: one hidden block per chunk, three stages, chunk pairs");
+        auto stg = [&](int n) { return smem + (n % 3) * K::STAGE; };
+        // one piece of store_chunk: piece j < NJ1 is W1' register j, NJ1 <= j < NJ1 + NJ2 is W2 register j - NJ1 (two 8-byte stores), the last piece also stores c / d
+        auto store_piece = [&](int buf, int j) {
+            char* base = smem + buf * K::STAGE;
+            if (j < K::NJ1) {
+                const int idx = tid + j * NT;
+                if (idx < K::W1P) *(u32x4*)(base + (idx / (C / 8)) * K::W1STR + (idx % (C / 8)) * 16) = w1r[j];
+            } else if (j < K::NJ1 + K::NJ2) {
+                const int idx = tid + (j - K::NJ1) * NT;
+                if (idx < K::W2P) {
+                    char* d = base + K::W1B + (idx / (HC / 8)) * K::W2STR + (idx % (HC / 8)) * 16;
+                    *(u32x2*)d = u32x2{w2r[j - K::NJ1][0], w2r[j - K::NJ1][1]};
+                    *(u32x2*)(d + 8) = u32x2{w2r[j - K::NJ1][2], w2r[j - K::NJ1][3]};
+                }
+                if (j == K::NJ1 + K::NJ2 - 1 && tid < 2 * HC) *(float*)(base + K::W1B + K::W2B + tid * 4) = cr;
+            }
+        };
+        static_assert(!PIPE || (K::NJ1 + K::NJ2 <= 2 * CB && 2 * CB == KS), "the pipelined form pairs one W2 fragment and one staging piece with every MFMA");
+        auto half = [&](f32x16& accN, const f32x16& accC, const char* stN, const char* stC, int sbuf) {
+            // ---- W1' fragments of chunk n + 1 and the fold constants of chunk n: all reads in flight together
+            bf16x8 a1[KS];
+            f32x4 cc[4], dd[4];
+            {
+                const char* a0 = stN + r * K::W1STR + h * 16;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a1[ks] = *(const bf16x8*)(a0 + ks * 32);
+                const float* cs = (const float*)(stC + K::W1B + K::W2B);
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    cc[i4] = *(const f32x4*)(cs + 8 * i4 + 4 * h);
+                    dd[i4] = *(const f32x4*)(cs + HC + 8 * i4 + 4 * h);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accN[i] = 0.f;
+            u32x4 a2[CB][2];
+            unsigned pkv[8], gk[8];
+            float q[16];
+            const char* w2b = stC + K::W1B + r * K::W2STR + 8 * h;
+            // ---- 18 x { one MFMA of H(n + 1); one W2 fragment of chunk n; one step of GELU(n) }.  GELU of value pair p (accumulator registers 2p, 2p + 1) in two steps:
+            //      A(p) at MFMA 2p: LayerNorm fold, bf16 rounding, table addresses, the two ds_read_b32; B(p) three MFMAs later: relu - |t| T(|t|), bf16 pair.
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[k], xf[k], accN, 0, 0, 0);
+                {
+                    const char* b0 = w2b + (k >> 1) * 32 * K::W2STR + 32 * (k & 1);
+                    const u32x2 lo = *(const u32x2*)b0, hi = *(const u32x2*)(b0 + 16);
+                    a2[k >> 1][k & 1] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+                if ((k & 1) == 0 && (k >> 1) < 8) {
+                    const int pp = k >> 1, i4 = pp >> 1, e = 2 * (pp & 1);
+                    const float v0 = __builtin_fmaf(rinv, accC[2 * pp], __builtin_fmaf(nmr, cc[i4][e], dd[i4][e]));
+                    const float v1 = __builtin_fmaf(rinv, accC[2 * pp + 1], __builtin_fmaf(nmr, cc[i4][e + 1], dd[i4][e + 1]));
+                    unsigned pk = pack_bf2(v0, v1);
+                    asm("" : "+v"(pk));
+                    constexpr unsigned LO = kActTabLoBits, HI = kActTabLoBits + kActTabN - 1;
+                    const unsigned m0 = pk & 0x7fffu, m1 = __builtin_amdgcn_ubfe(pk, 16, 15);
+                    const unsigned ad0 = (min(max(m0, LO), HI) << 2) + tb, ad1 = (min(max(m1, LO), HI) << 2) + tb;
+                    q[2 * pp] = *(lds_cfloat*)(size_t)ad0;
+                    q[2 * pp + 1] = *(lds_cfloat*)(size_t)ad1;
+                    pkv[pp] = pk;
+                }
+                if (k >= 3 && (k & 1) == 1 && ((k - 3) >> 1) < 8) {
+                    const int pp = (k - 3) >> 1;
+                    const unsigned t0 = pkv[pp] << 16, t1 = pkv[pp] & 0xffff0000u;
+                    const int r0 = max((int)t0, 0), r1 = max((int)t1, 0);
+                    float y0, y1;
+                    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y0) : "v"(t0), "v"(q[2 * pp]), "v"(r0));
+                    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y1) : "v"(t1), "v"(q[2 * pp + 1]), "v"(r1));
+                    gk[pp] = pack_bf2(y0, y1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 gb[2];
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) gb[ss] = __builtin_bit_cast(bf16x8, u32x4{gk[4 * ss], gk[4 * ss + 1], gk[4 * ss + 2], gk[4 * ss + 3]});
+            // ---- Y^T += W2(n) G(n): 18 MFMAs, one piece of the next chunk's LDS staging beside each (stale registers in the last trip: stored, never read)
+#pragma unroll
+            for (int k = 0; k < 2 * CB; ++k) {
+                y[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2[k >> 1][k & 1]), gb[k & 1], y[k >> 1], 0, 0, 0);
+                store_piece(sbuf, k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        load_chunk(0);
+        store_chunk(0);
+        load_chunk(1);
+        store_chunk(1);
+        __syncthreads();
+        f32x16 accA, accB;
+        first_product(accA, stg(0), 0);
+#pragma unroll 1
+        for (int ch = 0; ch < K::NCH; ch += 2) {
+            if (ch + 2 < K::NCH) load_chunk(ch + 2);
+            half(accB, accA, stg(ch + 1), stg(ch), (ch + 2) % 3);    // H(ch + 1) under GELU(ch), then Y += W2(ch) G(ch) with chunk ch + 2 going into its stage
+            __syncthreads();
+            if (ch + 3 < K::NCH) load_chunk(ch + 3);
+            half(accA, accB, stg(ch + 2), stg(ch + 1), (ch + 3) % 3);  // (the last trip's H(NCH) reads a stale stage: computed, never used)
+            __syncthreads();
+        }
     }
     // ---- epilogue: + b2 + x, one bf16 rounding; the tile is transposed through LDS (now free) so that whole rows leave
     char* ot = smem;
 #pragma unroll
-    for (int cb = 0; cb < HM_CB; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
             const int c = cb * 32 + 8 * i4 + 4 * h;
-            if (c < HM_C) {
-                const u32x2 xb = *(const u32x2*)(p.x + tokc * HM_C + c);
+            if (c < C) {
+                const u32x2 xb = *(const u32x2*)(p.x + tokc * C + c);
                 const u32x2 bb = *(const u32x2*)(p.b2 + c);
                 const float v0 = y[cb][4 * i4 + 0] + __uint_as_float(bb[0] << 16) + __uint_as_float(xb[0] << 16);
                 const float v1 = y[cb][4 * i4 + 1] + __uint_as_float(bb[0] & 0xffff0000u) + __uint_as_float(xb[0] & 0xffff0000u);
                 const float v2 = y[cb][4 * i4 + 2] + __uint_as_float(bb[1] << 16) + __uint_as_float(xb[1] << 16);
                 const float v3 = y[cb][4 * i4 + 3] + __uint_as_float(bb[1] & 0xffff0000u) + __uint_as_float(xb[1] & 0xffff0000u);
-                *(u32x2*)(ot + (wave * 32 + r) * HM_OSTR + c * 2) = u32x2{pack_bf2(v0, v1), pack_bf2(v2, v3)};
+                *(u32x2*)(ot + (wave * 32 + r) * K::OSTR + c * 2) = u32x2{pack_bf2(v0, v1), pack_bf2(v2, v3)};
             }
         }
     __syncthreads();
-    for (int idx = tid; idx < HM_TOK * 18; idx += 512) {
-        const int row = idx / 18, c16 = idx % 18;
-        if (tok0 + row < p.M) *(u32x4*)(p.y + (tok0 + row) * HM_C + c16 * 8) = *(const u32x4*)(ot + row * HM_OSTR + c16 * 16);
+    for (int idx = tid; idx < K::TOK * (C / 8); idx += NT) {
+        const int row = idx / (C / 8), c16 = idx % (C / 8);
+        if (tok0 + row < p.M) *(u32x4*)(p.y + (tok0 + row) * C + c16 * 8) = *(const u32x4*)(ot + row * K::OSTR + c16 * 16);
     }
+}
+
+template <class K, bool PIPE>
+static int launch_hiera_mlp(const HmArgs& a, hipStream_t st, const char* name) {
+    auto kern = hiera_mlp_kernel<K, PIPE>;
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, K::LDS, lds_grant, name)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.M, K::TOK)), dim3(K::NT), K::LDS, st, a);
+    RGA3_CHECK_LAUNCH(name);
+    return 0;
 }
 
 }  // namespace rga3
 
 using namespace rga3;
 
-// y [M, 144] = x + W2 gelu(LayerNorm(x; eps) folded into W1f / c1 / d1) + b2   (Hiera stage-1 MLP, dims 144 -> 576 -> 144), all bf16 except c1 (f32).
-// w1f / c1 / d1 as rga3_gemm_ln_bf16 takes them: W1 diag(gamma) rounded to bf16, its row sums in f32, beta W1^T + b1 in bf16.  x, y contiguous, 16-byte aligned.
-extern "C" int rga3_hiera_mlp144(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, float eps,
-                                 void* stream) {
-    RGA3_CHECK_ARG(x && w1f && c1 && d1 && w2 && b2 && y && M > 0, "hiera_mlp144: null pointer / M %ld", (long)M);
-    RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1f | (uintptr_t)w2 | (uintptr_t)y | (uintptr_t)c1) & 15) == 0 && (((uintptr_t)b2 | (uintptr_t)d1) & 7) == 0, "hiera_mlp144: alignment");
-    RGA3_CHECK_ARG(x != y, "hiera_mlp144: in place is not supported (the residual is re-read)");
-    static LdsGrant lds_grant;
-    if (int rc = grant_dyn_lds((const void*)hiera_mlp144_kernel, HM_LDS, lds_grant, "hiera_mlp144")) return rc;
+// y [M, C] = x + W2 gelu(LayerNorm(x; eps) folded into W1f / c1 / d1) + b2   (Hiera MLP, dims C -> 4 C -> C; C = 144: stage 1, C = 288: stage 2), all bf16 except c1
+// (f32).  w1f / c1 / d1 as rga3_gemm_ln_bf16 takes them: W1 diag(gamma) rounded to bf16, its row sums in f32, beta W1^T + b1 in bf16.  x, y contiguous, 16-byte aligned.
+extern "C" int rga3_hiera_mlp(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, int C, float eps,
+                              void* stream) {
+    RGA3_CHECK_ARG(x && w1f && c1 && d1 && w2 && b2 && y && M > 0, "hiera_mlp: null pointer / M %ld", (long)M);
+    RGA3_CHECK_ARG(C == 144 || C == 288, "hiera_mlp: C = %d (144: Hiera-L stage 1, 288: stage 2)", C);
+    RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1f | (uintptr_t)w2 | (uintptr_t)y | (uintptr_t)c1) & 15) == 0 && (((uintptr_t)b2 | (uintptr_t)d1) & 7) == 0, "hiera_mlp: alignment");
+    RGA3_CHECK_ARG(x != y, "hiera_mlp: in place is not supported (the residual is re-read)");
     HmArgs a;
     a.x = (const unsigned short*)x; a.w1f = (const unsigned short*)w1f; a.c1 = c1; a.d1 = (const unsigned short*)d1;
     a.w2 = (const unsigned short*)w2; a.b2 = (const unsigned short*)b2; a.y = (unsigned short*)y; a.M = M; a.eps = eps;
-    hipLaunchKernelGGL(hiera_mlp144_kernel, dim3((unsigned)cdiv(M, HM_TOK)), dim3(512), HM_LDS, (hipStream_t)stream, a);
-    RGA3_CHECK_LAUNCH("hiera_mlp144_kernel");
-    return 0;
+    if (C == 144) return launch_hiera_mlp<HmCfg<144, 8, 64, 2>, false>(a, (hipStream_t)stream, "hiera_mlp_kernel<144>");
+    return launch_hiera_mlp<HmCfg<288, 4, 32, 3>, true>(a, (hipStream_t)stream, "hiera_mlp_kernel<288>");
+}
+
+// the round-3 entry point (stage 1 only), kept for callers bound to it
+extern "C" int rga3_hiera_mlp144(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, float eps,
+                                 void* stream) {
+    return rga3_hiera_mlp(x, w1f, c1, d1, w2, b2, y, M, 144, eps, stream);
 }

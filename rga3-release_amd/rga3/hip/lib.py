@@ -58,6 +58,7 @@ SIGNATURES = {
     "rga3_attn_varlen_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _p, _f, _i, _p, _i64, _p],
     "rga3_transpose16_many": [_p, _p, _i, _p],
     "rga3_hiera_mlp144": [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _p],
+    "rga3_hiera_mlp": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _p],
     "rga3_mlp3_rows": [_p, _p, _i, _i64, _p],
     "rga3_sam_select_objptr": [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
     "rga3_memattn_cross_ws_floats": [_i64, _i],

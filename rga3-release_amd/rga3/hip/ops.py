@@ -254,17 +254,21 @@ def fold_layernorm(weight, bias, gamma, beta):
     return wf, colc, bf.to(torch.bfloat16).contiguous()
 
 
-def hiera_mlp144(x, wf, colc, biasf, w2, b2, eps: float):
-    """x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 for the 144 -> 576 -> 144 MLP of a frozen Hiera stage-1 block in one launch (csrc/hiera_mlp.hip);
+def hiera_mlp(x, wf, colc, biasf, w2, b2, eps: float):
+    """x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 for the C -> 4 C -> C MLP of a frozen Hiera block in one launch (csrc/hiera_mlp.hip), C = 144 (stage 1) or 288 (stage 2);
     (wf, colc, biasf) = fold_layernorm(W1, b1, gamma, beta)."""
     _need_cuda(x, wf, colc, biasf, w2, b2)
     assert x.dtype == wf.dtype == w2.dtype == b2.dtype == biasf.dtype == torch.bfloat16 and colc.dtype == torch.float32
-    assert x.dim() == 2 and x.shape[1] == 144 and x.is_contiguous() and tuple(wf.shape) == (576, 144) and tuple(w2.shape) == (144, 576) and wf.is_contiguous() and w2.is_contiguous()
-    assert colc.numel() == 576 and biasf.numel() == 576 and b2.numel() == 144 and colc.is_contiguous() and biasf.is_contiguous() and b2.is_contiguous()
+    C = x.shape[1]
+    assert x.dim() == 2 and C in (144, 288) and x.is_contiguous() and tuple(wf.shape) == (4 * C, C) and tuple(w2.shape) == (C, 4 * C) and wf.is_contiguous() and w2.is_contiguous()
+    assert colc.numel() == 4 * C and biasf.numel() == 4 * C and b2.numel() == C and colc.is_contiguous() and biasf.is_contiguous() and b2.is_contiguous()
     y = torch.empty_like(x)
-    _lib.check(_lib.load().rga3_hiera_mlp144(x.data_ptr(), wf.data_ptr(), colc.data_ptr(), biasf.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(), x.shape[0],
-                                             float(eps), _stream()), "hiera_mlp144")
+    _lib.check(_lib.load().rga3_hiera_mlp(x.data_ptr(), wf.data_ptr(), colc.data_ptr(), biasf.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(), x.shape[0], C,
+                                          float(eps), _stream()), "hiera_mlp")
     return y
+
+
+hiera_mlp144 = hiera_mlp      # the round-3 name (stage 1 only)
 
 
 _LN_TILES = (20, 3, 5, 12, 13)

@@ -36,7 +36,8 @@ _DEBUG = None   # set to a dict by tools/grad_locate.py (diagnostic)
 
 _DECIMG = True    # mask decoder at inference: the image side of a two-way block boundary in one launch (csrc/decimg.hip)
 _ROWCHAIN = True  # memory attention at inference: the row-wise steps between the attention kernels in one launch each (csrc/memlayer.hip)
-_MLP_FUSE = True  # stage-1 MLP of the frozen Hiera trunk as one launch (csrc/hiera_mlp.hip); tools/ flip it for A/B runs
+_MLP_FUSE = True  # stage-1 / stage-2 MLP of the frozen Hiera trunk as one launch (csrc/hiera_mlp.hip); tools/ flip it for A/B runs
+_MLP_FUSE_DIMS = (144, 288)
 _LN_FOLD = True   # LayerNorm of the frozen Hiera trunk folded into the consuming product (tools/ flip this module attribute for A/B runs; no environment switch)
 
 
@@ -237,10 +238,11 @@ class MultiScaleBlock(nn.Module):
         if self.pool_q:
             H, W, layout_w = H // 2, W // 2, ws // 2
         l0, l1 = self.mlp.layers[0], self.mlp.layers[1]
-        if (fold and _MLP_FUSE and self.dim_out == 144 and l0.out_features == 576 and self.mlp.num_layers == 2 and self.mlp.act == "gelu" and l0.bias is not None
-                and l1.bias is not None and x.is_contiguous()):
-            # stage-1 MLP (144 -> 576 -> 144 over 65 536 tokens per frame) in one launch: the hidden activation and the LayerNorm statistics never reach HBM
-            x = ops.hiera_mlp144(x, *self._folded("fc1"), l1.weight, l1.bias, self.norm2.eps)
+        if (fold and _MLP_FUSE and self.dim_out in _MLP_FUSE_DIMS and l0.out_features == 4 * self.dim_out and self.mlp.num_layers == 2 and self.mlp.act == "gelu"
+                and l0.bias is not None and l1.bias is not None and x.is_contiguous()):
+            # stage-1 / stage-2 MLP (144 -> 576 -> 144 over 65 536 tokens per frame, 288 -> 1152 -> 288 over 16 384) in one launch: the hidden activation and the
+            # LayerNorm statistics never reach HBM
+            x = ops.hiera_mlp(x, *self._folded("fc1"), l1.weight, l1.bias, self.norm2.eps)
         elif fold and self.dim_out % 8 == 0:
             hmid = ops.gemm_ln(x, ops.layernorm_stats(x, self.norm2.eps), *self._folded("fc1"), act="gelu")
             x = self.mlp.layers[1](hmid, residual=x)
@@ -1019,7 +1021,8 @@ class SAM2(nn.Module):
         the reference concatenates the per-frame yields [n_obj, 1, S, S] of propagate_in_video on dim 0 (:399-403), i.e. FRAME-major (frame 0 obj 0, frame 0 obj 1,
         frame 1 obj 0, ...) -- [T, 1, S, S] for the single object of every RGA3 caller; pinned at n_obj = 2 by tests/golden/sam2_multiobj.npz."""
         T = len(language_embd)
-        embs = [e.reshape(-1, e.shape[-1]) for e in language_embd]
+        # language_embd[t]: a tensor [n_obj, C] / [C] or a list of n_obj tensors (the reference indexes language_embd[frame_idx][obj_idx], :385-388)
+        embs = [(torch.stack([x.reshape(-1) for x in e]) if isinstance(e, (list, tuple)) else e.reshape(-1, e.shape[-1])) for e in language_embd]
         n_obj = embs[0].shape[0]
         outs = []
         for o in range(n_obj):   # objects do not interact (non_overlap_masks / non_overlap_masks_for_mem_enc / clear_non_cond_mem_* are False: reference :2392, :3512-3517)

@@ -296,31 +296,33 @@ def test_fused_decoder_heads_and_selection(dev):
     assert torch.equal(ptr[1].cpu(), no_obj) and torch.equal(ptr[2].cpu(), no_obj)
 
 
-@pytest.mark.parametrize("M", [65536, 1000, 256 * 3 + 17])
-def test_hiera_stage1_mlp_fused(dev, M):
-    """csrc/hiera_mlp.hip: x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 (144 -> 576 -> 144) in one launch against fp32 torch (LayerNorm eps 1e-6, exact-erf GELU) on the same
-    bf16 operands, and against the unfused pair it replaces (rga3_layernorm_stats + rga3_gemm_ln_bf16 + rga3_gemm_bf16) -- a full frame's 65 536 tokens and ragged row
-    counts (a partial last 256-token workgroup, a partial last 32-token wave)."""
+@pytest.mark.parametrize("C,M", [(144, 65536), (144, 1000), (144, 256 * 3 + 17), (288, 16384), (288, 1000), (288, 128 * 3 + 17), (288, 131072)])
+def test_hiera_stage1_mlp_fused(dev, C, M):
+    """csrc/hiera_mlp.hip: x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 (C -> 4 C -> C; C = 144: Hiera-L stage 1, C = 288: stage 2, reference model/sam2.py:1035-1117,
+    :2305-2329) in one launch against fp32 torch (LayerNorm eps 1e-6, exact-erf GELU) on the same bf16 operands, and against the unfused pair it replaces
+    (rga3_layernorm_stats + rga3_gemm_ln_bf16 + rga3_gemm_bf16) -- a full frame's tokens (65 536 / 16 384), eight frames of stage 2, and ragged row counts (a partial
+    last workgroup, a partial last 32-token wave).  Run to run bit-identical."""
     from rga3.hip import ops
 
-    g = torch.Generator().manual_seed(M)
-    x = (torch.randn(M, 144, generator=g) * 1.5 + 0.3 * torch.randn(M, 1, generator=g)).to(torch.bfloat16)
-    w1 = (torch.randn(576, 144, generator=g) * 0.08).to(torch.bfloat16)
-    b1 = (torch.randn(576, generator=g) * 0.1).to(torch.bfloat16)
-    w2 = (torch.randn(144, 576, generator=g) * 0.05).to(torch.bfloat16)
-    b2 = (torch.randn(144, generator=g) * 0.1).to(torch.bfloat16)
-    gamma = (1 + 0.2 * torch.randn(144, generator=g)).to(torch.bfloat16)
-    beta = (0.1 * torch.randn(144, generator=g)).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 1.5 + 0.3 * torch.randn(M, 1, generator=g)).to(torch.bfloat16)
+    w1 = (torch.randn(4 * C, C, generator=g) * 0.08 * (144 / C) ** 0.5).to(torch.bfloat16)
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).to(torch.bfloat16)
+    w2 = (torch.randn(C, 4 * C, generator=g) * 0.05 * (144 / C) ** 0.5).to(torch.bfloat16)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(torch.bfloat16)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    beta = (0.1 * torch.randn(C, generator=g)).to(torch.bfloat16)
     xd = x.to(dev)
     wf, colc, biasf = ops.fold_layernorm(w1.to(dev), b1.to(dev), gamma.to(dev), beta.to(dev))
-    y = ops.hiera_mlp144(xd, wf, colc, biasf, w2.to(dev), b2.to(dev), 1e-6)
+    y = ops.hiera_mlp(xd, wf, colc, biasf, w2.to(dev), b2.to(dev), 1e-6)
     xf = x.float()
-    ref = xf + F.linear(F.gelu(F.linear(F.layer_norm(xf, (144,), gamma.float(), beta.float(), 1e-6), w1.float(), b1.float())), w2.float(), b2.float())
+    ref = xf + F.linear(F.gelu(F.linear(F.layer_norm(xf, (C,), gamma.float(), beta.float(), 1e-6), w1.float(), b1.float())), w2.float(), b2.float())
     assert rel(y, ref) < 1e-2, rel(y, ref)
     hmid = ops.gemm_ln(xd, ops.layernorm_stats(xd, 1e-6), wf, colc, biasf, act="gelu")
     y2 = ops.gemm(hmid, w2.to(dev), b2.to(dev), residual=xd)
     assert rel(y, y2) < 4e-3, rel(y, y2)
-    assert torch.equal(y, ops.hiera_mlp144(xd, wf, colc, biasf, w2.to(dev), b2.to(dev), 1e-6))
+    assert torch.equal(y, ops.hiera_mlp(xd, wf, colc, biasf, w2.to(dev), b2.to(dev), 1e-6))
+    assert bool(torch.isfinite(y.float()).all())
 
 
 def test_in_launch_reductions_equal_two_launch_forms(dev):
