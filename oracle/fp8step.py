@@ -14,6 +14,9 @@ from . import qwen25vl as Q
 from .kernels_ref import gemm_fp8_ref, quant_fp8_rows_ref
 
 FROZEN = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+# the frozen vision tower's contractions (rga3.model.qwen_train.vision_block_forward_fp8); the build pads the MLP width 3420 -> 3456 with zero columns, which changes
+# neither a row's amax nor any code, so the down projection is quantised here at its own width
+FROZEN_VISION = ("attn.qkv", "attn.proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
 
 
 class Fp8FrozenLinear(torch.autograd.Function):
@@ -39,11 +42,13 @@ class Fp8FrozenLinear(torch.autograd.Function):
 
 
 @contextlib.contextmanager
-def fp8_frozen_linears():
+def fp8_frozen_linears(vision: bool = False):
     orig = Q._lin
 
     def lin(x, P, name):
-        if not (name.startswith("model.layers.") and name.endswith(FROZEN)) or x.shape[-1] % 128 != 0:
+        dec = name.startswith("model.layers.") and name.endswith(FROZEN) and x.shape[-1] % 128 == 0
+        vis = vision and name.startswith("visual.blocks.") and name.endswith(FROZEN_VISION) and ((x.shape[-1] + 63) // 64 * 64) % 128 == 0
+        if not (dec or vis):
             return orig(x, P, name)
         y = Fp8FrozenLinear.apply(x, P[name + ".weight"], P.get(name + ".bias"))
         a = P.get(name + ".lora_A.default.weight")

@@ -992,6 +992,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     };
 
     unsigned soff[4][2];
+    unsigned soffA3[3];    // MH == 3: the three 64-row A units of a K-tile (one piece per wave each)
     int nm0 = 0, nn0 = 0;  // tile origin of the item whose offsets are in soff
     auto setup_tile = [&](int tile, int lane) {
         const int sch = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
@@ -1017,6 +1018,18 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 soff[2 + h][i] = (unsigned)((long)min(nn0 + bcol, p.N - 1) * p.ldw + sch * 8);
             }
         }
+        if constexpr (MH == 3) {
+            // A unit u (phase u of a K-tile) = m-tiles 2u, 2u + 1 of both wave rows: LDS row lr = 8 wid + lane / 8 of the unit is tile row (lr / 32) * 96 + 32 u + lr % 32
+            const int lr = wid * 8 + (lane >> 3);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) soffA3[u] = (unsigned)((long)min(nm0 + (lr >> 5) * 96 + 32 * u + (lr & 31), p.M - 1) * p.lda + sch * 8);
+        }
+    };
+    auto stage_a3 = [&](int u, int kt, int buf) {   // MH == 3: one 1-KiB piece per wave
+        const unsigned short* base = p.A + (long)kt * BK;
+        unsigned o = soffA3[u];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(smem + buf * BUF + u * 8192 + wid * 1024), 16, 0, 0);
     };
     auto stage = [&](auto KIND, int kt, int buf) {
         constexpr int kind = decltype(KIND)::value;
@@ -1044,6 +1057,20 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     };
     // the first K-tile of an item always goes to buffer 1, the second to buffer 0, ...
     auto prologue_issue = [&](int kb, int ke) {
+        if constexpr (MH == 3) {
+            // the steady-state issue order of the three-phase loop: B0 A_0 | B1 A_1 | A_2 of the first K-tile (buffer 1), B0 A_0 of the second (buffer 0) -- the counted
+            // waits of the loop assume exactly this sequence; B1 / A_2 of buffer 0 (where the epilogue parks its row statistics) follow inside the loop
+            stage(K_B0{}, kb, 1);
+            stage_a3(0, kb, 1);
+            stage(K_B1{}, kb, 1);
+            stage_a3(1, kb, 1);
+            stage_a3(2, kb, 1);
+            if (ke - kb > 1) {
+                stage(K_B0{}, kb + 1, 0);
+                stage_a3(0, kb + 1, 0);
+            }
+            return;
+        }
         stage(K_A0{}, kb, 1);
         stage(K_B0{}, kb, 1);
         stage(K_B1{}, kb, 1);
@@ -1093,6 +1120,36 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
+    // ---- MH == 3 (192-row tiles): THREE phases of 16 MFMAs per K-tile instead of four of 12.  The fixed cost of a phase (two barriers, the fragment reads, the DMA
+    //      issue: ~170 cycles against 512 of matrix work for the two waves of a SIMD) is what made the four-phase form of these tiles lose the 8 % of padding they save
+    //      at M = 2112 = 11 x 192 (520 vs 523 us on the gate | up product).  Phase u multiplies m-tiles 2u, 2u + 1 of the wave's 96 rows by ALL four n-tiles: the B
+    //      fragments of a K-tile are read once (phase 0) and kept in registers (32), A unit u (64 rows: 2 m-tiles x 2 wave rows) is read at phase u.
+    auto read_a3 = [&](const char* cur, int u) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8*)(cur + u * 8192 + wr * 4096 + mi * 2048 + foff[kk]);
+    };
+    auto mma_phase3 = [&](auto U) {
+        constexpr int u = decltype(U)::value;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) mfma_inplace(acc[(MH == 3 ? 2 * u : 0) + mi][ni], b0[ni][kk], af[mi][kk]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) mfma_inplace(acc[(MH == 3 ? 2 * u : 0) + mi][2 + ni], b1[ni][kk], af[mi][kk]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
 
     // activation table (GELU / SwiGLU epilogues): 10 KiB behind the two buffers, once per workgroup = once per CU and launch
     if constexpr (act_uses_table<ACT>()) stage_act_table<8>(smem + 2 * BUF, ACT == ACT_SWIGLU, wid, lane);
@@ -1123,6 +1180,34 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
         const int nkt = ke - kb;
         const int last = 4 * nkt - 1;
         int q = 0;
+        if constexpr (MH == 3) {
+            // Issue order (pieces per wave: B halves 2, A units 1):  ... | q.ph0: B1(q+1) A_1(q+1) | q.ph1: A_2(q+1) | q.ph2: B0(q+2) A_0(q+2) | ...
+            // Every unit is issued >= 2 phases after the last read of its region and >= 3 phases before its first read; a counted wait sits before the FIRST barrier
+            // of a phase and retires what the NEXT phase reads (one barrier more than the lockstep rule: the wave rows run a barrier apart).
+            //   end of ph0 needs A_1(q):  issued after it  A_2(q) 1 + [B0 A_0 B1 A_1](q+1) 6   -> vmcnt(7), vmcnt(1) on the last K-tile
+            //   end of ph1 needs A_2(q):  issued after it  [B0 A_0 B1 A_1 A_2](q+1) 7          -> vmcnt(7), vmcnt(0) on the last K-tile
+            //   end of ph2 needs B0 A_0 B1 (q+1): after them  A_1(q+1) A_2(q+1) 2 + [B0 A_0](q+2) 3 -> vmcnt(5), vmcnt(2) when q + 2 does not exist
+            do {
+                const int kt = kb + q;
+                const int buf = (q + 1) & 1;
+                const char* cur = smem + buf * BUF;
+                const bool e1 = q + 1 < nkt, e2 = q + 2 < nkt;
+                read_a3(cur, 0);
+                read_b(b0, cur, 0);
+                read_b(b1, cur, 1);
+                if (e1) { stage(K_B1{}, kt + 1, buf ^ 1); stage_a3(1, kt + 1, buf ^ 1); }
+                if (e1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                mma_phase3(U0{});
+                read_a3(cur, 1);
+                if (e1) stage_a3(2, kt + 1, buf ^ 1);
+                if (e1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                mma_phase3(U1{});
+                read_a3(cur, 2);
+                if (e2) { stage(K_B0{}, kt + 2, buf); stage_a3(0, kt + 2, buf); }
+                if (e2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else if (e1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                mma_phase3(U2{});
+            } while (++q < nkt);
+        } else
         do {  // nkt >= 1 always; the do-while form keeps one accumulator live range (no zero-trip merge after the loop)
             const int kt = kb + q;
             const int buf = (q + 1) & 1;

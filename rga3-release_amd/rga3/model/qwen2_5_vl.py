@@ -267,6 +267,9 @@ class GatedMLP(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ vision tower
+_VIT_BLOCK_FP8 = [None]      # set by rga3.model.qwen_train.set_fp8_frozen_gemms: the e4m3 forward of one frozen vision block (kept there with the other fp8 plumbing)
+
+
 class VisionPatchEmbed(nn.Module):
     def __init__(self, c: Qwen2_5_VLVisionConfig):
         super().__init__()
@@ -404,7 +407,18 @@ class VisionTransformer(nn.Module):
         unit = c.spatial_merge_size ** 2
         x = self.patch_embed(pixel_values.to(self.dtype))
         x = ops.gather_rows(x, pl["window_index"], rows_per_idx=unit)
-        fold = _fold_ok(x, *[m_ for b_ in self.blocks for m_ in (b_.attn.qkv, b_.attn.proj, b_.mlp.gate_proj, b_.mlp.up_proj, b_.mlp.down_proj)])
+        plain = [m_ for b_ in self.blocks for m_ in (b_.attn.qkv, b_.attn.proj, b_.mlp.gate_proj, b_.mlp.up_proj, b_.mlp.down_proj)]
+        hook = _VIT_BLOCK_FP8[0]
+        if hook is not None and not torch.is_grad_enabled() and x.shape[1] % 128 == 0 and x.dtype == torch.bfloat16 and _is_plain(*plain):
+            # BASELINE configs[4]: the frozen tower's contractions in e4m3 (rga3.model.qwen_train.vision_block_forward_fp8; norms, RoPE, attention stay bf16)
+            for i, blk in enumerate(self.blocks):
+                full = i in c.fullatt_block_indexes
+                x = hook(blk, x, pl["cu_full" if full else "cu_win"], pl["max_full" if full else "max_win"], pl["cos"], pl["sin"])
+            m = self.merger(x)
+            out = torch.empty_like(m)
+            ops.scatter_rows_(out, pl["window_index"], m)
+            return out
+        fold = _fold_ok(x, *plain)
         nb = len(self.blocks)
         sums = torch.zeros((2 * nb, x.shape[0]), dtype=torch.int64, device=x.device) if fold else None    # one memset for the whole tower
         for i, blk in enumerate(self.blocks):

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from ..hip import ops
 from ..utils.staging import upload
+from . import qwen2_5_vl as _Q
 from .qwen2_5_vl import GatedMLP, Linear, _versions
 
 
@@ -89,11 +90,12 @@ def _wt(owner, key, *srcs, build):
 _fp8 = {"on": False}
 
 
-def set_fp8_frozen_gemms(on: bool):
-    """Run the decoder's frozen-weight contractions (qkv / o / gate-up / down and their transposes in backward) through the e4m3 GEMM
-    (BASELINE.json configs[4]).  Activations are quantised per token on the fly, weights per output row once (cached per weight version);
-    LoRA factors, lm_head, embeddings, norms, attention and the ViT stay bf16."""
+def set_fp8_frozen_gemms(on: bool, vision: bool = True):
+    """Run the frozen-weight contractions -- the decoder's qkv / o / gate-up / down and their transposes in backward, and (vision=True) the frozen vision tower's
+    qkv / proj / gate-up / down -- through the e4m3 GEMM (BASELINE.json configs[4]).  Activations are quantised per token on the fly, weights per output row once
+    (cached per weight version); LoRA factors, lm_head, embeddings, norms, attention, the patch embedding and the merger stay bf16."""
     _fp8["on"] = bool(on)
+    _Q._VIT_BLOCK_FP8[0] = vision_block_forward_fp8 if (on and vision) else None
 
 
 def fp8_frozen_gemms() -> bool:
@@ -127,6 +129,27 @@ def _fgemm_q(xq, xs, owner, key, srcs, build, bias=None, residual=None, out=None
 
 def _fp8_fused(k: int) -> bool:
     return _fp8["on"] and k % 128 == 0
+
+
+def vision_block_forward_fp8(blk, x, cu, max_len, cos, sin):
+    """One frozen Qwen2.5-VL vision block (HF modeling_qwen2_5_vl.py:290-321: x + attn(norm1(x)), x + mlp(norm2(x))) with its four contractions in e4m3: the
+    configs[4] fine-tune runs the tower on 32 frames per micro-step (21 TFLOP, a fifth of the step's GEMM time in bf16).  Same operation order as the bf16 route;
+    the SwiGLU kernel emits the e4m3 operand of the down projection directly.  Inference only (the tower is frozen: reference train_joint.py:190-191)."""
+    at, mlp = blk.attn, blk.mlp
+    N = x.shape[0]
+    H, D = at.num_heads, at.head_dim
+    h1 = blk.norm1(x)
+    qkv = _fgemm(h1, at, "wqkv", (at.qkv.weight,), lambda: at.qkv.weight.detach(), bias=at.qkv.bias).view(N, 3 * H, D)
+    if ops.attn_rope_win_ok(max_len, D):
+        att = ops.attn_varlen_rope(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, cos, sin, causal=False, rope_k=True)
+    else:
+        ops.rope_(qkv, cos, sin, 0, 2 * H)
+        att = ops.attn_varlen(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], cu, cu, max_len, D ** -0.5, causal=False, max_k=max_len)
+    x1 = _fgemm(att.view(N, H * D), at, "wproj", (at.proj.weight,), lambda: at.proj.weight.detach(), bias=at.proj.bias, residual=x)
+    h2 = blk.norm2(x1)
+    wgu, bgu, wd = mlp._packed()
+    gu = _fgemm(h2, mlp, "wgu", (mlp.gate_proj.weight, mlp.up_proj.weight), lambda: wgu, bias=bgu)
+    return _down_from_gu(mlp, gu, wd, x1)
 
 
 def _lora_parts(lin):

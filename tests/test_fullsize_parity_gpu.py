@@ -83,6 +83,42 @@ def test_vit_blocks_7b_grid_8_32_32(dev, frames):
     assert rel(y, ref) < 2e-2
 
 
+def test_vit_blocks_7b_fp8_grid_16_32_32(dev):
+    """configs[4] (fp8 LoRA fine-tune, 32 frames -> grid [16,32,32], 16 384 patches): the frozen vision tower's qkv / proj / gate|up / down contractions in e4m3
+    (rga3.model.qwen_train.vision_block_forward_fp8; reference run: the frozen tower under run_torchrun.sh:28-40) on one windowed + one full-attention block at the 7B
+    tower's dimensions, against the oracle's e4m3 restatement (oracle/fp8step.py with vision=True: same quantiser, same scales, products summed in fp32).  Bound: 1.25 x
+    what e4m3 itself costs these two blocks (the oracle's e4m3 run against its fp32 run, printed), never less than the bf16 tolerance 2e-2; and the e4m3 route must
+    really have run (its weight packs exist, its output differs from the bf16 route's)."""
+    from rga3.model import qwen_train as QT
+    from rga3.model.qwen2_5_vl import Qwen2_5_VLVisionConfig, VisionTransformer
+    from oracle.fp8step import fp8_frozen_linears
+
+    _threads()
+    vc = Qwen2_5_VLVisionConfig(depth=2, fullatt_block_indexes=(1,))
+    vt = _init(VisionTransformer(vc), 12)
+    px = torch.randn(16 * 1024, 1176, generator=torch.Generator().manual_seed(4)).clamp_(-1.8, 2.2).to(torch.bfloat16)
+    grid = np.array([[16, 32, 32]])
+    P = {"visual." + k: v.detach().to(torch.bfloat16).float() for k, v in vt.state_dict().items()}
+    vtd = vt.to(torch.bfloat16).to(dev).eval()
+    ocfg = Q.QwenCfg(vision=Q.VisionCfg(depth=2, fullatt_block_indexes=(1,)), text=Q.TextCfg(num_hidden_layers=1))
+    with torch.no_grad():
+        y16 = vtd(px.to(dev), grid)
+        QT.set_fp8_frozen_gemms(True)
+        try:
+            y8 = vtd(px.to(dev), grid)
+        finally:
+            QT.set_fp8_frozen_gemms(False)
+        with fp8_frozen_linears(vision=True):
+            r8 = Q.vit_forward(P, px.float(), grid, ocfg)
+        r32 = Q.vit_forward(P, px.float(), grid, ocfg)
+    assert any(k.startswith("fp8:") for k in vtd.blocks[0].mlp.__dict__.get("_wt_cache", {})), "the e4m3 weight packs were not built: the bf16 route ran"
+    e8, yard, e16 = rel(y8, r8), rel(r8, r32), rel(y16, r32)
+    print("VIT_FP8", {"fp8_vs_oracle_fp8": e8, "oracle_fp8_vs_oracle_fp32": yard, "bf16_vs_oracle_fp32": e16, "fp8_vs_bf16_product": rel(y8, y16)})
+    assert tuple(y8.shape) == (4096, 3584) and e16 < 2e-2
+    assert e8 < max(2e-2, 1.25 * yard), (e8, yard)
+    assert rel(y8, y16) > 0.25 * yard                      # the two routes are different arithmetic
+
+
 @pytest.mark.parametrize("S_", [2112, 4160])
 def test_attention_backward_gqa_fullsize(dev, S_):
     """dq / dk / dv at the decoder's shapes (28 Q heads over 4 KV heads x 128: the per-query-head dK/dV workspace + fixed-order reduce) against autograd
