@@ -265,10 +265,14 @@ int rga3_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
  * rga3_gemm_ln_bf16 takes (W1 diag(gamma) in bf16, its row sums in f32, beta W1^T + b1 in bf16); the hidden activation and the row statistics never reach HBM.
  * x, y contiguous bf16, x != y. */
 int rga3_hiera_mlp144(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, float eps, void* stream);
-/* The same block for either narrow stage of the frozen Hiera-L trunk: C = 144 (stage 1, blocks 0 - 1: 65 536 tokens per 1024^2 frame) or C = 288 (stage 2, blocks 2 - 7:
- * 16 384 tokens per frame; reference model/sam2.py:1035-1117 with dim_out = 288, MLP 288 -> 1152 -> 288): y [M, C] = x + W2 gelu(LayerNorm(x) W1^T + b1) + b2.  At C = 288
- * a workgroup is four waves, one per SIMD on the 512-register budget, the first product of hidden chunk n + 1 issued ahead of chunk n's GELU.  Operands as above. */
-int rga3_hiera_mlp(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, int C, float eps, void* stream);
+/* The same block for stage 2 of the frozen Hiera-L trunk (blocks 2 - 7, C = 288, 16 384 tokens per 1024^2 frame; reference model/sam2.py:1035-1117 with dim_out = 288,
+ * MLP 288 -> 1152 -> 288): y [M, 288] = x + W2 gelu(LayerNorm(x) W1^T + b1) + b2.  A workgroup is four waves, one per SIMD on the 512-register budget; the weights are
+ * streamed by LDS-DMA from PACKED chunk images (rga3_hiera_mlp288_pack_bytes() bytes, built once per frozen block by rga3_hiera_mlp288_pack from the operands of the
+ * C = 144 form; layout in csrc/hiera_mlp.hip), W1' and W2 through separate three-slot LDS rings, the first product of hidden chunk n + 1 interleaved with chunk n's
+ * GELU.  x, y contiguous bf16, x != y. */
+int64_t rga3_hiera_mlp288_pack_bytes(void);
+int rga3_hiera_mlp288_pack(const void* w1f, const float* c1, const void* d1, const void* w2, void* pack, void* stream);
+int rga3_hiera_mlp288(const void* x, const void* pack, const void* b2, void* y, int64_t M, float eps, void* stream);
 /* Token-side tail of the SAM2 mask decoder at inference (csrc/dechead.hip).
  * rga3_mlp3_rows: n (<= 8) three-layer MLPs (Linear+ReLU, Linear+ReLU, Linear [+ sigmoid]) on ONE row per frame, B frames, one launch -- replaces the per-layer calls of
  * reference model/sam2.py:2142-2155 (output_hypernetworks_mlps, iou_prediction_head, pred_obj_score_head; MLP.forward :2319-2329).  HOST arrays:

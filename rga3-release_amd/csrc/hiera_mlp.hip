@@ -63,7 +63,7 @@ struct HmArgs {
     float eps;
 };
 
-template <class K, bool PIPE>
+template <class K>
 __global__ __launch_bounds__(K::NT) void hiera_mlp_kernel(HmArgs p) {
     constexpr int C = K::C, HC = K::HC, KS = K::KS, CB = K::CB, NHB = K::NHB, NT = K::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,135 +207,22 @@ __global__ __launch_bounds__(K::NT) void hiera_mlp_kernel(HmArgs p) {
         }
     };
 
-    if constexpr (!PIPE) {
-        load_chunk(0);
-        store_chunk(0);
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int ch = 0; ch < K::NCH; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < K::NCH) load_chunk(ch + 1);
+        const char* st = smem + buf * K::STAGE;
+        // ---- all H^T blocks of the chunk first (MFMAs back to back), then per block the vector work followed by its Y^T MFMAs -- block 1's GELU has no dependence
+        //      on block 0's MFMAs, so the two pipes can overlap
+        f32x16 acc[NHB];
+#pragma unroll
+        for (int hb = 0; hb < NHB; ++hb) first_product(acc[hb], st, hb);
+#pragma unroll
+        for (int hb = 0; hb < NHB; ++hb) second_product(acc[hb], st, hb);
+        if (ch + 1 < K::NCH) store_chunk(buf ^ 1);
         __syncthreads();
-        for (int ch = 0; ch < K::NCH; ++ch) {
-            const int buf = ch & 1;
-            if (ch + 1 < K::NCH) load_chunk(ch + 1);
-            const char* st = smem + buf * K::STAGE;
-            // ---- all H^T blocks of the chunk first (MFMAs back to back), then per block the vector work followed by its Y^T MFMAs -- block 1's GELU has no dependence
-            //      on block 0's MFMAs, so the two pipes can overlap
-            f32x16 acc[NHB];
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb) first_product(acc[hb], st, hb);
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb) second_product(acc[hb], st, hb);
-            if (ch + 1 < K::NCH) store_chunk(buf ^ 1);
-            __syncthreads();
-        }
-    } else {
-        // ---- one wave per SIMD: chunk n + 1's first product runs UNDER chunk n's GELU.  A lone in-order wave overlaps its matrix and vector work only when the two
-        //      are interleaved in its instruction stream (an MFMA holds the issue port for 8 of its 32 cycles; ~6 vector instructions fit in the rest), so a
-        //      half-trip is:  every weight fragment of both products read up front (18 ds_read_b128 + 36 ds_read_b64, all in flight together: one LDS latency instead
-        //      of one per MFMA) -> { 1 MFMA of H(n + 1), ~9 vector instructions of GELU(n) } x 18 (sched_group_barrier pins the pattern) -> 18 MFMAs of Y += W2(n) G(n),
-        //      under which the next chunk's staging (global loads issued at the top, LDS stores at the end) proceeds.
-        //      Three LDS stages: in the half-trip of chunk n the first product reads W1' of stage (n + 1) % 3, the second product W2 / c / d of stage n % 3, and chunk
-        //      n + 2 (fetched to registers at the top) is stored into stage (n + 2) % 3, last read one barrier ago -- one barrier per chunk.  Two chunks per trip so that
-        //      the two accumulator sets keep their names (no runtime-indexed register arrays); stage offsets are scalar arithmetic.
-        static_assert(!PIPE || (NHB == 1 && K::NSTG == 3 && K::NCH % 2 == 0), "the pipelined form: one hidden block per chunk, three stages, chunk pairs");
-        auto stg = [&](int n) { return smem + (n % 3) * K::STAGE; };
-        // one piece of store_chunk: piece j < NJ1 is W1' register j, NJ1 <= j < NJ1 + NJ2 is W2 register j - NJ1 (two 8-byte stores), the last piece also stores c / d
-        auto store_piece = [&](int buf, int j) {
-            char* base = smem + buf * K::STAGE;
-            if (j < K::NJ1) {
-                const int idx = tid + j * NT;
-                if (idx < K::W1P) *(u32x4*)(base + (idx / (C / 8)) * K::W1STR + (idx % (C / 8)) * 16) = w1r[j];
-            } else if (j < K::NJ1 + K::NJ2) {
-                const int idx = tid + (j - K::NJ1) * NT;
-                if (idx < K::W2P) {
-                    char* d = base + K::W1B + (idx / (HC / 8)) * K::W2STR + (idx % (HC / 8)) * 16;
-                    *(u32x2*)d = u32x2{w2r[j - K::NJ1][0], w2r[j - K::NJ1][1]};
-                    *(u32x2*)(d + 8) = u32x2{w2r[j - K::NJ1][2], w2r[j - K::NJ1][3]};
-                }
-                if (j == K::NJ1 + K::NJ2 - 1 && tid < 2 * HC) *(float*)(base + K::W1B + K::W2B + tid * 4) = cr;
-            }
-        };
-        static_assert(!PIPE || (K::NJ1 + K::NJ2 <= 2 * CB && 2 * CB == KS), "the pipelined form pairs one W2 fragment and one staging piece with every MFMA");
-        auto half = [&](f32x16& accN, const f32x16& accC, const char* stN, const char* stC, int sbuf) {
-            // ---- W1' fragments of chunk n + 1 and the fold constants of chunk n: all reads in flight together
-            bf16x8 a1[KS];
-            f32x4 cc[4], dd[4];
-            {
-                const char* a0 = stN + r * K::W1STR + h * 16;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) a1[ks] = *(const bf16x8*)(a0 + ks * 32);
-                const float* cs = (const float*)(stC + K::W1B + K::W2B);
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    cc[i4] = *(const f32x4*)(cs + 8 * i4 + 4 * h);
-                    dd[i4] = *(const f32x4*)(cs + HC + 8 * i4 + 4 * h);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) accN[i] = 0.f;
-            u32x4 a2[CB][2];
-            unsigned pkv[8], gk[8];
-            float q[16];
-            const char* w2b = stC + K::W1B + r * K::W2STR + 8 * h;
-            // ---- 18 x { one MFMA of H(n + 1); one W2 fragment of chunk n; one step of GELU(n) }.  GELU of value pair p (accumulator registers 2p, 2p + 1) in two steps:
-            //      A(p) at MFMA 2p: LayerNorm fold, bf16 rounding, table addresses, the two ds_read_b32; B(p) three MFMAs later: relu - |t| T(|t|), bf16 pair.
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[k], xf[k], accN, 0, 0, 0);
-                {
-                    const char* b0 = w2b + (k >> 1) * 32 * K::W2STR + 32 * (k & 1);
-                    const u32x2 lo = *(const u32x2*)b0, hi = *(const u32x2*)(b0 + 16);
-                    a2[k >> 1][k & 1] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                }
-                if ((k & 1) == 0 && (k >> 1) < 8) {
-                    const int pp = k >> 1, i4 = pp >> 1, e = 2 * (pp & 1);
-                    const float v0 = __builtin_fmaf(rinv, accC[2 * pp], __builtin_fmaf(nmr, cc[i4][e], dd[i4][e]));
-                    const float v1 = __builtin_fmaf(rinv, accC[2 * pp + 1], __builtin_fmaf(nmr, cc[i4][e + 1], dd[i4][e + 1]));
-                    unsigned pk = pack_bf2(v0, v1);
-                    asm("" : "+v"(pk));
-                    constexpr unsigned LO = kActTabLoBits, HI = kActTabLoBits + kActTabN - 1;
-                    const unsigned m0 = pk & 0x7fffu, m1 = __builtin_amdgcn_ubfe(pk, 16, 15);
-                    const unsigned ad0 = (min(max(m0, LO), HI) << 2) + tb, ad1 = (min(max(m1, LO), HI) << 2) + tb;
-                    q[2 * pp] = *(lds_cfloat*)(size_t)ad0;
-                    q[2 * pp + 1] = *(lds_cfloat*)(size_t)ad1;
-                    pkv[pp] = pk;
-                }
-                if (k >= 3 && (k & 1) == 1 && ((k - 3) >> 1) < 8) {
-                    const int pp = (k - 3) >> 1;
-                    const unsigned t0 = pkv[pp] << 16, t1 = pkv[pp] & 0xffff0000u;
-                    const int r0 = max((int)t0, 0), r1 = max((int)t1, 0);
-                    float y0, y1;
-                    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y0) : "v"(t0), "v"(q[2 * pp]), "v"(r0));
-                    asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y1) : "v"(t1), "v"(q[2 * pp + 1]), "v"(r1));
-                    gk[pp] = pack_bf2(y0, y1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            bf16x8 gb[2];
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) gb[ss] = __builtin_bit_cast(bf16x8, u32x4{gk[4 * ss], gk[4 * ss + 1], gk[4 * ss + 2], gk[4 * ss + 3]});
-            // ---- Y^T += W2(n) G(n): 18 MFMAs, one piece of the next chunk's LDS staging beside each (stale registers in the last trip: stored, never read)
-#pragma unroll
-            for (int k = 0; k < 2 * CB; ++k) {
-                y[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2[k >> 1][k & 1]), gb[k & 1], y[k >> 1], 0, 0, 0);
-                store_piece(sbuf, k);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        load_chunk(0);
-        store_chunk(0);
-        load_chunk(1);
-        store_chunk(1);
-        __syncthreads();
-        f32x16 accA, accB;
-        first_product(accA, stg(0), 0);
-#pragma unroll 1
-        for (int ch = 0; ch < K::NCH; ch += 2) {
-            if (ch + 2 < K::NCH) load_chunk(ch + 2);
-            half(accB, accA, stg(ch + 1), stg(ch), (ch + 2) % 3);    // H(ch + 1) under GELU(ch), then Y += W2(ch) G(ch) with chunk ch + 2 going into its stage
-            __syncthreads();
-            if (ch + 3 < K::NCH) load_chunk(ch + 3);
-            half(accA, accB, stg(ch + 2), stg(ch + 1), (ch + 3) % 3);  // (the last trip's H(NCH) reads a stale stage: computed, never used)
-            __syncthreads();
-        }
     }
     // ---- epilogue: + b2 + x, one bf16 rounding; the tile is transposed through LDS (now free) so that whole rows leave
     char* ot = smem;
@@ -361,9 +248,240 @@ __global__ __launch_bounds__(K::NT) void hiera_mlp_kernel(HmArgs p) {
     }
 }
 
-template <class K, bool PIPE>
+
+// ================================================================================================ stage 2: C = 288, one wave per SIMD
+// X^T (72) + Y^T (144) + two H accumulator sets (32) registers per lane do not fit 256: 4 waves x 32 tokens on the 512-register budget, hidden chunks of 32.
+// A lone in-order wave overlaps matrix and vector work only where the two are interleaved in its instruction stream (an MFMA holds the issue port for 8 of its 32
+// cycles), so the loop is hand-scheduled: a HALF-TRIP of chunk n is
+//     the first six W1' fragments of chunk n + 1 + the fold constants of chunk n read up front (one LDS latency, not one per MFMA), the rest six MFMAs ahead
+//  -> { 1 MFMA of H(n + 1) ; 1 W2 fragment of chunk n ; one step of GELU(n) } x 18      (sched_barrier walls pin the order)
+//  -> { 1 MFMA of Y += W2(n) G(n) ; one LDS-DMA piece of a later chunk } x 18
+// Weight chunks come from PACKED images in global memory (rga3_hiera_mlp288_pack: per chunk the exact LDS bytes -- W1' rows padded to 592 B, W2 rows to 72 B, then c
+// and d as f32 -- so a chunk is 19 + 21 one-KiB LDS-DMA pieces, lane-linear, no staging registers, no ds_write, no address arithmetic).  W1' and W2 of the same chunk
+// are read one half-trip apart, so they live in SEPARATE three-slot rings: W1'(c) [slot c % 3] is read in half-trip c - 1 and refilled from half-trip c - 3 on;
+// W2(c) is read in half-trip c and refilled from c - 2 on.  Half-trip n issues W1'(n + 3) and W2(n + 2): every piece has a whole half-trip to land before the counted
+// wait in front of the barrier that precedes its first read (register-staged, the same data was waited for INSIDE the half-trip that fetched it: 0.33 -> 0.22 ms
+// per block and 8 frames with the staging ablated).
+namespace hm288 {
+constexpr int C = 288, H = 1152, HC = 32, NCH = H / HC, KS = C / 16, CB = C / 32, NW = 4, NT = 256, TOK = 128;
+constexpr int W1STR = C * 2 + 16, W2STR = HC * 2 + 8;
+constexpr int W1B = HC * W1STR;                     // 18 944
+constexpr int W2B = C * W2STR;                      // 20 736, then c[32] d[32] f32
+constexpr int W1P = 19, W2P = 21;                   // one-KiB pieces per chunk image
+constexpr int W1S = W1P * 1024, W2S = W2P * 1024;   // ring slots = image sizes
+constexpr int RW1 = 0, RW2 = 3 * W1S, TAB = 3 * W1S + 3 * W2S;
+constexpr int LDS = TAB + kActTabBytes;             // 133 120
+constexpr int OSTR = C * 2 + 16;
+static_assert(W1B <= W1S && W2B + HC * 8 <= W2S && TOK * OSTR <= TAB && LDS <= 160 * 1024 && NCH % 2 == 0 && 2 * CB == KS, "hiera_mlp288: configuration");
+}  // namespace hm288
+
+struct Hm288Args {
+    const unsigned short* x;   // [M, 288] bf16
+    const char* pack;          // [36][W1S + W2S] bytes (rga3_hiera_mlp288_pack)
+    const unsigned short* b2;  // [288] bf16
+    unsigned short* y;         // [M, 288] bf16
+    long M;
+    float eps;
+};
+
+__global__ __launch_bounds__(hm288::NT) void hiera_mlp288_kernel(Hm288Args p) {
+    using namespace hm288;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long tok0 = (long)blockIdx.x * TOK;
+    const long tok = tok0 + wave * 32 + r;
+    const long tokc = tok < p.M ? tok : p.M - 1;
+
+    // ---- LDS-DMA of chunk images: piece pc of an image = 1 KiB, lane-linear on both sides; wave w takes pieces w, w + 4, ...
+    const char* const psrc = p.pack + lane * 16;
+    auto dma_w1_piece = [&](int ch, int j) {      // j-th piece of this wave
+        const int pc = wave + 4 * j;
+        if (pc < W1P) __builtin_amdgcn_global_load_lds((gbl_void*)(psrc + (long)ch * (W1S + W2S) + pc * 1024), (lds_void*)(smem + RW1 + (ch % 3) * W1S + pc * 1024), 16, 0, 0);
+    };
+    auto dma_w2_piece = [&](int ch, int j) {
+        const int pc = wave + 4 * j;
+        if (pc < W2P) __builtin_amdgcn_global_load_lds((gbl_void*)(psrc + (long)ch * (W1S + W2S) + W1S + pc * 1024), (lds_void*)(smem + RW2 + (ch % 3) * W2S + pc * 1024), 16, 0, 0);
+    };
+    constexpr int J1 = (W1P + 3) / 4, J2 = (W2P + 3) / 4;   // 5, 6 issue slots per wave
+    // prologue: W1'(0..2), W2(0..1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < J1; ++j) dma_w1_piece(c, j);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < J2; ++j) dma_w2_piece(c, j);
+
+    // ---- this wave's 32 tokens as B operands: lane (r, h) holds x[tok][16 ks + 8 h .. + 8]
+    bf16x8 xf[KS];
+    {
+        const unsigned short* xr = p.x + tokc * C + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const bf16x8*)(xr + 16 * ks);
+    }
+    float rinv, nmr;     // h = rinv acc + (d - mean rinv c)
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)xf[ks][e];
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)xf[ks][e] - mean;
+                q += d * d;
+            }
+        q += __shfl_xor(q, 32, 64);
+        rinv = __builtin_amdgcn_rsqf(q * (1.0f / C) + p.eps);
+        nmr = -mean * rinv;
+    }
+    // the ordinary loads above are consumed (the statistics read every fragment): no pending VGPR load is left for the compiler to drain the LDS-DMAs behind
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
+    // the GELU table (10 KiB) behind the rings
+    for (int i = tid; i < kActTabN; i += NT) *(unsigned*)(smem + TAB + i * 4) = g_act_tab[0][i];
+    const unsigned tb = act_tab_base(smem + TAB);
+
+    f32x16 y[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[cb][i] = 0.f;
+
+    auto w1slot = [&](int c) { return smem + RW1 + (c % 3) * W1S; };
+    auto w2slot = [&](int c) { return smem + RW2 + (c % 3) * W2S; };
+    auto first_product = [&](f32x16& acc, const char* w1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const char* a0 = w1 + r * W1STR + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(a0 + ks * 32), xf[ks], acc, 0, 0, 0);
+    };
+    // half-trip of chunk n: accN = H(n + 1) from w1n, Y += W2(n) gelu(fold(accC)) from w2c; DMA of W1'(n + 3) and W2(n + 2) in the second product's gaps
+    auto half = [&](f32x16& accN, const f32x16& accC, const char* w1n, const char* w2c, int n) {
+        bf16x8 a1[KS];
+        f32x4 cc[4], dd[4];
+        constexpr int PRE = 6;     // W1' fragments read ahead of their MFMA: all 18 up front is 104 KiB per CU = 400 cycles of the LDS array with nothing to overlap
+        const char* const a0 = w1n + r * W1STR + h * 16;
+        {
+#pragma unroll
+            for (int ks = 0; ks < PRE; ++ks) a1[ks] = *(const bf16x8*)(a0 + ks * 32);
+            const float* cs = (const float*)(w2c + W2B);
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                cc[i4] = *(const f32x4*)(cs + 8 * i4 + 4 * h);
+                dd[i4] = *(const f32x4*)(cs + HC + 8 * i4 + 4 * h);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accN[i] = 0.f;
+        u32x4 a2[CB][2];
+        unsigned pkv[8], gk[8];
+        float q[16];
+        const char* w2b = w2c + r * W2STR + 8 * h;
+        // GELU of value pair pp (accumulator registers 2 pp, 2 pp + 1) in two steps: A(pp) at MFMA 2 pp: LayerNorm fold, bf16 rounding, table addresses, the two
+        // ds_read_b32; B(pp) three MFMAs later: relu - |t| T(|t|), bf16 pair
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[k], xf[k], accN, 0, 0, 0);
+            if (k + PRE < KS) a1[k + PRE] = *(const bf16x8*)(a0 + (k + PRE) * 32);
+            {
+                const char* b0 = w2b + (k >> 1) * 32 * W2STR + 32 * (k & 1);
+                const u32x2 lo = *(const u32x2*)b0, hi = *(const u32x2*)(b0 + 16);
+                a2[k >> 1][k & 1] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            if ((k & 1) == 0 && (k >> 1) < 8) {
+                const int pp = k >> 1, i4 = pp >> 1, e = 2 * (pp & 1);
+                const float v0 = __builtin_fmaf(rinv, accC[2 * pp], __builtin_fmaf(nmr, cc[i4][e], dd[i4][e]));
+                const float v1 = __builtin_fmaf(rinv, accC[2 * pp + 1], __builtin_fmaf(nmr, cc[i4][e + 1], dd[i4][e + 1]));
+                unsigned pk = pack_bf2(v0, v1);
+                asm("" : "+v"(pk));
+                constexpr unsigned LO = kActTabLoBits, HI = kActTabLoBits + kActTabN - 1;
+                const unsigned m0 = pk & 0x7fffu, m1 = __builtin_amdgcn_ubfe(pk, 16, 15);
+                const unsigned ad0 = (min(max(m0, LO), HI) << 2) + tb, ad1 = (min(max(m1, LO), HI) << 2) + tb;
+                q[2 * pp] = *(lds_cfloat*)(size_t)ad0;
+                q[2 * pp + 1] = *(lds_cfloat*)(size_t)ad1;
+                pkv[pp] = pk;
+            }
+            if (k >= 3 && (k & 1) == 1 && ((k - 3) >> 1) < 8) {
+                const int pp = (k - 3) >> 1;
+                const unsigned t0 = pkv[pp] << 16, t1 = pkv[pp] & 0xffff0000u;
+                const int r0 = max((int)t0, 0), r1 = max((int)t1, 0);
+                float y0, y1;
+                asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y0) : "v"(t0), "v"(q[2 * pp]), "v"(r0));
+                asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(y1) : "v"(t1), "v"(q[2 * pp + 1]), "v"(r1));
+                gk[pp] = pack_bf2(y0, y1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bf16x8 gb[2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) gb[ss] = __builtin_bit_cast(bf16x8, u32x4{gk[4 * ss], gk[4 * ss + 1], gk[4 * ss + 2], gk[4 * ss + 3]});
+        const bool f1 = n + 3 < NCH, f2 = n + 2 < NCH;     // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 2 * CB; ++k) {
+            y[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2[k >> 1][k & 1]), gb[k & 1], y[k >> 1], 0, 0, 0);
+            if (k < J1) { if (f1) dma_w1_piece(n + 3, k); }
+            else if (k < J1 + J2) { if (f2) dma_w2_piece(n + 2, k - J1); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // what the NEXT half-trip reads (W1'(n + 2), W2(n + 1)) was issued one half-trip ago or earlier: everything but this half-trip's own pieces must have landed.
+        // Pieces per wave and half-trip: 5 + 6 (wave 0), 5 + 5 (waves 1, 2), 4 + 5 (wave 3); in the last three half-trips fewer are issued: drain.
+        if (f1) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else if (wave == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 accA, accB;
+    first_product(accA, w1slot(0));
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ch += 2) {
+        half(accB, accA, w1slot(ch + 1), w2slot(ch), ch);
+        half(accA, accB, w1slot(ch + 2), w2slot(ch + 1), ch + 1);     // (the last trip's H(NCH) reads a stale slot: computed, never used)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- epilogue: + b2 + x, one bf16 rounding; the tile is transposed through LDS (the rings are free) so that whole rows leave
+    char* ot = smem;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int c = cb * 32 + 8 * i4 + 4 * h;
+            const u32x2 xb = *(const u32x2*)(p.x + tokc * C + c);
+            const u32x2 bb = *(const u32x2*)(p.b2 + c);
+            const float v0 = y[cb][4 * i4 + 0] + __uint_as_float(bb[0] << 16) + __uint_as_float(xb[0] << 16);
+            const float v1 = y[cb][4 * i4 + 1] + __uint_as_float(bb[0] & 0xffff0000u) + __uint_as_float(xb[0] & 0xffff0000u);
+            const float v2 = y[cb][4 * i4 + 2] + __uint_as_float(bb[1] << 16) + __uint_as_float(xb[1] << 16);
+            const float v3 = y[cb][4 * i4 + 3] + __uint_as_float(bb[1] & 0xffff0000u) + __uint_as_float(xb[1] & 0xffff0000u);
+            *(u32x2*)(ot + (wave * 32 + r) * OSTR + c * 2) = u32x2{pack_bf2(v0, v1), pack_bf2(v2, v3)};
+        }
+    __syncthreads();
+    for (int idx = tid; idx < TOK * (C / 8); idx += NT) {
+        const int row = idx / (C / 8), c16 = idx % (C / 8);
+        if (tok0 + row < p.M) *(u32x4*)(p.y + (tok0 + row) * C + c16 * 8) = *(const u32x4*)(ot + row * OSTR + c16 * 16);
+    }
+}
+
+template <class K>
 static int launch_hiera_mlp(const HmArgs& a, hipStream_t st, const char* name) {
-    auto kern = hiera_mlp_kernel<K, PIPE>;
+    auto kern = hiera_mlp_kernel<K>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, K::LDS, lds_grant, name)) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(a.M, K::TOK)), dim3(K::NT), K::LDS, st, a);
@@ -375,23 +493,65 @@ static int launch_hiera_mlp(const HmArgs& a, hipStream_t st, const char* name) {
 
 using namespace rga3;
 
-// y [M, C] = x + W2 gelu(LayerNorm(x; eps) folded into W1f / c1 / d1) + b2   (Hiera MLP, dims C -> 4 C -> C; C = 144: stage 1, C = 288: stage 2), all bf16 except c1
-// (f32).  w1f / c1 / d1 as rga3_gemm_ln_bf16 takes them: W1 diag(gamma) rounded to bf16, its row sums in f32, beta W1^T + b1 in bf16.  x, y contiguous, 16-byte aligned.
-extern "C" int rga3_hiera_mlp(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, int C, float eps,
-                              void* stream) {
-    RGA3_CHECK_ARG(x && w1f && c1 && d1 && w2 && b2 && y && M > 0, "hiera_mlp: null pointer / M %ld", (long)M);
-    RGA3_CHECK_ARG(C == 144 || C == 288, "hiera_mlp: C = %d (144: Hiera-L stage 1, 288: stage 2)", C);
-    RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1f | (uintptr_t)w2 | (uintptr_t)y | (uintptr_t)c1) & 15) == 0 && (((uintptr_t)b2 | (uintptr_t)d1) & 7) == 0, "hiera_mlp: alignment");
-    RGA3_CHECK_ARG(x != y, "hiera_mlp: in place is not supported (the residual is re-read)");
+// y [M, 144] = x + W2 gelu(LayerNorm(x; eps) folded into W1f / c1 / d1) + b2   (Hiera-L stage-1 MLP, 144 -> 576 -> 144), all bf16 except c1 (f32).  w1f / c1 / d1 as
+// rga3_gemm_ln_bf16 takes them: W1 diag(gamma) rounded to bf16, its row sums in f32, beta W1^T + b1 in bf16.  x, y contiguous, 16-byte aligned.
+extern "C" int rga3_hiera_mlp144(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, float eps,
+                                 void* stream) {
+    RGA3_CHECK_ARG(x && w1f && c1 && d1 && w2 && b2 && y && M > 0, "hiera_mlp144: null pointer / M %ld", (long)M);
+    RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1f | (uintptr_t)w2 | (uintptr_t)y | (uintptr_t)c1) & 15) == 0 && (((uintptr_t)b2 | (uintptr_t)d1) & 7) == 0, "hiera_mlp144: alignment");
+    RGA3_CHECK_ARG(x != y, "hiera_mlp144: in place is not supported (the residual is re-read)");
     HmArgs a;
     a.x = (const unsigned short*)x; a.w1f = (const unsigned short*)w1f; a.c1 = c1; a.d1 = (const unsigned short*)d1;
     a.w2 = (const unsigned short*)w2; a.b2 = (const unsigned short*)b2; a.y = (unsigned short*)y; a.M = M; a.eps = eps;
-    if (C == 144) return launch_hiera_mlp<HmCfg<144, 8, 64, 2>, false>(a, (hipStream_t)stream, "hiera_mlp_kernel<144>");
-    return launch_hiera_mlp<HmCfg<288, 4, 32, 3>, true>(a, (hipStream_t)stream, "hiera_mlp_kernel<288>");
+    return launch_hiera_mlp<HmCfg<144, 8, 64, 2>>(a, (hipStream_t)stream, "hiera_mlp_kernel<144>");
 }
 
-// the round-3 entry point (stage 1 only), kept for callers bound to it
-extern "C" int rga3_hiera_mlp144(const void* x, const void* w1f, const float* c1, const void* d1, const void* w2, const void* b2, void* y, int64_t M, float eps,
-                                 void* stream) {
-    return rga3_hiera_mlp(x, w1f, c1, d1, w2, b2, y, M, 144, eps, stream);
+// Stage 2 (288 -> 1152 -> 288).  The weights are handed over PACKED, once per block (they are frozen): rga3_hiera_mlp288_pack_bytes() bytes, 36 chunk images of
+// 19 + 21 KiB; image of hidden chunk ch (32 hidden units):
+//   [0, 18 944)            W1' rows 32 ch .. 32 ch + 31: 288 bf16 each, row stride 592 B (16 B of padding)
+//   [19 456, 19 456 + 20 736)   W2 rows 0 .. 287, columns 32 ch .. 32 ch + 31: 32 bf16 each, row stride 72 B (8 B of padding)
+//   then 32 f32 c (row sums of W1'), 32 f32 d (folded bias)         (unused bytes: anything)
+// rga3_hiera_mlp288_pack builds it on the device from the operands of the C = 144 form.
+extern "C" int64_t rga3_hiera_mlp288_pack_bytes(void) { return (int64_t)hm288::NCH * (hm288::W1S + hm288::W2S); }
+
+__global__ void hiera_mlp288_pack_kernel(const unsigned short* w1f, const float* c1, const unsigned short* d1, const unsigned short* w2, char* pack) {
+    using namespace hm288;
+    const int ch = blockIdx.x;
+    char* img = pack + (long)ch * (W1S + W2S);
+    for (int i = threadIdx.x; i < (W1S + W2S) / 4; i += blockDim.x) ((unsigned*)img)[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HC * C; i += blockDim.x) {
+        const int row = i / C, col = i % C;
+        *(unsigned short*)(img + row * W1STR + col * 2) = w1f[(long)(ch * HC + row) * C + col];
+    }
+    for (int i = threadIdx.x; i < C * HC; i += blockDim.x) {
+        const int row = i / HC, col = i % HC;
+        *(unsigned short*)(img + W1S + row * W2STR + col * 2) = w2[(long)row * H + ch * HC + col];
+    }
+    if (threadIdx.x < HC) {
+        ((float*)(img + W1S + W2B))[threadIdx.x] = c1[ch * HC + threadIdx.x];
+        ((float*)(img + W1S + W2B))[HC + threadIdx.x] = bf2f(d1[ch * HC + threadIdx.x]);
+    }
+}
+
+extern "C" int rga3_hiera_mlp288_pack(const void* w1f, const float* c1, const void* d1, const void* w2, void* pack, void* stream) {
+    RGA3_CHECK_ARG(w1f && c1 && d1 && w2 && pack && (((uintptr_t)pack) & 15) == 0, "hiera_mlp288_pack: null pointer / alignment");
+    hipLaunchKernelGGL(hiera_mlp288_pack_kernel, dim3(hm288::NCH), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)w1f, c1, (const unsigned short*)d1,
+                       (const unsigned short*)w2, (char*)pack);
+    RGA3_CHECK_LAUNCH("hiera_mlp288_pack_kernel");
+    return 0;
+}
+
+// y [M, 288] = x + W2 gelu(LayerNorm(x; eps) W1^T + b1) + b2 from the packed weights; x, y contiguous bf16, 16-byte aligned, x != y.
+extern "C" int rga3_hiera_mlp288(const void* x, const void* pack, const void* b2, void* y, int64_t M, float eps, void* stream) {
+    RGA3_CHECK_ARG(x && pack && b2 && y && M > 0, "hiera_mlp288: null pointer / M %ld", (long)M);
+    RGA3_CHECK_ARG((((uintptr_t)x | (uintptr_t)pack | (uintptr_t)y) & 15) == 0 && (((uintptr_t)b2) & 7) == 0, "hiera_mlp288: alignment");
+    RGA3_CHECK_ARG(x != y, "hiera_mlp288: in place is not supported (the residual is re-read)");
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)hiera_mlp288_kernel, hm288::LDS, lds_grant, "hiera_mlp288")) return rc;
+    Hm288Args a;
+    a.x = (const unsigned short*)x; a.pack = (const char*)pack; a.b2 = (const unsigned short*)b2; a.y = (unsigned short*)y; a.M = M; a.eps = eps;
+    hipLaunchKernelGGL(hiera_mlp288_kernel, dim3((unsigned)cdiv(M, hm288::TOK)), dim3(hm288::NT), hm288::LDS, (hipStream_t)stream, a);
+    RGA3_CHECK_LAUNCH("hiera_mlp288_kernel");
+    return 0;
 }

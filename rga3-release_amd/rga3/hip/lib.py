@@ -58,7 +58,9 @@ SIGNATURES = {
     "rga3_attn_varlen_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _i, _i, _p, _f, _i, _p, _i64, _p],
     "rga3_transpose16_many": [_p, _p, _i, _p],
     "rga3_hiera_mlp144": [_p, _p, _p, _p, _p, _p, _p, _i64, _f, _p],
-    "rga3_hiera_mlp": [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _p],
+    "rga3_hiera_mlp288_pack_bytes": [],
+    "rga3_hiera_mlp288_pack": [_p, _p, _p, _p, _p, _p],
+    "rga3_hiera_mlp288": [_p, _p, _p, _p, _i64, _f, _p],
     "rga3_mlp3_rows": [_p, _p, _i, _i64, _p],
     "rga3_sam_select_objptr": [_p, _p, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
     "rga3_memattn_cross_ws_floats": [_i64, _i],
@@ -103,7 +105,7 @@ SIGNATURES = {
     "rga3_bce_dice_grad_dev": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p],
 }
 
-_INT64_RESULTS = ("rga3_gemm_workspace_bytes", "rga3_memattn_cross_ws_floats", "rga3_gemm_timeout_counter_offset", "rga3_layernorm_bwd_ws_floats", "rga3_colsum_ws_floats", "rga3_mask_product_bwd_ws_floats", "rga3_bce_dice_sums_ws_floats")
+_INT64_RESULTS = ("rga3_hiera_mlp288_pack_bytes", "rga3_gemm_workspace_bytes", "rga3_memattn_cross_ws_floats", "rga3_gemm_timeout_counter_offset", "rga3_layernorm_bwd_ws_floats", "rga3_colsum_ws_floats", "rga3_mask_product_bwd_ws_floats", "rga3_bce_dice_sums_ws_floats")
 
 _lib = None
 

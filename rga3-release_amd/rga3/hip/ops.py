@@ -254,17 +254,38 @@ def fold_layernorm(weight, bias, gamma, beta):
     return wf, colc, bf.to(torch.bfloat16).contiguous()
 
 
+_hm288_packs = {}   # (pointers + versions of the folded operands) -> (packed chunk images, the operands themselves: kept alive so that an address cannot be recycled)
+
+
+def _hiera_mlp288_pack(wf, colc, biasf, w2):
+    """The 36 chunk images rga3_hiera_mlp288 streams by LDS-DMA (csrc/hiera_mlp.hip), built once per frozen block."""
+    key = (wf.data_ptr(), wf._version, colc.data_ptr(), colc._version, biasf.data_ptr(), biasf._version, w2.data_ptr(), w2._version)
+    hit = _hm288_packs.get(key)
+    if hit is None:
+        L = _lib.load()
+        pack = torch.empty(int(L.rga3_hiera_mlp288_pack_bytes()), dtype=torch.uint8, device=wf.device)
+        _lib.check(L.rga3_hiera_mlp288_pack(wf.data_ptr(), colc.data_ptr(), biasf.data_ptr(), w2.data_ptr(), pack.data_ptr(), _stream()), "hiera_mlp288_pack")
+        if len(_hm288_packs) > 64:
+            _hm288_packs.clear()
+        hit = _hm288_packs[key] = (pack, (wf, colc, biasf, w2))
+    return hit[0]
+
+
 def hiera_mlp(x, wf, colc, biasf, w2, b2, eps: float):
-    """x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 for the C -> 4 C -> C MLP of a frozen Hiera block in one launch (csrc/hiera_mlp.hip), C = 144 (stage 1) or 288 (stage 2);
-    (wf, colc, biasf) = fold_layernorm(W1, b1, gamma, beta)."""
+    """x + W2 gelu(LayerNorm(x) W1^T + b1) + b2 for the C -> 4 C -> C MLP of a frozen Hiera block in one launch (csrc/hiera_mlp.hip), C = 144 (stage 1) or 288 (stage 2:
+    the weights travel as packed chunk images, built on first use and kept per weight version); (wf, colc, biasf) = fold_layernorm(W1, b1, gamma, beta)."""
     _need_cuda(x, wf, colc, biasf, w2, b2)
     assert x.dtype == wf.dtype == w2.dtype == b2.dtype == biasf.dtype == torch.bfloat16 and colc.dtype == torch.float32
     C = x.shape[1]
     assert x.dim() == 2 and C in (144, 288) and x.is_contiguous() and tuple(wf.shape) == (4 * C, C) and tuple(w2.shape) == (C, 4 * C) and wf.is_contiguous() and w2.is_contiguous()
     assert colc.numel() == 4 * C and biasf.numel() == 4 * C and b2.numel() == C and colc.is_contiguous() and biasf.is_contiguous() and b2.is_contiguous()
     y = torch.empty_like(x)
-    _lib.check(_lib.load().rga3_hiera_mlp(x.data_ptr(), wf.data_ptr(), colc.data_ptr(), biasf.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(), x.shape[0], C,
-                                          float(eps), _stream()), "hiera_mlp")
+    if C == 288:
+        pack = _hiera_mlp288_pack(wf, colc, biasf, w2)
+        _lib.check(_lib.load().rga3_hiera_mlp288(x.data_ptr(), pack.data_ptr(), b2.data_ptr(), y.data_ptr(), x.shape[0], float(eps), _stream()), "hiera_mlp288")
+    else:
+        _lib.check(_lib.load().rga3_hiera_mlp144(x.data_ptr(), wf.data_ptr(), colc.data_ptr(), biasf.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(), x.shape[0],
+                                                 float(eps), _stream()), "hiera_mlp144")
     return y
 
 

@@ -5,7 +5,9 @@
   summarise  python3 tools/pmc_pipe_util.py sum <dir> <out.json>    reads every *counter_collection.csv under <dir> (one sub-directory per pass)
 
 Targets (kernel name needle -> the call that launches it at the shape of the headline step / configs[1] forward / configs[3] stream):
-  gemm_nt_sk_kernel<2,       LLM gate-up with the SwiGLU epilogue, 2112 x 37888 x 3584 (tile 22)
+  gemm_nt_sk_kernel<2, false, 4>   LLM gate-up with the SwiGLU epilogue, 2112 x 37888 x 3584 (tile 22)
+  gemm_nt_sk_kernel<0, false, 3>   the three-phase 192-row loop at the decoder's q|k|v shape, 2112 x 4608 x 3584 (tile 31)
+  hiera_mlp_kernel<HmCfg<144 / 288   fused Hiera MLP of stage 1 / stage 2 on 8 frames
   gemm_nt_sk_kernel<0,       LLM down projection + residual, 2112 x 3584 x 18944 (tile 22)
   gemm_nt_kernel<128, 192    Hiera-L stage-3 qkv, 32768 x 1728 x 576 (8 frames; tile 5)
   gemm_nt_kernel<128, 256    LLM o-proj + residual, 2112 x 3584 x 3584 (tile 3)
@@ -32,8 +34,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-TARGETS = ["gemm_nt_sk_kernel<2,", "gemm_nt_sk_kernel<0,", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel<0, false, false, true>", "gemm_nt_pp_kernel<1, false, true, false>", "attn_fwd_kernel<128", "attn_causal32_kernel",
-           "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_win_kernel<96, 8", "memattn_cross_kernel", "hiera_mlp576_kernel"]
+TARGETS = ["gemm_nt_sk_kernel<2, false, 4>", "gemm_nt_sk_kernel<0, false, 4>", "gemm_nt_sk_kernel<0, false, 3>", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel<0, false, false, true>", "gemm_nt_pp_kernel<1, false, true, false>", "attn_fwd_kernel<128", "attn_causal32_kernel",
+           "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_win_kernel<96, 8", "memattn_cross_kernel", "hiera_mlp_kernel<rga3::HmCfg<144", "hiera_mlp_kernel<rga3::HmCfg<288"]
 
 
 def run():
@@ -59,6 +61,11 @@ def run():
     for i in range(R):
         ops.gemm(h, wd[i % 2], residual=x, tile=22)
     del wd, h
+    # the three-phase 192-row loop at the decoder's q|k|v shape (round 5; tile 31: 11 x 18 tiles, one round)
+    wqkv = [rn(4608, 3584, scale=0.02) for _ in range(4)]
+    for i in range(2 * R):
+        ops.gemm(x, wqkv[i % 4], bias=rn(4608), tile=31)
+    del wqkv
     wo = [rn(3584, 3584, scale=0.02) for _ in range(8)]
     for i in range(2 * R):
         ops.gemm(x, wo[i % 8], residual=x, tile=3)
@@ -92,6 +99,14 @@ def run():
     for i in range(R):
         ops.gemm_ln(xr, st, wf, colc, bfold, act="gelu", tile=20)
     del xh, w2h
+    # ---- fused Hiera MLP, stage 1 (8 frames: 524 288 rows x 144) and stage 2 (131 072 rows x 288)
+    for C, rows in ((144, 8 * 65536), (288, 8 * 16384)):
+        xm = rn(rows, C)
+        wf2, colc2, bf2 = ops.fold_layernorm(rn(4 * C, C, scale=0.05), rn(4 * C), rn(C) + 1, rn(C, scale=0.1))
+        w2m, b2m = rn(C, 4 * C, scale=0.05), rn(C)
+        for i in range(R):
+            ops.hiera_mlp(xm, wf2, colc2, bf2, w2m, b2m, 1e-6)
+        del xm
     # ---- SAM2 memory cross-attention at the full bank
     mq, mk, mm = rn(4096, 256), rn(28736, 256), rn(28736, 64)
     for i in range(R):
