@@ -311,29 +311,53 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_bwd_dkv_kernel(AttnBwdArgs p)
     const int t0 = q_begin / BT;
     const int ntq = (Lq + BT - 1) / BT;
 
+    // Q / dO tiles (and their lse / delta) travel HBM -> registers -> LDS one tile AHEAD of their use, as the dQ kernel stages K / V: the loads of tile i + 1 are issued
+    // right after tile i is stored, so a whole tile of matrix work hides their latency (round 5; before, every tile was loaded and stored inside one barrier pair:
+    // 17 - 33 exposed memory round trips per workgroup)
+    u32x4 qreg[LOADS], oreg[LOADS];
+    float lreg = 0.f, dreg = 0.f;
+    auto load_tile = [&](int hq_, int qt_) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / CH, ch = idx % CH;
+            const int qi = qt_ * BT + r;
+            u32x4 zq = {0u, 0u, 0u, 0u}, zo = {0u, 0u, 0u, 0u};
+            if (qi < Lq && ch * 8 < p.D) {
+                zq = *(const u32x4*)(p.q + (long)(qs + qi) * p.q_st + (long)hq_ * p.q_sh + ch * 8);
+                zo = *(const u32x4*)(p.dout + (long)(qs + qi) * p.do_st + (long)hq_ * p.do_sh + ch * 8);
+            }
+            qreg[i] = zq;
+            oreg[i] = zo;
+        }
+        if (tid < BT) {
+            const int qi = qt_ * BT + tid;
+            lreg = (qi < Lq) ? p.lse[(long)hq_ * p.total_q + qs + qi] * 1.4426950408889634f : 0.f;
+            dreg = (qi < Lq) ? p.delta[(long)hq_ * p.total_q + qs + qi] : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / CH, ch = idx % CH;
+            *(u32x4*)(Qs + r * STRIDE + ch * 16) = qreg[i];
+            *(u32x4*)(Os + r * STRIDE + ch * 16) = oreg[i];
+        }
+        if (tid < BT) {
+            Ls[tid] = lreg;
+            Ls[BT + tid] = dreg;
+        }
+    };
+    if (t0 < ntq) load_tile(hk * group + hh0, t0);
     for (int hh = hh0; hh < hh1; ++hh) {
         const int hq = hk * group + hh;
         for (int qt = t0; qt < ntq; ++qt) {
             __syncthreads();  // previous tile fully consumed
-#pragma unroll
-            for (int i = 0; i < LOADS; ++i) {
-                const int idx = tid + i * NT;
-                const int r = idx / CH, ch = idx % CH;
-                const int qi = qt * BT + r;
-                u32x4 zq = {0u, 0u, 0u, 0u}, zo = {0u, 0u, 0u, 0u};
-                if (qi < Lq && ch * 8 < p.D) {
-                    zq = *(const u32x4*)(p.q + (long)(qs + qi) * p.q_st + (long)hq * p.q_sh + ch * 8);
-                    zo = *(const u32x4*)(p.dout + (long)(qs + qi) * p.do_st + (long)hq * p.do_sh + ch * 8);
-                }
-                *(u32x4*)(Qs + r * STRIDE + ch * 16) = zq;
-                *(u32x4*)(Os + r * STRIDE + ch * 16) = zo;
-            }
-            if (tid < BT) {
-                const int qi = qt * BT + tid;
-                Ls[tid] = (qi < Lq) ? p.lse[(long)hq * p.total_q + qs + qi] * 1.4426950408889634f : 0.f;
-                Ls[BT + tid] = (qi < Lq) ? p.delta[(long)hq * p.total_q + qs + qi] : 0.f;
-            }
+            store_tile();
             __syncthreads();
+            if (qt + 1 < ntq) load_tile(hq, qt + 1);
+            else if (hh + 1 < hh1) load_tile(hq + 1, t0);
             const int q0 = qt * BT;
             // S[q][key], dP[q][key]: "A" = Q / dO rows from LDS, "B" = K / V registers; lane = key, regs = 4 queries (4g + r) per 16-q tile j
             f32x4 s[4], dp[4];

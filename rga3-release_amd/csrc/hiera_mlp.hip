@@ -369,7 +369,10 @@ __global__ __launch_bounds__(hm288::NT) void hiera_mlp288_kernel(Hm288Args p) {
     auto half = [&](f32x16& accN, const f32x16& accC, const char* w1n, const char* w2c, int n) {
         bf16x8 a1[KS];
         f32x4 cc[4], dd[4];
-        constexpr int PRE = 6;     // W1' fragments read ahead of their MFMA: all 18 up front is 104 KiB per CU = 400 cycles of the LDS array with nothing to overlap
+#ifndef HM288_PRE
+#define HM288_PRE 6
+#endif
+        constexpr int PRE = HM288_PRE;     // W1' fragments read ahead of their MFMA: all 18 up front is 104 KiB per CU = 400 cycles of the LDS array with nothing to overlap
         const char* const a0 = w1n + r * W1STR + h * 16;
         {
 #pragma unroll
