@@ -473,10 +473,14 @@ template <int DP>
 static int launch_bwd(const AttnBwdArgs& a0, int nseg, int max_q, int max_k, hipStream_t st) {
     AttnBwdArgs a = a0;
     a.gx = 1; a.gy = 1;
-    constexpr int QT = (DP >= 128) ? 1 : 2;
     // 8 waves per workgroup at D = 128 (the decoder): a K/V (resp. Q/dO) tile staged once serves twice the rows
     constexpr int NW = (DP == 128) ? 8 : 4;
-    constexpr int BLOCK_M = NW * QT * 16;
+#ifdef RGA3_BWD_DQ_QT2   // measurement variant: the dQ kernel on 4 waves x 32 query rows (every K / V fragment read serves two 16-row tiles: half the LDS bytes per flop)
+    constexpr int QT = 2, NWQ = 4;
+#else
+    constexpr int QT = (DP >= 128) ? 1 : 2, NWQ = NW;
+#endif
+    constexpr int BLOCK_M = NWQ * QT * 16;
     constexpr int LDS_DQ = 2 * BT * (DP * 2 + 32);
     constexpr int LDS_DKV = 2 * BT * (DP * 2 + 32) + 2 * BT * 4;
     auto prep = [](const void* k, int lds) -> int {   // once per kernel instantiation
@@ -496,15 +500,15 @@ static int launch_bwd(const AttnBwdArgs& a0, int nseg, int max_q, int max_k, hip
     const unsigned nqb = (unsigned)cdiv(max_q, BLOCK_M), nkb = (unsigned)cdiv(max_k, 16 * NW);
     const bool pair = a.causal && nqb >= 4 && nkb >= 4;   // balanced causal rows (see the kernels)
     if (pair) {
-        auto kq = attn_bwd_dq_kernel<DP, QT, NW, true>;
+        auto kq = attn_bwd_dq_kernel<DP, QT, NWQ, true>;
         if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
         a.gx = (int)((nqb + 1) / 2); a.gy = a.Hq;
-        hipLaunchKernelGGL(kq, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
+        hipLaunchKernelGGL(kq, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NWQ), LDS_DQ, st, a);
     } else {
-        auto kq = attn_bwd_dq_kernel<DP, QT, NW, false>;
+        auto kq = attn_bwd_dq_kernel<DP, QT, NWQ, false>;
         if (int rc = prep((const void*)kq, LDS_DQ)) return rc;
         a.gx = (int)nqb; a.gy = a.Hq;
-        hipLaunchKernelGGL(kq, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NW), LDS_DQ, st, a);
+        hipLaunchKernelGGL(kq, dim3((unsigned)a.gx * (unsigned)a.gy * (unsigned)nseg), dim3(64 * NWQ), LDS_DQ, st, a);
     }
     RGA3_CHECK_LAUNCH("attn_bwd_dq_kernel");
     const unsigned gx = pair ? (nkb + 1) / 2 : nkb;

@@ -253,6 +253,51 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const unsigned shor
     }
 }
 
+// Row statistics only (rga3_layernorm_stats), for the widths the one-row-per-wave kernel serves badly: at 576 channels (Hiera-L stage 3: 72 sixteen-byte chunks) a
+// wave issued ONE full load and one eighth-full load per row and then ran two 6-step wave reductions -- 37.7 MB per 8 frames in 23.8 us = 1.6 TB/s, latency bound,
+// ~160 launches per training step (profiles/r04_train_step_timeline.txt).  Here LPR lanes share a row and every lane has its NCHL chunks in flight before the first
+// use: 8 lanes x 9 chunks (576 channels, 8 rows per wave), 16 x 9 (1152 channels, 4 rows per wave); the reductions are 3 / 4 shuffle steps.  Same two-pass
+// arithmetic (mean, then centred squares) on the register-resident row.
+template <int LPR, int NCHL>
+__global__ __launch_bounds__(256) void layernorm_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ stats, long rows, int dim, long ldx, float eps) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const long rowc = row < rows ? row : rows - 1;
+    const int nch = dim / 8;
+    u32x4 buf[NCHL];
+#pragma unroll
+    for (int i = 0; i < NCHL; ++i) {
+        const int ch = sub + i * LPR;
+        buf[i] = (ch < nch) ? *(const u32x4*)(x + rowc * ldx + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCHL; ++i) {
+        float f[8];
+        unpack8(buf[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += f[e];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    const float mean = s1 / (float)dim;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCHL; ++i) {
+        if (sub + i * LPR < nch) {
+            float f[8];
+            unpack8(buf[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; s2 += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    if (row < rows && sub == 0) *(float2*)(stats + 2 * row) = make_float2(mean, rsqrtf(s2 / (float)dim + eps));
+}
+
 // Narrow rows (dim < 8 or not a multiple of 8, <= 16): one thread per row, scalar bf16 loads.  The 4-channel LayerNorm2d + GELU of the
 // memory encoder's first mask-downsampler stage (reference model/sam2.py:611-643) runs 4 x 512 x 512 rows per frame through this.
 __global__ __launch_bounds__(256) void layernorm_tiny_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
@@ -535,6 +580,8 @@ extern "C" int rga3_layernorm_stats(const void* x, float* stats, int64_t rows, i
     dim3 grid((unsigned)cdiv(rows, 4));
     if (dim <= 16 * 8 * 2) hipLaunchKernelGGL(layernorm_rows_kernel<16>, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
     else if (dim <= 32 * 8 * 2) hipLaunchKernelGGL(layernorm_rows_kernel<32>, dim3((unsigned)cdiv(rows, 8)), dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
+    else if (dim <= 8 * 9 * 8) hipLaunchKernelGGL((layernorm_stats_kernel<8, 9>), dim3((unsigned)cdiv(rows, 32)), dim3(256), 0, st, xp, stats, (long)rows, (int)dim, (long)ldx, eps);
+    else if (dim <= 16 * 9 * 8) hipLaunchKernelGGL((layernorm_stats_kernel<16, 9>), dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, xp, stats, (long)rows, (int)dim, (long)ldx, eps);
     else if (dim <= 64 * 8 * 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
     else if (dim <= 64 * 8 * 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
     else hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, st, xp, nul, nul, (unsigned short*)nullptr, (long)rows, (int)dim, (long)ldx, 0L, eps, 0, stats);
