@@ -130,6 +130,11 @@ class BatchFeed:
         big = self.pool[self.j % len(self.pool)] if self.mode == "fresh" else self.first
         return {k: big[k] for k in ("pixel_values_videos", "video_grid_thw") if k in big}
 
+    def peek_sam(self):
+        """`images_sam` of the sample the NEXT call of next() will return (for model.prefetch_sam)."""
+        big = self.pool[self.j % len(self.pool)] if self.mode == "fresh" else self.first
+        return big.get("images_sam")
+
     def next(self):
         j, self.j = self.j, self.j + 1
         if self.mode != "fresh":
@@ -806,6 +811,8 @@ def main():
     ap.add_argument("--refine", action="store_true", help="training modes, 1 GPU: run the in-situ tile refinement before the warmup")
     ap.add_argument("--dense-embed-grad", action="store_true", help="exchange embed_tokens' gradient as a dense bucket (A/B of the sparse row exchange)")
     ap.add_argument("--sam-frames", type=int, default=16)
+    ap.add_argument("--sam-prefetch-layer", type=int, default=7, help="training modes: the next sample's SAM2 encoder is launched when the backward reaches this decoder layer")
+    ap.add_argument("--no-sam-prefetch", action="store_true", help="training modes: do not run the frozen SAM2 image encoder of the next sample beside the optimizer step (A/B)")
     ap.add_argument("--no-prefetch", action="store_true", help="training modes: do not run the frozen vision tower of the next sample one step ahead on a side stream (A/B)")
     ap.add_argument("--batches", choices=["fresh", "repeat"], default="fresh",
                     help="training modes: fresh = a new sample (new tensor objects, new token ids, [SEG] position, pixel tensors from a resident pool of 4) every step, as a "
@@ -907,6 +914,11 @@ def main():
     losses = []
     feed = BatchFeed(args.batches, cfg, dev, rank, inputs, "full" if full else "llm", sam_frames=args.sam_frames)
     prefetch = not args.no_prefetch and args.batches == "fresh"
+    sam_prefetch = not args.no_sam_prefetch
+    sam_pf_param = None
+    if full:
+        lay = model.model.layers[min(args.sam_prefetch_layer, len(model.model.layers) - 1)].self_attn.q_proj
+        sam_pf_param = next((p_ for p_ in lay.parameters() if p_.requires_grad), None)      # its LoRA factor: the gradient arrives when that layer's backward is done
     model.reuse_host_plan(args.batches == "repeat")
 
     def step(sync=True):
@@ -921,6 +933,10 @@ def main():
             loss = out["loss"] if isinstance(out, dict) else out.loss
             if pf and not full:  # no mask path in this mode: behind the forward, beside the backward / optimizer
                 model.prefetch_vision(**feed.peek_pixels())
+            if pf and sam_prefetch and full and mi + 1 == accum:
+                # the next sample's FROZEN SAM2 encoder goes out on a side stream when the backward has `sam_pf_layer` decoder layers left: its bandwidth-bound first
+                # stages run beside the last dX products, its matrix-bound stage 3 beside the HBM-bound optimizer, the rest beside the next forward's products
+                model.prefetch_sam(feed.peek_sam(), after=sam_pf_param)
             if mi + 1 < accum or not sync:
                 with reducer.no_sync():
                     (loss / accum).backward()
@@ -1038,8 +1054,12 @@ def main():
         variants = {"steps_each": nv}
         if prefetch:      # the same fresh-batch step with the next sample's frozen ViT computed inside its own forward instead of one step ahead on a side stream
             prefetch = False
-            variants["fresh_batch_no_vision_prefetch_ms"] = timed()
+            variants["fresh_batch_no_vision_prefetch_ms"] = timed()      # (neither tower ahead of time)
             prefetch = True
+            if sam_prefetch and full:   # ... and with only the SAM2 image encoder computed in line (the ViT still one step ahead)
+                sam_prefetch = False
+                variants["fresh_batch_no_sam_prefetch_ms"] = timed()
+                sam_prefetch = True
         if args.batches == "fresh":
             feed.mode = "repeat"
             model.reuse_host_plan(True)
@@ -1059,8 +1079,8 @@ def main():
                     accum, "bf16" if args.no_fp8 else "fp8 e4m3"), "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16" if args.no_fp8 else "fp8(e4m3)+bf16", "data": "synthetic",
-                "config": {"workload": "BASELINE.json configs[4] per GPU: Qwen2.5-VL-7B, 32 frames 448x448 (grid [16,32,32], S = 4160), ViT fwd bf16 (frozen), decoder "
-                                       "fwd (activations kept in HBM) + bwd with the frozen qkv / o / gate-up / down contractions in e4m3 (per-token / per-row scales), "
+                "config": {"workload": "BASELINE.json configs[4] per GPU: Qwen2.5-VL-7B, 32 frames 448x448 (grid [16,32,32], S = 4160), ViT fwd (frozen) and decoder "
+                                       "fwd (activations kept in HBM) + bwd with the frozen qkv / o / proj / gate-up / down contractions in e4m3 (per-token / per-row scales), "
                                        "LoRA r128 (dropout 0.05) + lm_head + embed_tokens + norms + attention in bf16, %d micro-steps per optimizer step, "
                                        "one bucketed RCCL all-reduce per optimizer step, AdamW" % accum,
                            "per_gpu_batch": 1, "grad_accum": accum, "seq_len": 4160, "parallelism": f"dp{world}", "trainable_params": n_train,
@@ -1087,9 +1107,11 @@ def main():
                                        "Qwen2.5-VL-7B ViT fwd (frozen) + decoder fwd+bwd (layer activations kept in HBM, no recompute), LoRA r128 (alpha 256, dropout 0.05) q/v + lm_head + embed_tokens "
                                        "trainable, AdamW step (weight decay 0 as in the reference; embed_tokens rows that never received a gradient -- g = m = v = 0, exactly unchanged by "
                                        "AdamW -- are not streamed), bucketed RCCL all-reduce (embed_tokens rows exchanged sparsely); 16 frames 448x448, S=2112, 1 sample/GPU" +
-                                       (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)" if full else ""),
+                                       (f"; SAM2-L on {args.sam_frames} frames 1024x1024 (frozen encoder, trainable mask decoder + text_hidden_fcs, BCE+dice)" if full else "") +
+                                       ("; the FROZEN towers of the NEXT sample (ViT, SAM2 image encoder) are launched one step ahead on side streams -- every step runs exactly one pass of "
+                                        "each, same kernels, same values (config.variants times the step without them)" if prefetch else ""),
                            "per_gpu_batch": 1, "seq_len": 2112, "parallelism": f"dp{world}", "trainable_params": n_train, "flops_per_sample": fl,
-                           "batches": args.batches, "vision_prefetch": bool(prefetch), "adamw_embed_rows_updated": rows_updated, "variants": variants},
+                           "batches": args.batches, "vision_prefetch": bool(prefetch), "sam_encoder_prefetch": bool(prefetch and sam_prefetch and full), "adamw_embed_rows_updated": rows_updated, "variants": variants},
                 "roofline": fwd_roof if fwd_roof is not None else rfb, "roofline_fwd_bwd": rfb,
                 "verify": dict(fwd_verify or {}, loss_first_last=[round(float(lv[0]), 5), round(float(lv[-1]), 5)]),
                 "comm": comm, "cpu_baseline": cpu}

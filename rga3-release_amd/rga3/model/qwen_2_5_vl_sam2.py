@@ -142,6 +142,61 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
         if nxt is not None:
             self.prefetch_vision(**nxt)
 
+    # -- frozen SAM2 image encoder, one step ahead --------------------------------------------------------------------------
+    def prefetch_sam(self, images_sam, after=None):
+        """(after: a trainable parameter -- the launch is DEFERRED to the moment that parameter's gradient has been accumulated in the running / next backward, once.  The
+        encoder opens with its bandwidth-bound stages (1 M tokens x 144 channels per frame batch): started a few decoder layers before the end of backward they run
+        beside matrix-bound dX products, and the matrix-bound stage 3 then meets the bandwidth-bound optimizer.)
+        Run the FROZEN SAM2 image encoder (Hiera-L trunk + FPN: a third of a training step, all matrix work) on the NEXT batch's `images_sam` now, on a side
+        stream, and keep the result for the forward that receives this same tensor.  Meant to be called right before the optimizer step: AdamW streams 28 bytes per
+        trainable element at the HBM roofline and leaves the matrix pipe idle (5.9 ms per step at 1.15 B elements), the encoder is the opposite -- the two overlap,
+        and the rest of the encoder runs beside the next forward's products.  It reads no parameter the optimizer updates (reference qwen_2_5_vl_sam2.py:121 freezes
+        the grounding encoder; conv_s0 / conv_s1 of the trainable mask decoder are applied in the forward itself), every step still runs exactly one encoder pass per
+        sample, and the features are bit-identical to the ones computed in line (same kernels).  Optional: a forward without a matching prefetch computes them itself."""
+        gm = self.grounding_encoder
+        enc = gm.sam2_model.image_encoder
+        if images_sam is None or not images_sam.is_cuda or images_sam.requires_grad or any(p_.requires_grad for p_ in enc.parameters()):
+            return
+        if after is not None:
+            box = {}
+
+            def fire(_p):
+                box.pop("h").remove()          # one shot
+                self.prefetch_sam(images_sam)
+
+            box["h"] = after.register_post_accumulate_grad_hook(fire)
+            return
+        st = self.__dict__.get("_pf_sam_stream")
+        if st is None:
+            st = self.__dict__["_pf_sam_stream"] = torch.cuda.Stream(device=images_sam.device)
+        cache = self.__dict__.setdefault("_pf_sam_cache", {})
+        cache.clear()
+        cur = torch.cuda.current_stream(images_sam.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        for i in range(images_sam.shape[0]):
+            img = images_sam[i]
+            with torch.cuda.stream(st), torch.no_grad():
+                st.wait_event(ready)
+                images_sam.record_stream(st)
+                lv = gm.sam2_model.encode_frozen(img)
+                done = torch.cuda.Event()
+                done.record(st)
+            cache[img.data_ptr()] = ((images_sam._version, tuple(img.shape), img.dtype), images_sam, lv, done)   # holds images_sam: its address cannot be recycled meanwhile
+
+    def _prefetched_sam(self, images_sam, i):
+        cache = self.__dict__.get("_pf_sam_cache")
+        img = images_sam[i]
+        hit = cache.pop(img.data_ptr(), None) if cache else None
+        if hit is None or hit[0] != (images_sam._version, tuple(img.shape), img.dtype):
+            return None
+        _, _, lv, done = hit
+        cur = torch.cuda.current_stream(images_sam.device)
+        cur.wait_event(done)
+        for t, _, _ in lv:
+            t.record_stream(cur)              # allocated on the side stream, consumed (and later freed) on this one
+        return lv
+
     # ---- helpers ------------------------------------------------------------------------------------------
     def _seg_embeddings(self, hidden_last: torch.Tensor, seg_token_mask_np: np.ndarray, pl=None):
         """text_hidden_fcs on the gathered rows (value-identical to MLP-then-gather, reference :215-218)."""
@@ -217,7 +272,7 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
                 continue  # empty slice: contributes 0 to both losses and to num_masks (reference :289-305)
             e = sample_embedding(i)
             assert e.shape[0] == 1, "one [SEG] per sample on the training path (reference sam2.py:3356 assert)"
-            st = gm.get_sam2_embeddings_train(images_sam[i])
+            st = gm.get_sam2_embeddings_train(images_sam[i], frozen=self._prefetched_sam(images_sam, i))
             self._launch_prefetch()      # next batch's frozen ViT (if the trainer announced it) goes out beside the mask decoder / its backward
             _, high = gm.inject_language_embd_train(st, e[None].expand(num_frames_sam, -1, -1))
             grad = torch.is_grad_enabled()

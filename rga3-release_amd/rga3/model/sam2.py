@@ -917,12 +917,18 @@ class SAM2VideoPredictor(nn.Module):
         return self.no_mem_embed.dtype
 
     # -- image encoder --------------------------------------------------------------------------------------
-    def forward_image(self, img):
-        """reference sam2.py:2790-2802 (+ FPN, scalp). Returns dict of raster token maps."""
+    def encode_frozen(self, img):
+        """The FROZEN part of forward_image: Hiera trunk + FPN neck (reference qwen_2_5_vl_sam2.py:121 freezes the grounding encoder; only sam_mask_decoder trains).
+        It depends on nothing the optimizer updates, so a trainer may run it for the NEXT sample ahead of time (UniGRModel.prefetch_sam)."""
         Fn = img.shape[0]
-        with torch.no_grad():  # trunk + neck are frozen on every RGA3 path (reference qwen_2_5_vl_sam2.py:121)
+        with torch.no_grad():
             stages = self.image_encoder.trunk(img.to(self.dtype))
-            lv = self.image_encoder.neck(stages, Fn)[: len(stages) - self.image_encoder.scalp]
+            return self.image_encoder.neck(stages, Fn)[: len(stages) - self.image_encoder.scalp]
+
+    def forward_image(self, img, frozen=None):
+        """reference sam2.py:2790-2802 (+ FPN, scalp). Returns dict of raster token maps.  frozen: the result of encode_frozen(img) when it was computed ahead of time."""
+        Fn = img.shape[0]
+        lv = frozen if frozen is not None else self.encode_frozen(img)
         (f0, H0, W0), (f1, H1, W1), (f2, H2, W2) = lv
         dec = self.sam_mask_decoder   # conv_s0 / conv_s1 belong to the (trainable) mask decoder: they record autograd when enabled
 
@@ -999,9 +1005,9 @@ class SAM2(nn.Module):
             load_sam2_checkpoint(self.sam2_model, ckpt_path)
 
     # ---- training path: frames independent (reference :412-433, :343-375)
-    def get_sam2_embeddings_train(self, images, expand_size=1):
+    def get_sam2_embeddings_train(self, images, expand_size=1, frozen=None):
         assert expand_size == 1, "num_objs == 1 on the RGA3 path (model/qwen_2_5_vl_sam2.py:263)"
-        return self.sam2_model.forward_image(images)
+        return self.sam2_model.forward_image(images, frozen=frozen)
 
     def inject_language_embd_train(self, sam_states, language_embd, nf_nobj=None):
         m = self.sam2_model

@@ -423,3 +423,38 @@ def test_vision_prefetch_is_bit_identical_and_optional(model, dev, G):
         out3 = model(**b, inference=False)
         for k in ref:
             assert torch.equal(ref[k], out3[k]), k
+
+
+def test_sam_encoder_prefetch_is_bit_identical_and_optional(model, dev, G):
+    """UniGRModel.prefetch_sam (round 5): the FROZEN SAM2 image encoder (Hiera trunk + FPN; reference qwen_2_5_vl_sam2.py:121 freezes the grounding encoder) of a batch
+    computed AHEAD on a side stream -- a trainer calls it for the next sample right before the optimizer step -- gives the same loss dict, bit for bit, as computing it
+    inside the forward; conv_s0 / conv_s1 of the TRAINABLE mask decoder are not part of what is prefetched (a weight update between prefetch and forward is seen);
+    an entry is used once and only for the very tensor it was computed from.  (Both samples carry a [SEG]: a sample without one never reaches the encoder -- its entry
+    would simply be dropped by the next prefetch.)"""
+    b = to_dev(make_batch(CASES["11"], seed=3), dev)
+    dec = model.grounding_encoder.sam2_model.sam_mask_decoder
+    with torch.no_grad():
+        ref = model(**b, inference=False)
+        model.prefetch_sam(b["images_sam"])
+        assert len(model.__dict__["_pf_sam_cache"]) == b["images_sam"].shape[0]
+        out = model(**b, inference=False)
+        assert len(model.__dict__["_pf_sam_cache"]) == 0                      # consumed
+        for k in ref:
+            assert torch.equal(ref[k], out[k]), k
+        # the optimizer steps between prefetch and forward: the trainable 1x1 convolutions on the high-resolution levels must use the NEW weights
+        model.prefetch_sam(b["images_sam"])
+        w0 = dec.conv_s0.weight.detach().clone()
+        dec.conv_s0.weight.mul_(1.5)
+        upd = model(**b, inference=False)
+        now = model(**b, inference=False)                                     # the same forward without a prefetch
+        for k in ref:
+            assert torch.equal(upd[k], now[k]), k
+        assert not torch.equal(upd["mask_bce_loss"], ref["mask_bce_loss"])
+        dec.conv_s0.weight.copy_(w0)
+        # a stale entry (the frames were written after the prefetch) is not used
+        model.prefetch_sam(b["images_sam"])
+        b["images_sam"].mul_(1.0)
+        out3 = model(**b, inference=False)
+        for k in ref:
+            assert torch.equal(ref[k], out3[k]), k
+        model.__dict__["_pf_sam_cache"].clear()
