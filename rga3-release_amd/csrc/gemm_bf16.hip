@@ -892,6 +892,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
 __device__ __forceinline__ void mfma_inplace(f32x4& c, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+// c = a . b (C operand = the inline constant 0): the first k-step of an accumulation defines the accumulator
+__device__ __forceinline__ void mfma_zero(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
 
 // =====================================================================================================================
 // Persistent ping-pong GEMM with a stream-K tail (tile ids 21 / 22).  One workgroup per CU walks a list of work items:
@@ -917,23 +921,34 @@ constexpr int sk_lds_bytes() {
     return LDS_MAIN > LDS_RES ? LDS_MAIN : LDS_RES;
 }
 
+constexpr int kSkMaxP = 320;   // workgroups (= CUs) a run table has room for
 struct SkArgs {
     float* slabs;     // [P][512 lanes][32] f32x4 in register order (256 KiB per workgroup)
     unsigned* flags;  // [P] 1 = slab written
     unsigned* tmo;    // tmo[0]: bounded-spin give-up counter; tmo[1]: fault injection (tests), 0 in real runs
     int P;            // workgroups launched
-    int P_sk;         // workgroups that take part in the stream-K tail
+    int P_sk;         // workgroups that take part in the stream-K tail (host bookkeeping: the kernel reads the run table)
     int t_dp;         // tiles [0, t_dp) are data-parallel (t_dp % P == 0 or sk_tiles == 0)
     int sk_tiles;     // tiles [t_dp, t_dp + sk_tiles) are split
     int all_partial;  // split-K mode (tile 25): every slice only writes its slab; gemm_slab_reduce_kernel sums them afterwards
     int plain_slabs;  // measurement builds only (RGA3_AB, env RGA3_SK_PLAIN=1): the round-3 hand-off -- plain slab stores + agent-scope release fence
+    // ragged = 1 (tiles 26 / 27): the last tile row holds <= 64 rows (M = 2112 = 8 x 256 + 64); its ntn tiles run the quarter-work loop at about half the time of a full
+    // tile, so TWO of them make one unit of the data-parallel rounds ("pair").  Tile numbering then: [0, ntn) the ragged tiles by column, [ntn, T) the full tiles in the
+    // grouped order over ntm - 1 tile rows.  Data-parallel units v = w, w + P, ... < t_dp_v: v < npairs is the pair of ragged tiles 2v, 2v + 1 (the last pair is a single
+    // tile when ntn is odd), v >= npairs the full tile ntn + v - npairs.  t_dp (tile numbering) is where the stream-K tail starts.  ragged = 0: npairs = 0, t_dp_v = t_dp.
+    int ragged, npairs, t_dp_v;
     unsigned long long* dbg = nullptr;   // measurement builds only (RGA3_AB, env RGA3_SK_DBG=1): [P][8 items][8] s_memtime stamps of wave 0 (tools/probes/sk_items.py)
+    // run table of the stream-K tail: workgroup w takes K-iterations [start[w], start[w + 1]) of the line  tile t_dp (nk iterations), tile t_dp + 1, ...
+    // (host-made: equal runs, or runs sized by cost when ragged tiles are cheaper; sk_plan_*).  Empty runs are allowed.
+    unsigned start[kSkMaxP + 1];
 };
 
 // MH = 16-row m-tiles per A half-tile and wave row: 4 -> 256-row tiles, 3 -> 192-row tiles (M = 2112 = 11 x 192: no padded tile row;
 // the A half-tiles then hold 96 rows in their 128-row LDS regions, and waves 4-7 repeat the second staging piece of waves 0-3 so that
 // every wave still issues two loads per half-tile and the counted vmcnt schedule is the same).
-template <int ACT, bool OUT_F32, int MH = 4>
+// RG: the instantiation that also holds the ragged-tile loop (tiles 26 / 27).  It is a separate program: the persistent kernel sits at the register limit, and a second
+// loop in the same program moved the allocation of the first (a staging offset spilled INTO the full loop: a scratch reload + vmcnt(0) per K-tile, half the rate).
+template <int ACT, bool OUT_F32, int MH = 4, bool RG = false>
 __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) {
     constexpr int BM = 64 * MH, BN = 256, BK = 64, ROWB = 128;
     constexpr int HALF = 128 * ROWB;
@@ -960,26 +975,36 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     // K % 64 == 0 here (the launcher sends ragged K to the one-tile-per-workgroup kernel, which has the zero-source tail)
     char* est = PREFETCH ? smem + (wr ? 3 * HALF : HALF) + wc * EPW : smem + wid * EPW;
 
-    // ---- work list
+    // ---- work list.  A run [x0, x1) of the tail line decomposes into: the END of the tile it starts inside (owner slice: this workgroup adds the partial sums of the
+    //      lower-numbered workgroups that computed the tile's earlier K-iterations), whole tiles, and the START of the tile it ends inside (non-owner slice).  A run that
+    //      neither starts nor ends at a tile boundary of its single tile is a non-owner (middle) slice.
     int na_tile = -1, na_kb = 0, na_ke = 0;  // non-owner slice (first)
     int ow_tile = -1, ow_kb = 0;             // owner slice [ow_kb, nk) (last)
-    if (sk.sk_tiles > 0 && w < sk.P_sk) {
-        const long tot = (long)sk.sk_tiles * nk;
-        const long it0 = (long)w * tot / sk.P_sk, it1 = (long)(w + 1) * tot / sk.P_sk;
-        if (it0 < it1) {
-            const int ta = (int)(it0 / nk);
-            const long tend = (long)(ta + 1) * nk;
-            if (it1 >= tend) {
-                ow_tile = sk.t_dp + ta;
-                ow_kb = (int)(it0 - (long)ta * nk);
-                if (it1 > tend) { na_tile = sk.t_dp + ta + 1; na_kb = 0; na_ke = (int)(it1 - tend); }
-            } else {
-                na_tile = sk.t_dp + ta; na_kb = (int)(it0 - (long)ta * nk); na_ke = (int)(it1 - (long)ta * nk);
+    int tw0 = 0, n_tw = 0;                   // whole tiles inside the run (after the data-parallel ones)
+    if (sk.sk_tiles > 0) {
+        const unsigned x0 = sk.start[w], x1 = sk.start[w + 1];
+        if (x0 < x1) {
+            const int ta = (int)(x0 / (unsigned)nk), tz = (int)((x1 - 1) / (unsigned)nk);
+            const unsigned sa = (unsigned)ta * nk, ez = (unsigned)(tz + 1) * nk;
+            int first_whole = ta, end_whole = tz + 1;
+            if (x0 > sa) {   // the run starts inside tile ta
+                first_whole = ta + 1;
+                if (x1 >= sa + nk) { ow_tile = sk.t_dp + ta; ow_kb = (int)(x0 - sa); }
+                else { na_tile = sk.t_dp + ta; na_kb = (int)(x0 - sa); na_ke = (int)(x1 - sa); }
             }
+            if (x1 < ez && (tz > ta || x0 == sa)) {   // the run ends inside tile tz, whose first iteration it holds
+                end_whole = tz;
+                na_tile = sk.t_dp + tz; na_kb = 0; na_ke = (int)(x1 - (unsigned)tz * nk);
+            }
+            tw0 = sk.t_dp + first_whole;
+            n_tw = max(end_whole - first_whole, 0);
         }
     }
-    const int n_dp = (w < sk.t_dp) ? (sk.t_dp - w + sk.P - 1) / sk.P : 0;
-    const int n_items = (na_tile >= 0) + n_dp + (ow_tile >= 0);
+    const int n_dpv = (w < sk.t_dp_v) ? (sk.t_dp_v - w + sk.P - 1) / sk.P : 0;                          // data-parallel units of this workgroup ...
+    const int np_w = (w < sk.npairs) ? (min(sk.npairs, sk.t_dp_v) - w + sk.P - 1) / sk.P : 0;          // ... of which pairs of ragged tiles (they come first)
+    const int n_pi = 2 * np_w - ((np_w > 0 && 2 * (w + (np_w - 1) * sk.P) + 1 >= p.ntn) ? 1 : 0);   // tiles in those pairs (the last pair of an odd ntn is one tile)
+    const int n_dp = n_dpv - np_w + n_pi;
+    const int n_items = (na_tile >= 0) + n_dp + n_tw + (ow_tile >= 0);
     if (n_items == 0) return;
     // item i -> (tile, kb, ke, kind): kind 0 = whole tile, 1 = non-owner slice, 2 = owner slice
     auto item = [&](int i, int& tile, int& kb, int& ke, int& kind) {
@@ -987,23 +1012,44 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             if (i == 0) { tile = na_tile; kb = na_kb; ke = na_ke; kind = 1; return; }
             --i;
         }
-        if (i < n_dp) { tile = w + i * sk.P; kb = 0; ke = nk; kind = 0; return; }
-        tile = ow_tile; kb = ow_kb; ke = nk; kind = sk.all_partial ? 1 : ((ow_kb > 0) ? 2 : 0);
+        if (i < n_dp) {
+            if (i < n_pi) tile = 2 * (w + (i >> 1) * sk.P) + (i & 1);
+            else tile = (sk.ragged ? p.ntn : 0) + (w + (i - n_pi + np_w) * sk.P) - sk.npairs;
+            kb = 0; ke = nk; kind = 0;
+            return;
+        }
+        i -= n_dp;
+        if (i < n_tw) { tile = tw0 + i; kb = 0; ke = nk; kind = 0; return; }
+        tile = ow_tile; kb = ow_kb; ke = nk; kind = sk.all_partial ? 1 : 2;
     };
 
     unsigned soff[4][2];
     unsigned soffA3[3];    // MH == 3: the three 64-row A units of a K-tile (one piece per wave each)
     int nm0 = 0, nn0 = 0;  // tile origin of the item whose offsets are in soff
+    // Ragged tiles (MH = 4, sk.ragged): a tile of the last tile row that holds <= 64 rows (M = 2112 = 8 x 256 + 64: one tile row in nine multiplied 75 % padding).
+    // Its rows are exactly LDS rows 0..63 of half-tile A0 under the normal staging map, so the item stages only the FIRST piece of A0 and no A1, and wave row wr reads LDS
+    // rows wr * 32 + [0, 32) (two m-tiles: 16 MFMAs per K-tile and wave instead of 64); its own three-stage loop is at the item loop.
+    constexpr bool RGOK = RG && (MH == 4);
+    bool rg_n = false;     // ... and whether that tile is ragged
     auto setup_tile = [&](int tile, int lane) {
         const int sch = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
         const unsigned GROUP_M = (unsigned)p.group_m;
-        const unsigned t = (unsigned)tile;
-        const unsigned per_group = GROUP_M * p.ntn;
-        const unsigned group = t / per_group;
-        const unsigned first_m = group * GROUP_M;
-        const unsigned gsz = min((unsigned)p.ntm - first_m, GROUP_M);
-        nm0 = (int)(first_m + (t % per_group) % gsz) * BM;
-        nn0 = (int)((t % per_group) / gsz) * BN;
+        bool ragged_tile = false;
+        if constexpr (RGOK) ragged_tile = sk.ragged && tile < p.ntn;
+        if (ragged_tile) {
+            nm0 = (p.ntm - 1) * BM;
+            nn0 = tile * BN;
+        } else {
+            const unsigned ntm_f = (unsigned)p.ntm - ((RGOK && sk.ragged) ? 1u : 0u);   // tile rows in the grouped order
+            const unsigned t = (unsigned)tile - ((RGOK && sk.ragged) ? (unsigned)p.ntn : 0u);
+            const unsigned per_group = GROUP_M * p.ntn;
+            const unsigned group = t / per_group;
+            const unsigned first_m = group * GROUP_M;
+            const unsigned gsz = min(ntm_f - first_m, GROUP_M);
+            nm0 = (int)(first_m + (t % per_group) % gsz) * BM;
+            nn0 = (int)((t % per_group) / gsz) * BN;
+        }
+        if constexpr (RGOK) rg_n = ragged_tile;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (wid + 8 * i) * 8 + (lane >> 3);
@@ -1044,6 +1090,12 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(dst + i * second), 16, 0, 0);
         }
     };
+    auto stage_a_rg = [&](int kt, int buf) {   // ragged tile: the 64 live rows of A0, one 1-KiB piece per wave
+        const unsigned short* base = p.A + (long)kt * BK;
+        unsigned o = soff[0][0];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(smem + buf * BUF + wid * 1024), 16, 0, 0);
+    };
     using K_A0 = std::integral_constant<int, 0>;
     using K_A1 = std::integral_constant<int, 1>;
     using K_B0 = std::integral_constant<int, 2>;
@@ -1057,6 +1109,18 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
     };
     // the first K-tile of an item always goes to buffer 1, the second to buffer 0, ...
     auto prologue_issue = [&](int kb, int ke) {
+        if constexpr (RGOK) {
+            if (rg_n) {   // the same order without A1 and with one A0 piece: 5 (3) loads per wave
+                stage_a_rg(kb, 1);
+                stage(K_B0{}, kb, 1);
+                stage(K_B1{}, kb, 1);
+                if (ke - kb > 1) {
+                    stage_a_rg(kb + 1, 0);
+                    stage(K_B0{}, kb + 1, 0);
+                }
+                return;
+            }
+        }
         if constexpr (MH == 3) {
             // the steady-state issue order of the three-phase loop: B0 A_0 | B1 A_1 | A_2 of the first K-tile (buffer 1), B0 A_0 of the second (buffer 0) -- the counted
             // waits of the loop assume exactly this sequence; B1 / A_2 of buffer 0 (where the epilogue parks its row statistics) follow inside the loop
@@ -1161,13 +1225,13 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
 
     for (int it = 0; it < n_items; ++it) {
         const int m0 = nm0, n0 = nn0;
+        const bool rg = rg_n;   // this item's tile is ragged (wave-uniform; false unless MH = 4 and sk.ragged)
         // ---- all six (or four) prologue half-tiles have been issued; older stores of the previous epilogue count in
         //      vmcnt too, so simply drain: the loads have been in flight for a whole epilogue
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
 #ifdef RGA3_AB
         if (sk.dbg && tid == 0 && it < 8) sk.dbg[(size_t)w * 64 + it * 8 + 0] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1206,6 +1270,95 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 if (e2) { stage(K_B0{}, kt + 2, buf); stage_a3(0, kt + 2, buf); }
                 if (e2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else if (e1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 mma_phase3(U2{});
+            } while (++q < nkt);
+        } else if (RGOK && rg) {
+            // ---- ragged tile: THREE stages of 40 KiB (A' = the 64 live rows, one piece per wave; B0, B1 = two pieces each) in the two buffers' 128 KiB, K-tile q in stage q % 3:
+            //        stage 0 = buffer 1's A0 (lower half) / B0 / B1,   stage 1 = buffer 0's,   stage 2 = upper half of buffer 1's A0 / buffer 1's A1 / buffer 0's A1.
+            //      The four-phase skeleton of the full loop on a quarter of the MFMAs ran a K-tile in 0.78 of the full loop's time: every load had ONE K-tile to land and the
+            //      loop sat at the memory latency.  Here a K-tile is issued two K-tiles ahead, and a K-tile is ONE cluster of 16 MFMAs between two barriers:
+            //        barrier | read the 12 fragments of q | issue K-tile q + 2 (5 loads) | 16 MFMAs | vmcnt: K-tile q + 1 has landed | barrier
+            //      With the wave rows a barrier apart (as in the full loop): a row's first barrier pairs with the other row's second barrier of the K-tile before, so the
+            //      counted wait in front of the SECOND barrier is what makes q + 1 visible to the other row, and a stage is restaged only after both rows have read it
+            //      (stage (q + 2) % 3 was read during q - 1; the issuing row has passed a barrier that the other row reaches after its reads of q - 1).
+            //      vmcnt: issued after K-tile q + 1: the 5 loads of q + 2 -> vmcnt(5); none left to issue -> vmcnt(0).  The prologue brought K-tile kb complete and A', B0 of
+            //      kb + 1 (B1 of stage 1 and all of stage 2 overlap the previous item's epilogue staging): q = 0 issues B1(kb + 1) first.
+            auto rg_off = [&](int st, int which) {   // byte offset of stage st's A' (0) / B0 (1) / B1 (2) region
+                return which == 0 ? (st == 0 ? BUF : st == 1 ? 0 : BUF + 8192)
+                     : which == 1 ? (st == 0 ? BUF + 2 * HALF : st == 1 ? 2 * HALF : BUF + HALF)
+                                  : (st == 0 ? BUF + 3 * HALF : st == 1 ? 3 * HALF : HALF);
+            };
+            auto stage_rg_b = [&](int h, int kt, int off) {
+                const unsigned short* base = p.W + (long)kt * BK;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    unsigned o = soff[2 + h][i];
+                    asm volatile("" : "+v"(o));
+                    __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(smem + off + wid * 1024 + i * 8192), 16, 0, 0);
+                }
+            };
+            auto stage_rg_a = [&](int kt, int off) {
+                const unsigned short* base = p.A + (long)kt * BK;
+                unsigned o = soff[0][0];
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(smem + off + wid * 1024), 16, 0, 0);
+            };
+            int st = 0;
+            do {
+                const int kt = kb + q;
+                const int oa = rg_off(st, 0) + wr * (32 * ROWB), ob0 = rg_off(st, 1) + (wc * 32) * ROWB, ob1 = rg_off(st, 2) + (wc * 32) * ROWB;
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *(const bf16x8*)(smem + oa + mi * 2048 + foff[kk]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        b0[ni][kk] = *(const bf16x8*)(smem + ob0 + ni * 2048 + foff[kk]);
+                        b1[ni][kk] = *(const bf16x8*)(smem + ob1 + ni * 2048 + foff[kk]);
+                    }
+                if (q == 0 && nkt > 1) stage_rg_b(1, kt + 1, rg_off(1, 2));
+                const bool e2 = q + 2 < nkt;
+                if (e2) {
+                    const int s2 = st == 0 ? 2 : st - 1;   // (st + 2) % 3
+                    stage_rg_a(kt + 2, rg_off(s2, 0));
+                    stage_rg_b(0, kt + 2, rg_off(s2, 1));
+                    stage_rg_b(1, kt + 2, rg_off(s2, 2));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_setprio(1);
+                // The first k-step of an item takes the constant 0 as its C operand: the accumulators are DEFINED by those MFMAs.  With "acc = 0; acc += ..." the compiler
+                // peeled the first K-tile and materialised each zero right before its first MFMA -- in a register that an MFMA issued just before still read as an operand
+                // (no hazard is visible behind an asm MFMA): wrong sums in the ragged rows.
+                if (q == 0) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) mfma_zero(acc[mi][ni], b0[ni][0], af[mi][0]);
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) mfma_zero(acc[mi][2 + ni], b1[ni][0], af[mi][0]);
+                    }
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) mfma_inplace(acc[mi][ni], b0[ni][0], af[mi][0]);
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) mfma_inplace(acc[mi][2 + ni], b1[ni][0], af[mi][0]);
+                    }
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) mfma_inplace(acc[mi][ni], b0[ni][1], af[mi][1]);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) mfma_inplace(acc[mi][2 + ni], b1[ni][1], af[mi][1]);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (e2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                st = st == 2 ? 0 : st + 1;
             } while (++q < nkt);
         } else
         do {  // nkt >= 1 always; the do-while form keeps one accumulator live range (no zero-trip merge after the loop)
@@ -1260,7 +1413,16 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             // its own stores, the workgroup meets, one lane raises the flag -- no agent-scope release fence.  The plain-store form paid a buffer_wbl2 (write back
             // the XCD L2's dirty lines) behind 256 KiB of freshly dirtied slab per workgroup: 8.2 vs 3.0 us per publish in the guide's measurement.  The owner
             // still acquires (agent scope) before its plain loads.  In split-K mode (tile 25) the kernel boundary is the hand-off: plain stores there.
-            if (sk.all_partial || sk.plain_slabs) {
+            if (RGOK && rg) {   // ragged tile: the eight live quads (m-tiles 0, 1), at the positions the owner's two-m-tile epilogue reads
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(slab), "v"(acc[i][j]) : "memory");
+                        slab += 64;
+                        asm volatile("" : "+v"(slab));
+                    }
+            } else if (sk.all_partial || sk.plain_slabs) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1296,7 +1458,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             const char* resl = nullptr;
             char* est_i = est;
             if constexpr (pp_res_lds<ACT, OUT_F32>()) {
-                if (!has_next && residual_stageable<64, OUT_F32>(p, n0 + wc * 64, p.N)) {
+                if (!has_next && !(RGOK && rg) && residual_stageable<64, OUT_F32>(p, n0 + wc * 64, p.N)) {
                     char* dst = smem + 8 * 1024 + wid * res_stage_bytes<MT, 64>();
                     stage_residual<MT, 64>(p, dst, m0 + wr * 32 * MH, n0 + wc * 64, lane_e);
                     resl = dst;
@@ -1305,12 +1467,20 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             }
             const f32x4 *part1 = nullptr, *part2 = nullptr;
             float poison = 0.f;
+            int fl1 = -1, fl2 = -1;   // contributors whose flags the owner re-arms
             if (cur_kind == 2) {
                 // ---- owner slice: add the partial sums of the (at most two: P_sk <= 2 * sk_tiles) lower-numbered
                 //      workgroups that computed this tile's earlier K-iterations
-                const long tot = (long)sk.sk_tiles * nk;
-                const long x0 = (long)(ow_tile - sk.t_dp) * nk;  // first iteration of this tile in stream-K numbering
-                const bool two = w >= 2 && ((long)(w - 1) * tot / sk.P_sk) > x0;
+                const unsigned sa = (unsigned)(ow_tile - sk.t_dp) * (unsigned)nk;   // first iteration of this tile on the tail line
+                // contributors = the nearest lower-numbered workgroups with a run (the host's plan leaves at most two slices before the owner's)
+                int c1 = w - 1;
+                while (c1 > 0 && sk.start[c1] == sk.start[c1 + 1]) --c1;
+                int c2 = -1;
+                if (sk.start[c1] > sa) {
+                    c2 = c1 - 1;
+                    while (c2 > 0 && sk.start[c2] == sk.start[c2 + 1]) --c2;
+                }
+                const bool two = c2 >= 0;
                 volatile unsigned* gave_up = (volatile unsigned*)(smem + sk_lds_bytes<ACT, OUT_F32, MH>());   // 16 bytes behind everything else in LDS
                 if (tid == 0) {
                     // sk.tmo[1]: fault injection for tests (0 in every real run: the caller zeroes the flag page): 0xffffffff = behave as if a contributor never
@@ -1320,7 +1490,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                     unsigned gave = 0;
                     for (int c = 0; c < (two ? 2 : 1); ++c) {
                         unsigned spins = 0;
-                        while (inject == 0xffffffffu || __hip_atomic_load(sk.flags + (w - 1 - c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+                        while (inject == 0xffffffffu || __hip_atomic_load(sk.flags + (c ? c2 : c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
                             __builtin_amdgcn_s_sleep(8);
                             if (inject == 0xffffffffu || ++spins > limit) {
                                 __hip_atomic_fetch_add(sk.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1336,17 +1506,22 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
                 __syncthreads();
                 // a give-up used to fall through and sum whatever was in the slab: a finite, wrong tile.  Now the tile is poisoned (+inf into every sum)
                 poison = __builtin_amdgcn_readfirstlane((int)*gave_up) ? __builtin_inff() : 0.f;   // wave-uniform: lives in a scalar register
-                part1 = (const f32x4*)sk.slabs + (size_t)(w - 1) * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
-                if (two) part2 = part1 - 512 * 32;
+                part1 = (const f32x4*)sk.slabs + (size_t)c1 * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
+                if (two) part2 = (const f32x4*)sk.slabs + (size_t)c2 * (512 * 32) + (size_t)wid * (32 * 64) + lane_e;
+                fl1 = c1; fl2 = c2;
             }
-            if (cur_kind == 2) gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, true>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2, resl, poison);
+            if (RGOK && rg) {   // two m-tiles per wave: rows m0 + wr * 32 + [0, 32)
+                f32x4 (&acc2)[2][NTL] = *reinterpret_cast<f32x4 (*)[2][NTL]>(&acc[0][0]);
+                if (cur_kind == 2) gemm_epilogue<2, NTL, 32, 64, ACT, OUT_F32, false, true>(acc2, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2, nullptr, poison);
+                else gemm_epilogue<2, NTL, 32, 64, ACT, OUT_F32, false, false>(acc2, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, nullptr, nullptr, nullptr);
+            } else if (cur_kind == 2) gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, true>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, part1, part2, resl, poison);
             else gemm_epilogue<MT, NTL, 32 * MH, 64, ACT, OUT_F32, false, false>(acc, p, est_i, smem + 2 * BUF, lane_e, m0, n0, wr, wc, nullptr, nullptr, resl);
             if (cur_kind == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();  // every wave has consumed its slab values ...
                 if (tid == 0) {   // ... re-arm the flags for the next launch
-                    __hip_atomic_store(sk.flags + (w - 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (part2) __hip_atomic_store(sk.flags + (w - 2), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sk.flags + fl1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (fl2 >= 0) __hip_atomic_store(sk.flags + fl2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -1461,8 +1636,73 @@ static inline int sk_plain_slabs() {
 template <int ACT, bool OUT_F32, bool LNF = false, bool N192 = false>
 static int launch_pp(const GemmArgs& a0, hipStream_t st);
 
+// ---- run tables of the stream-K tail (SkArgs::start)
+// equal runs over the first P_sk workgroups (rounds 2 - 4: the kernel computed w * tot / P_sk itself)
+static void sk_plan_uniform(SkArgs& sk, int nk) {
+    const long tot = (long)sk.sk_tiles * nk;
+    for (int w = 0; w <= kSkMaxP; ++w) sk.start[w] = (unsigned)((sk.P_sk > 0 && w < sk.P_sk) ? (long)w * tot / sk.P_sk : tot);
+}
+
+// Plan for a product whose last tile row is ragged (<= 64 rows: its ntn tiles run the quarter-work loop at about half a full tile's time; tools/probes/ragged_probe.py).
+// Two ragged tiles make one unit ("pair"): T_v = (ntm - 1) ntn + ceil(ntn / 2) units of about equal time.  Whole rounds of P units are data-parallel; the remaining
+// units go to the stream-K tail as EQUAL runs in unit time (run >= half a unit, so a full tile is cut into at most three slices and a ragged tile into at most two: the
+// owner adds at most two slabs) -- the tail's slices start at the half-unit marks, as tile 22's do: runs sized by a finer cost model (water-filling the workgroups to one
+// level) put every slice at its own K offset, the workgroups of an XCD stopped sharing operand tiles in L2, and the tail ran 1.75 x slower per iteration (measured:
+// gate | up 520 us against 491 for tile 22).  The pairs have the lowest unit numbers, so they are data-parallel whenever a whole round exists, and the tail then holds
+// full tiles only; a product with less than one round of units is all tail, ragged tiles first (a run of half a unit there is one whole ragged tile).
+// Returns false when neither form applies (0 < t_dp_v < npairs: never for the model's shapes).
+static bool sk_plan_ragged(SkArgs& sk, const GemmArgs& a, int nk, int P, bool split) {
+    constexpr int MIN_SEG = 8;
+    const int ntn = a.ntn, T = a.ntm * a.ntn;
+    const int npairs = (ntn + 1) / 2;
+    const int T_v = (a.ntm - 1) * ntn + npairs;
+    const int rem_v = T_v % P;
+    sk.ragged = 1;
+    sk.npairs = npairs;
+    sk.all_partial = 0;
+    if (!split || rem_v == 0) {   // data-parallel only (the last round may be partly filled)
+        sk.P = T_v < P ? T_v : P;
+        sk.t_dp_v = T_v;
+        sk.t_dp = T;
+        sk.sk_tiles = 0;
+        sk.P_sk = 0;
+        sk_plan_uniform(sk, nk);
+        return true;
+    }
+    sk.P = P;
+    sk.t_dp_v = T_v - rem_v;
+    if (sk.t_dp_v == 0) {
+        // everything is tail: line = ntn ragged tiles (half time per iteration), then the full tiles.  Equal runs in unit time, 2 * nk half-time ticks per unit.
+        sk.t_dp = 0;
+        sk.sk_tiles = T;
+        long want = 2L * T_v, cap = (long)T_v * nk / MIN_SEG;
+        if (want > cap) want = cap;
+        if (want > P) want = P;
+        if (want < T_v) want = T_v;   // T_v < P here
+        sk.P_sk = (int)want;
+        const long ticks = (long)ntn * nk + 2L * (T - ntn) * nk;   // ragged iteration = 1 tick, full iteration = 2
+        const long rag_ticks = (long)ntn * nk;
+        for (int w = 0; w <= kSkMaxP; ++w) {
+            long tk = (w < sk.P_sk) ? (long)w * ticks / sk.P_sk : ticks;
+            sk.start[w] = (unsigned)(tk <= rag_ticks ? tk : rag_ticks + (tk - rag_ticks) / 2);
+        }
+        return true;
+    }
+    if (sk.t_dp_v < npairs) return false;
+    // pairs are data-parallel; the tail is rem_v full tiles: tile 22's equal runs
+    sk.t_dp = ntn + (sk.t_dp_v - npairs);
+    sk.sk_tiles = rem_v;
+    long cap = (long)rem_v * nk / MIN_SEG, want = 2L * rem_v;
+    if (want > cap) want = cap;
+    if (want > P) want = P;
+    if (want < rem_v) want = rem_v;
+    sk.P_sk = (int)want;
+    sk_plan_uniform(sk, nk);
+    return true;
+}
+
 template <int ACT, bool OUT_F32, int MH = 4>
-static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
+static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st, bool ragged = false) {
     void* ws_ptr = a0.ws; const int64_t ws_bytes = a0.ws_bytes;
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, 64 * MH);
@@ -1473,7 +1713,7 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
     ws.P = cu_count();
     ws.slabs = nullptr;
     ws.flags = nullptr;
-    if (ws.P <= 0) return launch_pp<ACT, OUT_F32>(a0, st);
+    if (ws.P <= 0 || ws.P > kSkMaxP) return launch_pp<ACT, OUT_F32>(a0, st);
     if (split && sk_workspace(ws_ptr, ws_bytes, ws)) split = false;   // no (or too small a) caller workspace: persistent without the stream-K tail
     const int T = a.ntm * a.ntn;
     const int nk = (int)cdiv(a.K, 64);
@@ -1482,13 +1722,27 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
     sk.flags = ws.flags;
     sk.tmo = ws.flags ? ws.flags + ws.P : nullptr;
     const int rem = T % ws.P;
-    if (!split || rem == 0) {
+    sk.ragged = 0;
+    sk.npairs = 0;
+    // ragged last tile row (MH = 4, more than one tile row): pairs of ragged tiles as data-parallel units
+    const int last_rows = a.M - (a.ntm - 1) * 256;
+    bool planned = false;
+    if (MH == 4 && ragged && a.ntm >= 2 && last_rows <= 64) {
+        a.group_m = pick_group_m(a.ntm - 1, 256);   // the grouped order covers the full tile rows only
+        sk.plain_slabs = sk_plain_slabs();
+        planned = sk_plan_ragged(sk, a, nk, ws.P, split);
+        if (!planned) { sk.ragged = 0; sk.npairs = 0; a.group_m = pick_group_m(a.ntm, 256); }
+    }
+    if (planned) {
+    } else if (!split || rem == 0) {
         sk.P = T < ws.P ? T : ws.P;
         sk.t_dp = T;
         sk.sk_tiles = 0;
         sk.P_sk = 0;
         sk.all_partial = 0;
         sk.plain_slabs = sk_plain_slabs();
+        sk.t_dp_v = sk.t_dp;
+        sk_plan_uniform(sk, nk);
     } else {
         // slices per split tile <= 3 (owner + two contributors: the kernel's accumulator init reads at most two slabs)
         // <=> run length >= nk / 2 <=> P_sk <= 2 * sk_tiles; and no slice shorter than MIN_SEG K-iterations
@@ -1504,6 +1758,8 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
         sk.P_sk = (int)want;
         sk.all_partial = 0;
         sk.plain_slabs = sk_plain_slabs();
+        sk.t_dp_v = sk.t_dp;
+        sk_plan_uniform(sk, nk);
     }
 #ifdef RGA3_AB
     {   // stamps go to the start of the slab area: tile 21 / 31 only (no stream-K tail writes slabs there)
@@ -1514,6 +1770,16 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st) {
 #endif
     constexpr int LDS = sk_lds_bytes<ACT, OUT_F32, MH>() + 16;
     static_assert(LDS <= 160 * 1024, "persistent kernel: LDS");
+    if constexpr (MH == 4) {
+        if (sk.ragged) {
+            auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, 4, true>;
+            static LdsGrant lds_grant_rg;
+            if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant_rg, "gemm")) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)sk.P), dim3(512), LDS, st, a, sk);
+            RGA3_CHECK_LAUNCH("gemm_nt_sk_kernel<ragged>");
+            return 0;
+        }
+    }
     auto kern = gemm_nt_sk_kernel<ACT, OUT_F32, MH>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
@@ -1539,7 +1805,9 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     if (S < 2) return launch_sk<ACT, OUT_F32>(a0, false, st);
     SkArgs sk;
     sk.slabs = ws.slabs; sk.flags = ws.flags; sk.tmo = ws.flags + ws.P;
-    sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1; sk.plain_slabs = 0;
+    sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1; sk.plain_slabs = 0; sk.ragged = 0; sk.npairs = 0; sk.t_dp_v = 0;
+    if (sk.P > kSkMaxP) return launch_sk<ACT, OUT_F32>(a0, false, st);
+    sk_plan_uniform(sk, nk);
     constexpr int LDS = 2 * 4 * 128 * 128;
     auto kern = gemm_nt_sk_kernel<ACT_NONE, false>;
     static LdsGrant lds_grant;
@@ -2162,6 +2430,8 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
             else return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
         case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
+        case 26: return launch_sk<ACT, OUT_F32>(a, true, st, true);    // 22 / 21 whose ragged last tile row (<= 64 rows: M = 2112 = 8 x 256 + 64) runs the quarter-work loop,
+        case 27: return launch_sk<ACT, OUT_F32>(a, false, st, true);   //   two such tiles counted as one unit of work
         case 31: return launch_sk<ACT, OUT_F32, 3>(a, false, st);   // 192 x 256 tiles, persistent
         case 32: return launch_sk<ACT, OUT_F32, 3>(a, true, st);    // ... + stream-K tail
         case 25: return launch_splitk<ACT, OUT_F32>(a, st);
@@ -2215,6 +2485,26 @@ extern "C" int rga3_gemm_stream_k_timeouts(const void* workspace) {
     unsigned v = 0;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, ws.flags + ws.P, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}
+
+// Host only (no device needed): the work plan tiles 26 (split = 1) / 27 (split = 0) launch for an [M, N, K] product on `cus` compute units.  plan[8] = {first tile of the
+// stream-K tail, tiles of the tail, 1, pairs of ragged tiles, data-parallel units, workgroups launched, workgroups with a run, tile rows per group}; start[0 .. cus]:
+// workgroup w takes K-iterations [start[w], start[w + 1]) of the tail line.  Returns 0; 1 when the product has no ragged last tile row or no plan applies (the tiles
+// then run as 22 / 21); < 0 on bad arguments.  Lets CPU tests check what the kernel's owner / contributor hand-off relies on.
+extern "C" int rga3_gemm_ragged_plan(int64_t M, int64_t N, int64_t K, int cus, int split, int* plan, unsigned* start) {
+    RGA3_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0 && cus > 0 && cus <= kSkMaxP && plan && start, "gemm_ragged_plan: M, N > 0, K a multiple of 64, 0 < cus <= %d", kSkMaxP);
+    GemmArgs a{};
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.ntm = (int)cdiv(M, 256);
+    a.ntn = (int)cdiv(N, 256);
+    for (int i = 0; i < 8; ++i) plan[i] = 0;
+    if (a.ntm < 2 || M - (int64_t)(a.ntm - 1) * 256 > 64) return 1;
+    a.group_m = pick_group_m(a.ntm - 1, 256);
+    SkArgs sk;
+    if (!sk_plan_ragged(sk, a, (int)(K / 64), cus, split != 0)) return 1;
+    plan[0] = sk.t_dp; plan[1] = sk.sk_tiles; plan[2] = sk.ragged; plan[3] = sk.npairs; plan[4] = sk.t_dp_v; plan[5] = sk.P; plan[6] = sk.P_sk; plan[7] = a.group_m;
+    for (int w = 0; w <= cus; ++w) start[w] = sk.start[w];
+    return 0;
 }
 
 // Byte offset, inside a workspace of this device, of the 32-bit give-up counter rga3_gemm_stream_k_timeouts reads -- so a training loop can fetch it with its
@@ -2317,7 +2607,7 @@ static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const 
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || (tile >= 3 && tile <= 8) || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 23) || tile == 25 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || (tile >= 3 && tile <= 8) || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 23) || tile == 25 || tile == 26 || tile == 27 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;

@@ -69,6 +69,7 @@ SIGNATURES = {
     "rga3_gemm_rows16_many": [_p, _p, _i, _p],
     "rga3_gemm_stream_k_timeouts": [_p],
     "rga3_gemm_timeout_counter_offset": [],
+    "rga3_gemm_ragged_plan": [_i64, _i64, _i64, _i, _i, _p, _p],
     "rga3_quant_fp8_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "rga3_gemm_fp8": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "rga3_swiglu_fwd_quant_fp8": [_p, _p, _p, _i64, _i64, _p],

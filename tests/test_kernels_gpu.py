@@ -26,7 +26,7 @@ def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed / mis-mapped C fragment layout."""
     from rga3.hip import ops
 
-    for tile in (3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 20, 21, 22, 23, 31, 32):
+    for tile in (3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 20, 21, 22, 23, 26, 27, 31, 32):
         n, k = 256, 256
         a = torch.eye(k, dtype=torch.bfloat16, device=dev)
         w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(torch.bfloat16).to(dev)
@@ -36,7 +36,7 @@ def test_gemm_identity_asymmetric(dev):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (2112, 512, 3584), (8192, 1280, 1280), (64, 3456, 1280),
                                    (17, 24, 64), (1000, 152064 // 16, 192)])
-@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 23, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 23, 26, 27, 31, 32])
 def test_gemm_plain(dev, M, N, K, tile):
     from rga3.hip import ops
 
@@ -114,7 +114,7 @@ def test_gemm_stream_k_split_shapes(dev):
 
 
 @pytest.mark.parametrize("act", ["none", "gelu", "relu", "swiglu"])
-@pytest.mark.parametrize("tile", [3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 23, 31, 32])
+@pytest.mark.parametrize("tile", [3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 23, 26, 27, 31, 32])
 def test_gemm_epilogues(dev, act, tile):
     from rga3.hip import ops
 
@@ -127,6 +127,35 @@ def test_gemm_epilogues(dev, act, tile):
     ref = R.linear_ref(a.cpu(), w.cpu(), bias.cpu(), res.cpu(), act)
     assert out.shape == (M, n_out)
     assert _rel_l2(out, ref) < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(2112, 4736, 3584, "swiglu", False), (2112, 3584, 2368, "none", True), (320, 768, 192, "gelu", False), (4160, 1024, 1024, "none", True),
+                                             (257, 512, 64, "relu", True), (2112, 9472, 512, "none", False)])
+def test_gemm_ragged_last_tile_row(dev, M, N, K, act, res):
+    """Tiles 27 / 26 (persistent 256 x 256 / + stream-K tail; a last tile row of <= 64 rows -- M = 2112 = 8 x 256 + 64, the LLM's M in configs[1] / [2] -- runs a
+    quarter-work loop on three 40-KiB LDS stages, two such tiles scheduled as one unit): tile 27 has no K split and walks K in tile 21's order, so it is BIT-identical
+    to tile 21 (padded rows and all); tile 26 is equal to rounding and identical run to run; both against the fp32 reference (the products the reference reaches through
+    cuBLAS: HF modeling_qwen2_5_vl.py:211-321 gate | up, down via reference model/qwen_2_5_vl_sam2.py:182-200)."""
+    from rga3.hip import ops
+
+    a, w = _rand((M, K), dev, seed=61), _rand((N, K), dev, 0.05, seed=62)
+    bias = _rand((N,), dev, 0.3, seed=63)
+    n_out = N // 2 if act == "swiglu" else N
+    r = _rand((M, n_out), dev, seed=64) if res else None
+    ref21 = ops.gemm(a, w, bias=bias, residual=r, act=act, tile=21)
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, w, bias=bias, residual=r, act=act, tile=27), ref21)
+    z = ops.gemm(a, w, bias=bias, residual=r, act=act, tile=26)
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, w, bias=bias, residual=r, act=act, tile=26), z)
+    ref = R.linear_ref(a.cpu(), w.cpu(), bias.cpu(), r.cpu() if res else None, act)
+    assert _rel_l2(z, ref) < 8e-3 and _rel_l2(ref21, ref) < 8e-3
+    assert _rel_l2(z[M - 64:], ref[M - 64:]) < 8e-3          # the ragged rows by themselves
+    if act == "swiglu":    # the training forward's pre-activation output rides in the same epilogue
+        y27, pre27 = ops.gemm_swiglu_pre(a, w, bias, tile=27)
+        y21, pre21 = ops.gemm_swiglu_pre(a, w, bias, tile=21)
+        assert torch.equal(y27, y21) and torch.equal(pre27, pre21)
+    assert ops.gemm_stream_k_timeouts() == 0
 
 
 def test_gemm_f32_out_and_kpad(dev):
@@ -151,7 +180,7 @@ def test_gemm_rejects_bad_args(dev):
         ops.gemm(a.cpu(), w.cpu())
 
 
-@pytest.mark.parametrize("tile", [-1, 3, 12, 5, 6, 20, 21, 22, 23, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 12, 5, 6, 20, 21, 22, 23, 26, 27, 31, 32])
 @pytest.mark.parametrize("shape", [(300, 320, 256), (2112, 1280, 1280)])
 def test_gemm_rmsnorm_folded(dev, tile, shape):
     """RMSNorm folded into the products on either side (rga3_gemm_rms_bf16; HF Qwen2RMSNorm modeling_qwen2_5_vl.py:470-486 between o_proj / down_proj and
