@@ -53,7 +53,7 @@ int rga3_last_error(char* buf, size_t n);
  * reproducibly):
  *   20 = 256x256 ping-pong, one tile per workgroup;  21 = the same, persistent (one workgroup per CU);
  *   22 = persistent + stream-K tail (needs the caller workspace below);  27 / 26 = 21 / 22 whose last tile row, when it holds <= 64 rows (M = 2112 = 8 x 256 + 64),
- *   runs a quarter-work loop, two such tiles scheduled as one (as 21 / 22 for other M);  31 / 32 = 21 / 22 with 192x256 tiles (M = 2112 = 11 x 192);
+ *   runs a quarter-work loop on workgroups of its own (as 21 / 22 for other M);  31 / 32 = 21 / 22 with 192x256 tiles (M = 2112 = 11 x 192);
  *   25 = split-K for few output tiles over a very long K (same workspace; falls back to 21 when it does not apply);
  *   11, 12 / 3 / 4 / 5 / 13 = single-phase 128x128 / 128x256 / 128x320 / 128x192 / 64x64;  10 = single-phase 256x256 (first generation, A/B);
  *   14 = 64x64 with K cut into up to 32 slices (skinny plain products such as LoRA's x A^T: N = 128 over K = 3584; same workspace; runs as 13
@@ -321,7 +321,7 @@ int rga3_gemm_stream_k_timeouts(const void* workspace);
  * training loop can watch it every few steps without a device synchronisation (no reference counterpart: the reference's GEMMs are vendor BLAS calls) */
 int64_t rga3_gemm_timeout_counter_offset(void);
 /* HOST ONLY (no device call): the work plan tiles 26 (split = 1) / 27 (split = 0) launch for an [M, N, K] product on `cus` compute units.  plan[8] = {first tile of the
- * stream-K tail, tiles of the tail, 1, pairs of ragged tiles, data-parallel units, workgroups launched, workgroups with a run, tile rows per group}; start[cus + 1]:
+ * stream-K tail, tiles of the tail, 1, workgroups that take ragged tiles only, 0, workgroups launched, workgroups with a run, tile rows per group}; start[cus + 1]:
  * workgroup w takes K-iterations [start[w], start[w + 1]) of the tail line (tile-major, K / 64 iterations per tile).  Returns 0; 1 when the last tile row is not
  * ragged (more than 64 rows) or no plan applies (the tiles then run as 22 / 21); < 0 = bad arguments.  No reference counterpart (the reference's GEMMs are vendor
  * BLAS calls); exists so that what the kernel's hand-off relies on is testable without a GPU. */

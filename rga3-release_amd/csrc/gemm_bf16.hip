@@ -932,11 +932,12 @@ struct SkArgs {
     int sk_tiles;     // tiles [t_dp, t_dp + sk_tiles) are split
     int all_partial;  // split-K mode (tile 25): every slice only writes its slab; gemm_slab_reduce_kernel sums them afterwards
     int plain_slabs;  // measurement builds only (RGA3_AB, env RGA3_SK_PLAIN=1): the round-3 hand-off -- plain slab stores + agent-scope release fence
-    // ragged = 1 (tiles 26 / 27): the last tile row holds <= 64 rows (M = 2112 = 8 x 256 + 64); its ntn tiles run the quarter-work loop at about half the time of a full
-    // tile, so TWO of them make one unit of the data-parallel rounds ("pair").  Tile numbering then: [0, ntn) the ragged tiles by column, [ntn, T) the full tiles in the
-    // grouped order over ntm - 1 tile rows.  Data-parallel units v = w, w + P, ... < t_dp_v: v < npairs is the pair of ragged tiles 2v, 2v + 1 (the last pair is a single
-    // tile when ntn is odd), v >= npairs the full tile ntn + v - npairs.  t_dp (tile numbering) is where the stream-K tail starts.  ragged = 0: npairs = 0, t_dp_v = t_dp.
-    int ragged, npairs, t_dp_v;
+    // ragged = 1 (tiles 26 / 27): the last tile row holds <= 64 rows (M = 2112 = 8 x 256 + 64); its ntn tiles run the quarter-work loop.  Tile numbering then:
+    // [0, ntn) the ragged tiles by column, [ntn, T) the full tiles in the grouped order over ntm - 1 tile rows.  rg_wgs = G > 0: G workgroups, evenly spaced in the
+    // workgroup numbering (hence over the XCDs), take ONLY ragged tiles -- the one of rank j the columns j, j + G, ... -- and the other P - G share the full tiles
+    // [ntn, t_dp) strided by P - G.  G is sized so that both kinds finish together (sk_plan_ragged); a ragged workgroup then walks the tile columns at the pace the
+    // full-tile workgroups do, i.e. it reads weight columns that are in flight through the Infinity Cache anyway.  rg_wgs = 0: strided tiles w, w + P, ... < t_dp.
+    int ragged, rg_wgs;
     unsigned long long* dbg = nullptr;   // measurement builds only (RGA3_AB, env RGA3_SK_DBG=1): [P][8 items][8] s_memtime stamps of wave 0 (tools/probes/sk_items.py)
     // run table of the stream-K tail: workgroup w takes K-iterations [start[w], start[w + 1]) of the line  tile t_dp (nk iterations), tile t_dp + 1, ...
     // (host-made: equal runs, or runs sized by cost when ragged tiles are cheaper; sk_plan_*).  Empty runs are allowed.
@@ -1000,10 +1001,21 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             n_tw = max(end_whole - first_whole, 0);
         }
     }
-    const int n_dpv = (w < sk.t_dp_v) ? (sk.t_dp_v - w + sk.P - 1) / sk.P : 0;                          // data-parallel units of this workgroup ...
-    const int np_w = (w < sk.npairs) ? (min(sk.npairs, sk.t_dp_v) - w + sk.P - 1) / sk.P : 0;          // ... of which pairs of ragged tiles (they come first)
-    const int n_pi = 2 * np_w - ((np_w > 0 && 2 * (w + (np_w - 1) * sk.P) + 1 >= p.ntn) ? 1 : 0);   // tiles in those pairs (the last pair of an odd ntn is one tile)
-    const int n_dp = n_dpv - np_w + n_pi;
+    int n_dp, dp0 = w, dp_step = sk.P;   // data-parallel tiles dp0, dp0 + dp_step, ... (n_dp of them)
+    if (sk.rg_wgs > 0) {
+        const int G = sk.rg_wgs;
+        const int below = (w * G) / sk.P;   // ragged workgroups with a lower number
+        if (((w + 1) * G) / sk.P > below) {   // this workgroup takes ragged tiles only
+            dp0 = below; dp_step = G;
+            n_dp = (below < p.ntn) ? (p.ntn - below + G - 1) / G : 0;
+        } else {
+            const int rk = w - below, Pf = sk.P - G, nf = sk.t_dp - p.ntn;   // its rank among the full-tile workgroups; full tiles of the data-parallel part
+            dp0 = p.ntn + rk; dp_step = Pf;
+            n_dp = (rk < nf) ? (nf - rk + Pf - 1) / Pf : 0;
+        }
+    } else {
+        n_dp = (w < sk.t_dp) ? (sk.t_dp - w + sk.P - 1) / sk.P : 0;
+    }
     const int n_items = (na_tile >= 0) + n_dp + n_tw + (ow_tile >= 0);
     if (n_items == 0) return;
     // item i -> (tile, kb, ke, kind): kind 0 = whole tile, 1 = non-owner slice, 2 = owner slice
@@ -1012,12 +1024,7 @@ __global__ __launch_bounds__(512) void gemm_nt_sk_kernel(GemmArgs p, SkArgs sk) 
             if (i == 0) { tile = na_tile; kb = na_kb; ke = na_ke; kind = 1; return; }
             --i;
         }
-        if (i < n_dp) {
-            if (i < n_pi) tile = 2 * (w + (i >> 1) * sk.P) + (i & 1);
-            else tile = (sk.ragged ? p.ntn : 0) + (w + (i - n_pi + np_w) * sk.P) - sk.npairs;
-            kb = 0; ke = nk; kind = 0;
-            return;
-        }
+        if (i < n_dp) { tile = dp0 + i * dp_step; kb = 0; ke = nk; kind = 0; return; }
         i -= n_dp;
         if (i < n_tw) { tile = tw0 + i; kb = 0; ke = nk; kind = 0; return; }
         tile = ow_tile; kb = ow_kb; ke = nk; kind = sk.all_partial ? 1 : 2;
@@ -1643,61 +1650,79 @@ static void sk_plan_uniform(SkArgs& sk, int nk) {
     for (int w = 0; w <= kSkMaxP; ++w) sk.start[w] = (unsigned)((sk.P_sk > 0 && w < sk.P_sk) ? (long)w * tot / sk.P_sk : tot);
 }
 
-// Plan for a product whose last tile row is ragged (<= 64 rows: its ntn tiles run the quarter-work loop at about half a full tile's time; tools/probes/ragged_probe.py).
-// Two ragged tiles make one unit ("pair"): T_v = (ntm - 1) ntn + ceil(ntn / 2) units of about equal time.  Whole rounds of P units are data-parallel; the remaining
-// units go to the stream-K tail as EQUAL runs in unit time (run >= half a unit, so a full tile is cut into at most three slices and a ragged tile into at most two: the
-// owner adds at most two slabs) -- the tail's slices start at the half-unit marks, as tile 22's do: runs sized by a finer cost model (water-filling the workgroups to one
-// level) put every slice at its own K offset, the workgroups of an XCD stopped sharing operand tiles in L2, and the tail ran 1.75 x slower per iteration (measured:
-// gate | up 520 us against 491 for tile 22).  The pairs have the lowest unit numbers, so they are data-parallel whenever a whole round exists, and the tail then holds
-// full tiles only; a product with less than one round of units is all tail, ragged tiles first (a run of half a unit there is one whole ragged tile).
-// Returns false when neither form applies (0 < t_dp_v < npairs: never for the model's shapes).
+// Cost of a ragged tile in sixteenths of a full tile's time (tools/probes/ragged_cost.py, ragged_items.py: 0.58 next to the full tiles of its column, 0.62 - 0.8 when it
+// streams its weight columns from HBM alone; its loop without the loads 0.35)
+static int sk_ragged_cost16() {
+#ifdef RGA3_AB
+    static const int forced = [] { const char* e = getenv("RGA3_SK_RAGGED_COST"); return e ? atoi(e) : 0; }();
+    if (forced > 0 && forced <= 16) return forced;
+#endif
+    return 10;
+}
+
+// Plan for a product whose last tile row is ragged (<= 64 rows: its ntn tiles run the quarter-work loop at 0.6 of a full tile's time).
+//  * At least one round of tiles: G workgroups take ragged tiles only, P - G the full tiles (SkArgs::rg_wgs); G minimises max(ceil(ntn / G) c, rounds of the full
+//    tiles over P - G workgroups).  M = 2112 gate | up: 1184 full + 148 ragged tiles: 19 workgroups x 8 ragged tiles (5.0 rounds at c = 0.625), 237 x 5 full
+//    tiles -- five rounds where tile 22 runs five and a half and padded data-parallel rounds six.  (Two ragged tiles as ONE
+//    unit of the strided rounds -- the first form of these tiles -- left every pair 0.24 of a round over: 464 us against 486 for tile 22.)
+//    split: the full tiles beyond whole rounds of P - G go to the stream-K tail as tile 22's equal runs over the full-tile workgroups (ragged ones get an empty run).
+//  * Less than one round of tiles: no plan (tiles 22 / 21 as they are).  Tried: everything in the tail, ragged tiles first, equal runs in unit time -- the critical path
+//    stays half a full tile (down projection 247 against 239 us).  Also tried and dropped: tail runs sized by water-filling the workgroups' data-parallel cost to one
+//    level (every slice at its own K offset: the workgroups of an XCD stopped sharing operand tiles in L2 and the tail ran 1.75 x slower per iteration), and the natural
+//    tile order with the tail's half-tile slices handed to the workgroups that met ragged tiles (gate | up 494 against 478 us for tile 22; profiles/r05_ragged_experiments.log).
 static bool sk_plan_ragged(SkArgs& sk, const GemmArgs& a, int nk, int P, bool split) {
     constexpr int MIN_SEG = 8;
-    const int ntn = a.ntn, T = a.ntm * a.ntn;
-    const int npairs = (ntn + 1) / 2;
-    const int T_v = (a.ntm - 1) * ntn + npairs;
-    const int rem_v = T_v % P;
+    const int ntn = a.ntn, T = a.ntm * a.ntn, T_full = T - ntn;
     sk.ragged = 1;
-    sk.npairs = npairs;
+    sk.rg_wgs = 0;
     sk.all_partial = 0;
-    if (!split || rem_v == 0) {   // data-parallel only (the last round may be partly filled)
-        sk.P = T_v < P ? T_v : P;
-        sk.t_dp_v = T_v;
-        sk.t_dp = T;
-        sk.sk_tiles = 0;
+    if (T < P) return false;   // less than one round of tiles: tile 22's half-tile slices are the critical path either way (a whole ragged tile costs more than half a full one)
+    // G = the number of ragged workgroups with the shortest critical path (sixteenths of a full tile's time): ragged side ceil(ntn / G) c, full-tile side whole rounds
+    // of P - G plus the tail (split) or the partly filled last round
+    const int c16 = sk_ragged_cost16();
+    int G = 0;
+    long best = -1;
+    for (int g = 1; g < P / 2 && g <= ntn; ++g) {
+        const int pf = P - g;
+        const long rag = cdiv(ntn, g) * c16;
+        long full;
+        if (!split) full = 16L * cdiv(T_full, pf);
+        else {
+            const int r = T_full % pf;
+            long psk = 2L * r;
+            if (psk > pf) psk = pf;
+            full = 16L * (T_full / pf) + (r ? cdiv(16L * r, psk) : 0);
+        }
+        const long ms = rag > full ? rag : full;
+        if (best < 0 || ms < best) { best = ms; G = g; }
+    }
+    if (G < 1) return false;
+    const int Pf = P - G;
+    sk.P = P;
+    sk.rg_wgs = G;
+    const int rem = split ? T_full % Pf : 0;
+    sk.t_dp = T - rem;
+    sk.sk_tiles = rem;
+    if (rem == 0) {
         sk.P_sk = 0;
         sk_plan_uniform(sk, nk);
         return true;
     }
-    sk.P = P;
-    sk.t_dp_v = T_v - rem_v;
-    if (sk.t_dp_v == 0) {
-        // everything is tail: line = ntn ragged tiles (half time per iteration), then the full tiles.  Equal runs in unit time, 2 * nk half-time ticks per unit.
-        sk.t_dp = 0;
-        sk.sk_tiles = T;
-        long want = 2L * T_v, cap = (long)T_v * nk / MIN_SEG;
-        if (want > cap) want = cap;
-        if (want > P) want = P;
-        if (want < T_v) want = T_v;   // T_v < P here
-        sk.P_sk = (int)want;
-        const long ticks = (long)ntn * nk + 2L * (T - ntn) * nk;   // ragged iteration = 1 tick, full iteration = 2
-        const long rag_ticks = (long)ntn * nk;
-        for (int w = 0; w <= kSkMaxP; ++w) {
-            long tk = (w < sk.P_sk) ? (long)w * ticks / sk.P_sk : ticks;
-            sk.start[w] = (unsigned)(tk <= rag_ticks ? tk : rag_ticks + (tk - rag_ticks) / 2);
-        }
-        return true;
-    }
-    if (sk.t_dp_v < npairs) return false;
-    // pairs are data-parallel; the tail is rem_v full tiles: tile 22's equal runs
-    sk.t_dp = ntn + (sk.t_dp_v - npairs);
-    sk.sk_tiles = rem_v;
-    long cap = (long)rem_v * nk / MIN_SEG, want = 2L * rem_v;
+    long cap = (long)rem * nk / MIN_SEG, want = 2L * rem;
     if (want > cap) want = cap;
-    if (want > P) want = P;
-    if (want < rem_v) want = rem_v;
+    if (want > Pf) want = Pf;
+    if (want < rem) want = rem;
     sk.P_sk = (int)want;
-    sk_plan_uniform(sk, nk);
+    // equal runs over the first P_sk full-tile workgroups
+    const long tot = (long)rem * nk;
+    int rk = 0;
+    sk.start[0] = 0;
+    for (int w = 0; w < P; ++w) {
+        const bool rgw = ((long)(w + 1) * G) / P > ((long)w * G) / P;
+        if (!rgw && rk < sk.P_sk) ++rk;
+        sk.start[w + 1] = (unsigned)(rk < sk.P_sk ? (long)rk * tot / sk.P_sk : tot);
+    }
+    for (int w = P + 1; w <= kSkMaxP; ++w) sk.start[w] = (unsigned)tot;
     return true;
 }
 
@@ -1723,15 +1748,15 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st, bool ragged
     sk.tmo = ws.flags ? ws.flags + ws.P : nullptr;
     const int rem = T % ws.P;
     sk.ragged = 0;
-    sk.npairs = 0;
-    // ragged last tile row (MH = 4, more than one tile row): pairs of ragged tiles as data-parallel units
+    sk.rg_wgs = 0;
+    // ragged last tile row (MH = 4, more than one tile row): workgroups of their own for the ragged tiles
     const int last_rows = a.M - (a.ntm - 1) * 256;
     bool planned = false;
     if (MH == 4 && ragged && a.ntm >= 2 && last_rows <= 64) {
         a.group_m = pick_group_m(a.ntm - 1, 256);   // the grouped order covers the full tile rows only
         sk.plain_slabs = sk_plain_slabs();
         planned = sk_plan_ragged(sk, a, nk, ws.P, split);
-        if (!planned) { sk.ragged = 0; sk.npairs = 0; a.group_m = pick_group_m(a.ntm, 256); }
+        if (!planned) { sk.ragged = 0; sk.rg_wgs = 0; a.group_m = pick_group_m(a.ntm, 256); }
     }
     if (planned) {
     } else if (!split || rem == 0) {
@@ -1741,7 +1766,6 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st, bool ragged
         sk.P_sk = 0;
         sk.all_partial = 0;
         sk.plain_slabs = sk_plain_slabs();
-        sk.t_dp_v = sk.t_dp;
         sk_plan_uniform(sk, nk);
     } else {
         // slices per split tile <= 3 (owner + two contributors: the kernel's accumulator init reads at most two slabs)
@@ -1758,7 +1782,6 @@ static int launch_sk(const GemmArgs& a0, bool split, hipStream_t st, bool ragged
         sk.P_sk = (int)want;
         sk.all_partial = 0;
         sk.plain_slabs = sk_plain_slabs();
-        sk.t_dp_v = sk.t_dp;
         sk_plan_uniform(sk, nk);
     }
 #ifdef RGA3_AB
@@ -1805,7 +1828,7 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     if (S < 2) return launch_sk<ACT, OUT_F32>(a0, false, st);
     SkArgs sk;
     sk.slabs = ws.slabs; sk.flags = ws.flags; sk.tmo = ws.flags + ws.P;
-    sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1; sk.plain_slabs = 0; sk.ragged = 0; sk.npairs = 0; sk.t_dp_v = 0;
+    sk.P = T * S; sk.P_sk = T * S; sk.t_dp = 0; sk.sk_tiles = T; sk.all_partial = 1; sk.plain_slabs = 0; sk.ragged = 0; sk.rg_wgs = 0;
     if (sk.P > kSkMaxP) return launch_sk<ACT, OUT_F32>(a0, false, st);
     sk_plan_uniform(sk, nk);
     constexpr int LDS = 2 * 4 * 128 * 128;
@@ -2430,8 +2453,8 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
             else return launch_pp<ACT, OUT_F32>(a, st);
         case 21: return launch_sk<ACT, OUT_F32>(a, false, st);
         case 22: return launch_sk<ACT, OUT_F32>(a, true, st);
-        case 26: return launch_sk<ACT, OUT_F32>(a, true, st, true);    // 22 / 21 whose ragged last tile row (<= 64 rows: M = 2112 = 8 x 256 + 64) runs the quarter-work loop,
-        case 27: return launch_sk<ACT, OUT_F32>(a, false, st, true);   //   two such tiles counted as one unit of work
+        case 26: return launch_sk<ACT, OUT_F32>(a, true, st, true);    // 22 / 21 whose ragged last tile row (<= 64 rows: M = 2112 = 8 x 256 + 64) runs the quarter-work loop
+        case 27: return launch_sk<ACT, OUT_F32>(a, false, st, true);   //   on workgroups of its own
         case 31: return launch_sk<ACT, OUT_F32, 3>(a, false, st);   // 192 x 256 tiles, persistent
         case 32: return launch_sk<ACT, OUT_F32, 3>(a, true, st);    // ... + stream-K tail
         case 25: return launch_splitk<ACT, OUT_F32>(a, st);
@@ -2488,7 +2511,7 @@ extern "C" int rga3_gemm_stream_k_timeouts(const void* workspace) {
 }
 
 // Host only (no device needed): the work plan tiles 26 (split = 1) / 27 (split = 0) launch for an [M, N, K] product on `cus` compute units.  plan[8] = {first tile of the
-// stream-K tail, tiles of the tail, 1, pairs of ragged tiles, data-parallel units, workgroups launched, workgroups with a run, tile rows per group}; start[0 .. cus]:
+// stream-K tail, tiles of the tail, 1, workgroups that take ragged tiles only, 0, workgroups launched, workgroups with a run, tile rows per group}; start[0 .. cus]:
 // workgroup w takes K-iterations [start[w], start[w + 1]) of the tail line.  Returns 0; 1 when the product has no ragged last tile row or no plan applies (the tiles
 // then run as 22 / 21); < 0 on bad arguments.  Lets CPU tests check what the kernel's owner / contributor hand-off relies on.
 extern "C" int rga3_gemm_ragged_plan(int64_t M, int64_t N, int64_t K, int cus, int split, int* plan, unsigned* start) {
@@ -2502,7 +2525,7 @@ extern "C" int rga3_gemm_ragged_plan(int64_t M, int64_t N, int64_t K, int cus, i
     a.group_m = pick_group_m(a.ntm - 1, 256);
     SkArgs sk;
     if (!sk_plan_ragged(sk, a, (int)(K / 64), cus, split != 0)) return 1;
-    plan[0] = sk.t_dp; plan[1] = sk.sk_tiles; plan[2] = sk.ragged; plan[3] = sk.npairs; plan[4] = sk.t_dp_v; plan[5] = sk.P; plan[6] = sk.P_sk; plan[7] = a.group_m;
+    plan[0] = sk.t_dp; plan[1] = sk.sk_tiles; plan[2] = sk.ragged; plan[3] = sk.rg_wgs; plan[4] = 0; plan[5] = sk.P; plan[6] = sk.P_sk; plan[7] = a.group_m;
     for (int w = 0; w <= cus; ++w) start[w] = sk.start[w];
     return 0;
 }
