@@ -54,6 +54,8 @@ int rga3_last_error(char* buf, size_t n);
  *   20 = 256x256 ping-pong, one tile per workgroup;  21 = the same, persistent (one workgroup per CU);
  *   22 = persistent + stream-K tail (needs the caller workspace below);  27 / 26 = 21 / 22 whose last tile row, when it holds <= 64 rows (M = 2112 = 8 x 256 + 64),
  *   runs a quarter-work loop on workgroups of its own (as 21 / 22 for other M);  31 / 32 = 21 / 22 with 192x256 tiles (M = 2112 = 11 x 192);
+ *   28 = 256x256 on FOUR waves (128x128 wave blocks, accumulators in the AGPRs, hand-ordered MFMA / fragment-read / LDS-DMA stream), one tile per workgroup,
+ *        K a multiple of 64 (runs as 20 otherwise): bit-identical to 20, faster on long K (8192^3: 1 465 against 1 369 TFLOP/s), slower below K ~ 2000;
  *   25 = split-K for few output tiles over a very long K (same workspace; falls back to 21 when it does not apply);
  *   11, 12 / 3 / 4 / 5 / 13 = single-phase 128x128 / 128x256 / 128x320 / 128x192 / 64x64;  10 = single-phase 256x256 (first generation, A/B);
  *   14 = 64x64 with K cut into up to 32 slices (skinny plain products such as LoRA's x A^T: N = 128 over K = 3584; same workspace; runs as 13

@@ -1585,6 +1585,197 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(SlabReduceArgs p)
     }
 }
 
+// =====================================================================================================================
+// 256x256 tile on FOUR waves (tile id 28; one tile per workgroup, K % 64 == 0): wave blocks of 128 x 128, accumulators in the 256 AGPRs, one wave per SIMD.
+// Why: the 8-wave loops read 24 KiB of fragments per wave and K-tile -- 192 KiB per CU against 64 KiB staged: the LDS port is as busy as the matrix pipe (1536 + 512
+// of 2048 cycles) and the main loop runs at 75 % of the MFMA rate.  128 x 128 wave blocks read 32 KiB per wave = 128 KiB per CU (-33 %).  A lone wave per SIMD overlaps
+// nothing by itself, so the stream is hand-ordered (round 5 lesson 1): every fragment read and every LDS-DMA piece sits between two MFMAs, all as asm statements in
+// source order; fragments of quadrant g + 1 are read while quadrant g multiplies.
+//  * LDS image, swizzle, half-tiles A0 A1 B0 B1 as in the ping-pong kernels; a half-tile = 16 one-KiB pieces, four per wave.
+//  * per K-tile four quadrants of 32 MFMAs:  Q0 = A0 B0,  Q1 = A0 B1,  Q2 = A1 B1,  Q3 = A1 B0, and TWO barriers (the four waves run in lockstep): X in front of Q0,
+//    Y in front of Q2; the schedule is at the K-tile lambda below.
+//  * B0 fragments live in two register sets (B0 of K-tile q is still multiplied in Q3 while B0 of q + 1 is read): the loop is unrolled by two K-tiles.
+__device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void lds_frag(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory"); }
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, BK = 64, ROWB = 128;
+    constexpr int HALF = 128 * ROWB, BUF = 4 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const unsigned nwg = (unsigned)(p.ntm * p.ntn);
+    const unsigned t = xcd_remap(blockIdx.x, nwg);
+    const unsigned GROUP_M = (unsigned)p.group_m;
+    const unsigned per_group = GROUP_M * p.ntn;
+    const unsigned group = t / per_group;
+    const unsigned first_m = group * GROUP_M;
+    const unsigned gsz = min((unsigned)p.ntm - first_m, GROUP_M);
+    const int m0 = (int)(first_m + (t % per_group) % gsz) * BM;
+    const int n0 = (int)((t % per_group) / gsz) * BN;
+    const int nk = p.K / BK;
+
+    // staging: piece pc = wid + 4 i of a half-tile = LDS rows 8 pc .. 8 pc + 7
+    const int sch = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
+    unsigned soff[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wid + 4 * i) * 8 + (lane >> 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int arow = (r >> 6) * 128 + h * 64 + (r & 63);
+            const int bcol = (r >> 5) * 64 + h * 32 + (r & 31);
+            soff[h][i] = (unsigned)((long)min(m0 + arow, p.M - 1) * p.lda + sch * 8);
+            soff[2 + h][i] = (unsigned)((long)min(n0 + bcol, p.N - 1) * p.ldw + sch * 8);
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;   // LDS byte address of the buffers
+    auto stage_piece = [&](auto KIND, int i, int kt, int buf) {
+        constexpr int kind = decltype(KIND)::value;
+        const unsigned short* base = ((kind < 2) ? p.A : p.W) + (long)kt * BK;
+        unsigned o = soff[kind][i];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds((gbl_void*)(base + o), (lds_void*)(smem + buf * BUF + kind * HALF + (wid + 4 * i) * 1024), 16, 0, 0);
+    };
+    using K_A0 = std::integral_constant<int, 0>;
+    using K_A1 = std::integral_constant<int, 1>;
+    using K_B0 = std::integral_constant<int, 2>;
+    using K_B1 = std::integral_constant<int, 3>;
+    auto stage_all = [&](auto KIND, int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_piece(KIND, i, kt, buf);
+    };
+
+    // fragment addresses: one base register per (operand side, kk, buffer); half-tile and m- / n-tile offsets ride in the instruction's offset field
+    unsigned fa[2][2], fb[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned f = lds0 + (unsigned)(b * BUF) + (unsigned)((lane & 15) * ROWB + (((kk * 4 + (lane >> 4)) ^ ((lane >> 1) & 7)) << 4));
+            fa[b][kk] = f + (unsigned)((wr * 64) * ROWB);
+            fb[b][kk] = f + (unsigned)(2 * HALF + (wc * 64) * ROWB);
+        }
+    auto rd = [&](bf16x8& d, unsigned base, int off) {   // off folds to a constant after unrolling ("i": checked by the backend)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(base), "i"(off) : "memory");
+    };
+
+    f32x4 acc[8][8];
+    bf16x8 a0[4][2], a1[4][2], b1[4][2], b0x[4][2], b0y[4][2];
+
+    if constexpr (act_uses_table<ACT>()) stage_act_table<4>(smem + 2 * BUF, ACT == ACT_SWIGLU, wid, lane);
+
+    // ---- prologue, in the steady-state issue order  [A0 B0](0) [B1 A1](0) [A0 B0](1) [B1 A1](1)
+    stage_all(K_A0{}, 0, 0);
+    stage_all(K_B0{}, 0, 0);
+    stage_all(K_B1{}, 0, 0);
+    stage_all(K_A1{}, 0, 0);
+    if (nk > 1) {
+        stage_all(K_A0{}, 1, 1);
+        stage_all(K_B0{}, 1, 1);
+        stage_all(K_B1{}, 1, 1);
+        stage_all(K_A1{}, 1, 1);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // [A0 B0](0) have landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            rd(a0[mi][kk], fa[0][kk], mi * 2048);
+            rd(b0x[mi][kk], fb[0][kk], mi * 2048);
+        }
+
+    // quadrant (ha, hb): acc[ha * 4 + mi][(ni >> 1) * 4 + hb * 2 + (ni & 1)] += B frag (as the MFMA's A operand) x A frag; 32 MFMAs, `between(s)` runs after MFMA s.
+    // FIRST (K-tile 0): the first k-step takes the constant 0 as C operand -- the accumulators are defined by MFMAs and never exist outside the AGPRs inside the loop
+    auto quadrant = [&](auto FIRST, auto HA, auto HB, const bf16x8 (&af)[4][2], const bf16x8 (&bf)[4][2], auto&& between) {
+        constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
+        constexpr bool first = decltype(FIRST)::value;
+        int s = 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f32x4& c = acc[ha * 4 + mi][(ni >> 1) * 4 + hb * 2 + (ni & 1)];
+                    if (first && kk == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(bf[ni][kk]), "v"(af[mi][kk]));
+                    else mfma_agpr(c, bf[ni][kk], af[mi][kk]);
+                    between(s);
+                    ++s;
+                }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    using TRUE_T = std::true_type;
+    using FALSE_T = std::false_type;
+
+    // One K-tile in buffer PARITY: TWO barriers.  X (start): [B1 A1](q) have landed, every wave has retired its reads of [A0 B0](q) -- their regions take [A0 B0](q+2)
+    // during Q0 / Q1.  Y (middle): [A0 B0](q+1) have landed, the reads of [B1 A1](q) are retired -- their regions take [B1 A1](q+2) during Q2 / Q3.  In front of either
+    // barrier exactly 16 loads have been issued after the youngest half-tile it needs: vmcnt(16) (vmcnt(0) once nothing is left to issue).
+    // B0C = this K-tile's B0 fragments, B0N = the set the next K-tile's are read into.  STEADY: K-tiles q + 1 and q + 2 exist (no conditions inside).
+    auto ktile = [&](auto FIRST, auto PARITY, auto STEADY, int q, bf16x8 (&B0C)[4][2], bf16x8 (&B0N)[4][2]) {
+        constexpr int cur = decltype(PARITY)::value, nxt = cur ^ 1;
+        constexpr bool steady = decltype(STEADY)::value;
+        const bool e1 = steady || q + 1 < nk, e2 = steady || q + 2 < nk;
+        const unsigned short* const gA = p.A + (long)(q + 2) * BK;
+        const unsigned short* const gW = p.W + (long)(q + 2) * BK;
+        auto piece = [&](const unsigned short* g, int kind, int i) {
+            unsigned o = soff[kind][i];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_void*)(g + o), (lds_void*)(smem + cur * BUF + kind * HALF + (wid + 4 * i) * 1024), 16, 0, 0);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (e2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- Q0 = A0 B0: read B1(q); issue A0(q+2)
+        quadrant(FIRST, H0{}, H0{}, a0, B0C, [&](int s) {
+            if (s < 8) rd(b1[s >> 1][s & 1], fb[cur][s & 1], HALF + (s >> 1) * 2048);
+            else if (s >= 12 && s < 28 && ((s - 12) & 3) == 0 && e2) piece(gA, 0, (s - 12) >> 2);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- Q1 = A0 B1: read A1(q); issue B0(q+2)
+        quadrant(FIRST, H0{}, H1{}, a0, b1, [&](int s) {
+            if (s < 8) rd(a1[s >> 1][s & 1], fa[cur][s & 1], HALF + (s >> 1) * 2048);
+            else if (s >= 12 && s < 28 && ((s - 12) & 3) == 0 && e2) piece(gW, 2, (s - 12) >> 2);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (e2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- Q2 = A1 B1: issue B1(q+2); read A0(q+1)
+        quadrant(FIRST, H1{}, H1{}, a1, b1, [&](int s) {
+            if (s < 8) { if (e1) rd(a0[s >> 1][s & 1], fa[nxt][s & 1], (s >> 1) * 2048); }
+            else if (s >= 12 && s < 28 && ((s - 12) & 3) == 0 && e2) piece(gW, 3, (s - 12) >> 2);
+        });
+        // ---- Q3 = A1 B0: issue A1(q+2); read B0(q+1)
+        quadrant(FIRST, H1{}, H0{}, a1, B0C, [&](int s) {
+            if (s < 8) { if (e1) rd(B0N[s >> 1][s & 1], fb[nxt][s & 1], (s >> 1) * 2048); }
+            else if (s >= 12 && s < 28 && ((s - 12) & 3) == 0 && e2) piece(gA, 1, (s - 12) >> 2);
+        });
+    };
+    // K-tile 0, then pairs (odd buffer, even buffer); the last two K-tiles run the conditional form
+    if (nk >= 3) ktile(TRUE_T{}, H0{}, TRUE_T{}, 0, b0x, b0y); else ktile(TRUE_T{}, H0{}, FALSE_T{}, 0, b0x, b0y);
+    int q = 1;
+    for (; q + 3 < nk; q += 2) {
+        ktile(FALSE_T{}, H1{}, TRUE_T{}, q, b0y, b0x);
+        ktile(FALSE_T{}, H0{}, TRUE_T{}, q + 1, b0x, b0y);
+    }
+    for (; q < nk; q += 2) {
+        ktile(FALSE_T{}, H1{}, FALSE_T{}, q, b0y, b0x);
+        if (q + 1 < nk) ktile(FALSE_T{}, H0{}, FALSE_T{}, q + 1, b0x, b0y);
+    }
+    asm volatile("s_nop 15" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue<8, 8, 128, 128, ACT, OUT_F32>(acc, p, smem + wid * 1024, smem + 2 * BUF, lane, m0, n0, wr, wc);
+}
+
 // Tile order: consecutive logical tiles walk down GROUP_M tile rows, then step to the next tile column.  An XCD holds 32
 // consecutive tiles, i.e. GROUP_M x (32 / GROUP_M) of them share its L2.  GROUP_M = 4 keeps that block squarish (least
 // L2 fill traffic) but walks the whole weight matrix once per group of 4 tile rows: with few tile rows (M = 2112 is 9) and
@@ -1860,6 +2051,22 @@ static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn)), dim3(512), LDS, st, a);
     RGA3_CHECK_LAUNCH("gemm_nt_pp_kernel");
+    return 0;
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_w4(const GemmArgs& a0, hipStream_t st) {
+    if (a0.K % 64 != 0) return launch_pp<ACT, OUT_F32>(a0, st);
+    GemmArgs a = a0;
+    a.ntm = (int)cdiv(a.M, 256);
+    a.ntn = (int)cdiv(a.N, 256);
+    a.group_m = pick_group_m(a.ntm, 256);
+    constexpr int LDS = 2 * 4 * 128 * 128 + (act_uses_table<ACT>() ? kActTabBytes : 0);
+    auto kern = gemm_nt_w4_kernel<ACT, OUT_F32>;
+    static LdsGrant lds_grant;
+    if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "gemm")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntm * a.ntn)), dim3(256), LDS, st, a);
+    RGA3_CHECK_LAUNCH("gemm_nt_w4_kernel");
     return 0;
 }
 
@@ -2458,6 +2665,7 @@ static int launch_act(const GemmArgs& a, int tile, hipStream_t st) {
         case 31: return launch_sk<ACT, OUT_F32, 3>(a, false, st);   // 192 x 256 tiles, persistent
         case 32: return launch_sk<ACT, OUT_F32, 3>(a, true, st);    // ... + stream-K tail
         case 25: return launch_splitk<ACT, OUT_F32>(a, st);
+        case 28: return launch_w4<ACT, OUT_F32>(a, st);   // 256 x 256 on four waves (128 x 128 wave blocks, AGPR accumulators), one tile per workgroup
         case 40: return launch_gemv<ACT, OUT_F32>(a, st);   // M <= 4: weight stream (decode step)
         case 41: return launch_rows16<ACT, OUT_F32>(a, st);  // 5 <= M <= 16 token rows
         default: return launch_cfg<128, 128, 2, 2, ACT, OUT_F32, 0>(a, st);
@@ -2630,7 +2838,7 @@ static int gemm_bf16_impl(const void* A, const void* W, const void* bias, const 
     RGA3_CHECK_ARG(act >= 0 && act <= 3, "gemm: act %d", act);
     RGA3_CHECK_ARG(!(out_dtype == RGA3_F32 && (act != ACT_NONE || residual || colscale)), "gemm: f32 output supports bias only");
     RGA3_CHECK_ARG(act != ACT_SWIGLU || N % 32 == 0, "gemm: swiglu needs N %% 32 == 0");
-    RGA3_CHECK_ARG(tile == -1 || (tile >= 3 && tile <= 8) || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 23) || tile == 25 || tile == 26 || tile == 27 || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
+    RGA3_CHECK_ARG(tile == -1 || (tile >= 3 && tile <= 8) || (tile >= 10 && tile <= 14) || (tile >= 20 && tile <= 23) || tile == 25 || (tile >= 26 && tile <= 28) || tile == 31 || tile == 32 || tile == 40 || tile == 41, "gemm: tile %d", tile);
     RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm: operands must be < 2^32 elements (32-bit staging offsets)");
     GemmArgs a;
     a.A = (const unsigned short*)A;

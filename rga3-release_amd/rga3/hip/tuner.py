@@ -14,7 +14,7 @@ import os
 
 import torch
 
-CANDIDATES = (20, 21, 22, 27, 31, 32, 12, 13, 3, 4, 5, 6)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail / persistent with the ragged-row loop;
+CANDIDATES = (20, 21, 22, 27, 28, 31, 32, 12, 13, 3, 4, 5, 6)   # 256x256 ping-pong: one tile per workgroup / persistent / persistent + stream-K tail / persistent with the ragged-row loop; 28 = 256x256 on four waves;
                                                # 192x256 persistent / + stream-K tail (M = 2112 = 11 x 192); single-phase 128x128, 64x64,
                                                # 128x256, 128x320, 128x192; 128x256 with three LDS stages (two K-tiles in flight)
 _cache = {}

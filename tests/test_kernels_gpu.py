@@ -26,7 +26,7 @@ def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric W catches a transposed / mis-mapped C fragment layout."""
     from rga3.hip import ops
 
-    for tile in (3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 20, 21, 22, 23, 26, 27, 31, 32):
+    for tile in (3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 20, 21, 22, 23, 26, 27, 28, 31, 32):
         n, k = 256, 256
         a = torch.eye(k, dtype=torch.bfloat16, device=dev)
         w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(torch.bfloat16).to(dev)
@@ -36,7 +36,7 @@ def test_gemm_identity_asymmetric(dev):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (2112, 512, 3584), (8192, 1280, 1280), (64, 3456, 1280),
                                    (17, 24, 64), (1000, 152064 // 16, 192)])
-@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 23, 26, 27, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 4, 5, 10, 11, 12, 13, 14, 20, 21, 22, 23, 26, 27, 28, 31, 32])
 def test_gemm_plain(dev, M, N, K, tile):
     from rga3.hip import ops
 
@@ -114,7 +114,7 @@ def test_gemm_stream_k_split_shapes(dev):
 
 
 @pytest.mark.parametrize("act", ["none", "gelu", "relu", "swiglu"])
-@pytest.mark.parametrize("tile", [3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 23, 26, 27, 31, 32])
+@pytest.mark.parametrize("tile", [3, 4, 5, 10, 11, 12, 13, 20, 21, 22, 23, 26, 27, 28, 31, 32])
 def test_gemm_epilogues(dev, act, tile):
     from rga3.hip import ops
 
@@ -158,6 +158,25 @@ def test_gemm_ragged_last_tile_row(dev, M, N, K, act, res):
     assert ops.gemm_stream_k_timeouts() == 0
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(2112, 4736, 3584, "swiglu", False), (520, 3584, 2368, "none", True), (320, 768, 192, "gelu", False), (4160, 1024, 64, "none", True),
+                                             (257, 512, 128, "relu", True), (1000, 1000, 200, "none", False)])
+def test_gemm_four_wave_tile(dev, M, N, K, act, res):
+    """Tile 28 (256 x 256 on four waves: 128 x 128 wave blocks, accumulators in the AGPRs, MFMAs / fragment reads / LDS-DMA pieces in one hand-ordered stream, two
+    barriers per K-tile): every element is summed in tile 20's K order, so the outputs are BIT-identical to tile 20 -- one, two, three K-tiles (prologue / tail forms),
+    ragged M / N, every epilogue kind; K not a multiple of 64 runs as tile 20.  (The products the reference reaches through cuBLAS: HF modeling_qwen2_5_vl.py:211-321.)"""
+    from rga3.hip import ops
+
+    a, w = _rand((M, K), dev, seed=71), _rand((N, K), dev, 0.05, seed=72)
+    bias = _rand((N,), dev, 0.3, seed=73)
+    n_out = N // 2 if act == "swiglu" else N
+    r = _rand((M, n_out), dev, seed=74) if res else None
+    ref20 = ops.gemm(a, w, bias=bias, residual=r, act=act, tile=20)
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, w, bias=bias, residual=r, act=act, tile=28), ref20)
+    ref = R.linear_ref(a.cpu(), w.cpu(), bias.cpu(), r.cpu() if res else None, act)
+    assert _rel_l2(ref20, ref) < 8e-3
+
+
 def test_gemm_f32_out_and_kpad(dev):
     from rga3.hip import ops
 
@@ -180,7 +199,7 @@ def test_gemm_rejects_bad_args(dev):
         ops.gemm(a.cpu(), w.cpu())
 
 
-@pytest.mark.parametrize("tile", [-1, 3, 12, 5, 6, 20, 21, 22, 23, 26, 27, 31, 32])
+@pytest.mark.parametrize("tile", [-1, 3, 12, 5, 6, 20, 21, 22, 23, 26, 27, 28, 31, 32])
 @pytest.mark.parametrize("shape", [(300, 320, 256), (2112, 1280, 1280)])
 def test_gemm_rmsnorm_folded(dev, tile, shape):
     """RMSNorm folded into the products on either side (rga3_gemm_rms_bf16; HF Qwen2RMSNorm modeling_qwen2_5_vl.py:470-486 between o_proj / down_proj and
