@@ -65,6 +65,8 @@ rm -rf /tmp/pt; timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -
 python3 $R/tools/step_timeline.py /tmp/pt --bin-ms 5 --from-ms 0 --to-ms 1000 --exclude gemm_ > $O/r05_train_step_timeline.txt 2>&1; tail -n +2 $O/r05_train_step_timeline.txt | head -3
 # 5. probes + the GPU test suite, the driver's command
 timeout -k 10 600 python3 $R/tools/blas_reference_point.py > $O/r05_blas.log 2>&1; cp $O/blas_reference_point.json $O/r05_blas_reference_point.json
+(cd $R && timeout -k 10 600 python3 tools/probes/ragged_probe.py both 10 > $O/r05_ragged_probe.log 2>&1; tail -12 $O/r05_ragged_probe.log | cut -c1-300)
+(cd $R && timeout -k 10 600 python3 tools/probes/w4_probe.py 3 > $O/r05_w4_probe.log 2>&1; tail -3 $O/r05_w4_probe.log | cut -c1-300)
 python3 $R/tools/evaluate_probe.py > $O/r05_evaluate_probe.log 2>&1; tail -1 $O/r05_evaluate_probe.log
 python3 $R/tools/generate_probe.py 64 > $O/r05_generate_probe.log 2>&1; tail -1 $O/r05_generate_probe.log
 cd $R && python3 -m pytest tests/ -x -q -m gpu > $O/r05_gpu_tests.log 2>&1; tail -2 $O/r05_gpu_tests.log
