@@ -5,7 +5,8 @@
   summarise  python3 tools/pmc_pipe_util.py sum <dir> <out.json>    reads every *counter_collection.csv under <dir> (one sub-directory per pass)
 
 Targets (kernel name needle -> the call that launches it at the shape of the headline step / configs[1] forward / configs[3] stream):
-  gemm_nt_sk_kernel<2, false, 4>   LLM gate-up with the SwiGLU epilogue, 2112 x 37888 x 3584 (tile 22)
+  gemm_nt_sk_kernel<2, false, 4, false / true>   LLM gate-up with the SwiGLU epilogue, 2112 x 37888 x 3584 (tile 22 / tile 27: ragged last tile row on workgroups of its own)
+  gemm_nt_w4_kernel<0, false>   the four-wave kernel at the LM head's shape, 2112 x 152064 x 3584 (tile 28)
   gemm_nt_sk_kernel<0, false, 3>   the three-phase 192-row loop at the decoder's q|k|v shape, 2112 x 4608 x 3584 (tile 31)
   hiera_mlp_kernel<HmCfg<144 / 288   fused Hiera MLP of stage 1 / stage 2 on 8 frames
   gemm_nt_sk_kernel<0,       LLM down projection + residual, 2112 x 3584 x 18944 (tile 22)
@@ -34,7 +35,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-TARGETS = ["gemm_nt_sk_kernel<2, false, 4>", "gemm_nt_sk_kernel<0, false, 4>", "gemm_nt_sk_kernel<0, false, 3>", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel<0, false, false, true>", "gemm_nt_pp_kernel<1, false, true, false>", "attn_fwd_kernel<128", "attn_causal32_kernel",
+TARGETS = ["gemm_nt_sk_kernel<2, false, 4, true>", "gemm_nt_sk_kernel<2, false, 4, false>", "gemm_nt_sk_kernel<0, false, 4, false>", "gemm_nt_sk_kernel<0, false, 3, false>", "gemm_nt_w4_kernel<0, false>", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel<0, false, false, true>", "gemm_nt_pp_kernel<1, false, true, false>", "attn_fwd_kernel<128", "attn_causal32_kernel",
            "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_win_kernel<96, 8", "memattn_cross_kernel", "hiera_mlp_kernel<rga3::HmCfg<144", "hiera_mlp_kernel<rga3::HmCfg<288"]
 
 
@@ -55,7 +56,13 @@ def run():
     wgu = [rn(37888, 3584, scale=0.02) for _ in range(2)]
     for i in range(R):
         ops.gemm(x, wgu[i % 2], act="swiglu", tile=22)
+    for i in range(R):   # the ragged last tile row on workgroups of its own (round 5: what the forward runs)
+        ops.gemm(x, wgu[i % 2], act="swiglu", tile=27)
     del wgu
+    wlm = rn(152064, 3584, scale=0.02)   # the four-wave kernel at the LM head's shape (round 5; tile 28)
+    for i in range(2):
+        ops.gemm(x, wlm, tile=28)
+    del wlm
     h = rn(2112, 18944)
     wd = [rn(3584, 18944, scale=0.02) for _ in range(2)]
     for i in range(R):
@@ -145,6 +152,7 @@ def summarise(d, out):
         res[t] = e
     res["_derivation"] = ("mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); wave_* = share of SQ_WAVE_CYCLES; lds_array_busy = SQ_LDS_IDX_ACTIVE / "
                           "(kernel cycles x 256 CUs); separate rocprofv3 --pmc passes per counter set, program directly after '--'")
+    sys.path.insert(0, os.path.join(ROOT, "rga3-release_amd"))
     from rga3.utils.fingerprint import tree_fingerprint
     res["_tree"] = tree_fingerprint()     # bench.py quotes this file only while the running tree has the same fingerprint
     json.dump(res, open(out, "w"), indent=1)
