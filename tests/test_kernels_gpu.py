@@ -177,6 +177,22 @@ def test_gemm_four_wave_tile(dev, M, N, K, act, res):
     assert _rel_l2(ref20, ref) < 8e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(2112, 1536, 512), (320, 520, 192), (577, 256, 64)])
+def test_gemm_f32_output_on_the_round5_tilings(dev, M, N, K):
+    """f32 output (bias only) through tiles 26 / 27 (ragged last tile row when M leaves <= 64 rows) and 28 (four waves): the tuner offers them for every product,
+    f32-output ones included; equal to tile 20 (bit-identical for 27 / 28: same K order) and to the fp32 reference."""
+    from rga3.hip import ops
+
+    a, w, bias = _rand((M, K), dev, seed=91), _rand((N, K), dev, 0.05, seed=92), _rand((N,), dev, 0.3, seed=93)
+    ref20 = ops.gemm(a, w, bias=bias, out_dtype=torch.float32, tile=20)
+    ref = R.linear_ref(a.cpu(), w.cpu(), bias.cpu())
+    assert ref20.dtype == torch.float32 and _rel_l2(ref20, ref) < 1e-3
+    for tile in (27, 28):
+        assert torch.equal(ops.gemm(a, w, bias=bias, out_dtype=torch.float32, tile=tile), ref20), tile
+    z = ops.gemm(a, w, bias=bias, out_dtype=torch.float32, tile=26)
+    assert _rel_l2(z, ref) < 1e-3 and torch.equal(z, ops.gemm(a, w, bias=bias, out_dtype=torch.float32, tile=26))
+
+
 def test_gemm_f32_out_and_kpad(dev):
     from rga3.hip import ops
 
