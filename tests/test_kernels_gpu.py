@@ -193,6 +193,23 @@ def test_gemm_f32_output_on_the_round5_tilings(dev, M, N, K):
     assert _rel_l2(z, ref) < 1e-3 and torch.equal(z, ops.gemm(a, w, bias=bias, out_dtype=torch.float32, tile=26))
 
 
+def test_gemm_colscale_and_pre_on_the_round5_tilings(dev):
+    """Column scale + residual (ConvNeXt layer scale of the SAM2 memory encoder, reference model/sam2.py:2618-2655) and the SwiGLU pre-activation output through tiles
+    27 / 28 on a ragged M: bit-identical to tiles 21 / 20."""
+    from rga3.hip import ops
+
+    M, N, K = 2112, 768, 256
+    a, w, bias = _rand((M, K), dev, seed=95), _rand((N, K), dev, 0.05, seed=96), _rand((N,), dev, 0.3, seed=97)
+    r, cs = _rand((M, N), dev, seed=98), _rand((N,), dev, 0.2, seed=99)
+    ref = ops.gemm(a, w, bias=bias, residual=r, act="gelu", colscale=cs, tile=20)
+    for tile in (27, 28):
+        assert torch.equal(ops.gemm(a, w, bias=bias, residual=r, act="gelu", colscale=cs, tile=tile), ref), tile
+    y20, pre20 = ops.gemm_swiglu_pre(a, w, bias, tile=20)
+    for tile in (27, 28):
+        y, pre = ops.gemm_swiglu_pre(a, w, bias, tile=tile)
+        assert torch.equal(y, y20) and torch.equal(pre, pre20), tile
+
+
 def test_gemm_f32_out_and_kpad(dev):
     from rga3.hip import ops
 
