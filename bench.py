@@ -690,6 +690,48 @@ def sam2_stream(args, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def _board_sample(step, seconds=3.0):
+    """Board power / shader clock WHILE `step` runs in a loop (rocm-smi from a side thread; outside the timed region): every GEMM tiling of this model runs at the
+    board's power cap (DESIGN.md lesson 7), so the clock the run held is part of the measurement.  None when rocm-smi is missing or says nothing parseable."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def poll():
+        time.sleep(0.4)
+        while not stop[0] and len(samples) < 3:
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=15).stdout
+            except Exception:   # noqa: BLE001
+                return
+            d = {}
+            m = re.search(r"(?:Average|Current Socket) Graphics Package Power \(W\):\s*([\d.]+)", out)
+            if m:
+                d["power_w"] = float(m.group(1))
+            m = re.search(r"sclk clock level:\s*\d+:?\s*\((\d+)Mhz\)", out)
+            if m:
+                d["sclk_mhz"] = int(m.group(1))
+            if d:
+                samples.append(d)
+
+    try:
+        th = threading.Thread(target=poll, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        while th.is_alive() and time.perf_counter() - t0 < seconds:
+            step()
+            torch.cuda.synchronize()
+        stop[0] = True
+        th.join(timeout=20)
+    except Exception:   # noqa: BLE001
+        return None
+    if not samples:
+        return None
+    return {"power_w": [x.get("power_w") for x in samples], "sclk_mhz": [x.get("sclk_mhz") for x in samples],
+            "note": "rocm-smi sampled while the timed forward repeats (after the timed region); idle: ~310 W at 2400 MHz; the bf16 peak of the roofline (2.5 PFLOP/s) is the 2400 MHz figure"}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def measure_forward(model_fwd, inputs, args, rank, refine=True):
     """configs[1]: K timed forwards (+ the GEMM-family instrumented pass and the output check on rank 0).  Returns (ms per step, roofline dict, verify dict)."""
@@ -752,6 +794,9 @@ def measure_forward(model_fwd, inputs, args, rank, refine=True):
             "whole_forward_frac": round(TOTAL_FLOPS / (ms * 1e-3) / PEAK_BF16, 4), "flops_per_forward": TOTAL_FLOPS,
             "algorithmic_bytes_per_launch": round(gt.bytes / max(len(gt.ev), 1)), "variants_ms": variants_fwd}
     _put_traffic(roof, "forward")
+    board = _board_sample(step)
+    if board is not None:
+        roof["board"] = board
     mb, msrc = _mfma_busy("gemm_nt", "attn_causal32", "attn_win")
     if msrc is not None:
         roof["mfma_busy"], roof["mfma_busy_source"] = mb, msrc
