@@ -257,7 +257,7 @@ def _traffic(tag, family="gemm"):
     tj = json.load(open(path))
     if tj.get("tree") != _tree():
         return None, f"profiles/{os.path.basename(path)} REFUSED: collected on tree {tj.get('tree')}, running tree is {_tree()}", True
-    if not tj.get("launches_fetch_pass") or not tj.get("launches_write_pass"):     # a pass that recorded nothing (the profiler died): no figure, not a zero
+    if tj.get("launches_fetch_pass") == 0 or tj.get("launches_write_pass") == 0:     # a pass that recorded nothing (the profiler died): no figure, not a zero
         return None, f"profiles/{os.path.basename(path)}: the counter passes recorded no launches", False
     return round(tj["traffic_bytes_per_launch"]), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on tree {tj['tree']}, bytes per launch)", False
 
