@@ -690,19 +690,68 @@ def sam2_stream(args, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+_PROFILER_ENV = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCP_TOOL_LIB", "HSA_TOOLS_LIB", "ROCPROFILER_", "ROCPROF_", "ROCP_")
+
+
+def _under_profiler():
+    """True when a profiler's preload environment is present: a child started from here would inherit it (and a '#!/usr/bin/env python3' child such as rocm-smi
+    would then take an exec hop with the GPU already initialised by the preloaded library -- forbidden on this pool)."""
+    return any(k == p or (p.endswith("_") and k.startswith(p)) for k in os.environ for p in _PROFILER_ENV)
+
+
+def _sysfs_board():
+    """[(power file, clock file)] of every amdgpu card the kernel exposes: hwmon power1_average / power1_input (microwatts) and freq1_input (Hz) -- plain file
+    reads inside this process, nothing is spawned."""
+    import glob
+    cards = []
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        pw = next((os.path.join(hw, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, n))), None)
+        fq = os.path.join(hw, "freq1_input")
+        if pw is not None:
+            cards.append((pw, fq if os.path.exists(fq) else None))
+    return cards
+
+
+def _read_number(path):
+    try:
+        with open(path) as f:
+            return float(f.read().split()[0])
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def _board_sample(step, seconds=3.0):
-    """Board power / shader clock WHILE `step` runs in a loop (rocm-smi from a side thread; outside the timed region): every GEMM tiling of this model runs at the
-    board's power cap (DESIGN.md lesson 7), so the clock the run held is part of the measurement.  None when rocm-smi is missing or says nothing parseable."""
+    """Board power / shader clock WHILE `step` runs in a loop (outside the timed region): every GEMM tiling of this model runs at the board's power cap (DESIGN.md
+    lesson 7), so the clock the run held is part of the measurement.  Read from sysfs in-process (hwmon power1_average, freq1_input) by a side thread; with several
+    cards visible in sysfs the busiest one (highest power under this load) is reported.  rocm-smi is only a fallback, never under a profiler, and its child gets an
+    environment without the profiler's variables.  None when neither source says anything."""
     import re
     import subprocess
     import threading
     samples, stop = [], [False]
+    cards = _sysfs_board()
+    profiled = _under_profiler()
+    if not cards and profiled:
+        return None
 
-    def poll():
+    def poll_sysfs():
         time.sleep(0.4)
+        while not stop[0] and len(samples) < 6:
+            best = None
+            for pw, fq in cards:
+                w = _read_number(pw)
+                if w is not None and (best is None or w > best[0]):
+                    best = (w, _read_number(fq) if fq else None)
+            if best is not None:
+                samples.append({"power_w": round(best[0] / 1e6, 1), "sclk_mhz": None if best[1] is None else int(best[1] / 1e6)})
+            time.sleep(0.4)
+
+    def poll_smi():
+        time.sleep(0.4)
+        env = {k: v for k, v in os.environ.items() if not any(k == p or (p.endswith("_") and k.startswith(p)) for p in _PROFILER_ENV)}
         while not stop[0] and len(samples) < 3:
             try:
-                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=15).stdout
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=15, env=env).stdout
             except Exception:   # noqa: BLE001
                 return
             d = {}
@@ -716,7 +765,7 @@ def _board_sample(step, seconds=3.0):
                 samples.append(d)
 
     try:
-        th = threading.Thread(target=poll, daemon=True)
+        th = threading.Thread(target=poll_sysfs if cards else poll_smi, daemon=True)
         th.start()
         t0 = time.perf_counter()
         while th.is_alive() and time.perf_counter() - t0 < seconds:
@@ -728,8 +777,8 @@ def _board_sample(step, seconds=3.0):
         return None
     if not samples:
         return None
-    return {"power_w": [x.get("power_w") for x in samples], "sclk_mhz": [x.get("sclk_mhz") for x in samples],
-            "note": "rocm-smi sampled while the timed forward repeats (after the timed region); idle: ~310 W at 2400 MHz; the bf16 peak of the roofline (2.5 PFLOP/s) is the 2400 MHz figure"}
+    return {"power_w": [x.get("power_w") for x in samples], "sclk_mhz": [x.get("sclk_mhz") for x in samples], "source": "sysfs hwmon" if cards else "rocm-smi",
+            "note": "sampled while the timed forward repeats (after the timed region); idle: ~310 W at 2400 MHz; the bf16 peak of the roofline (2.5 PFLOP/s) is the 2400 MHz figure"}
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -794,7 +843,7 @@ def measure_forward(model_fwd, inputs, args, rank, refine=True):
             "whole_forward_frac": round(TOTAL_FLOPS / (ms * 1e-3) / PEAK_BF16, 4), "flops_per_forward": TOTAL_FLOPS,
             "algorithmic_bytes_per_launch": round(gt.bytes / max(len(gt.ev), 1)), "variants_ms": variants_fwd}
     _put_traffic(roof, "forward")
-    board = _board_sample(step)
+    board = None if getattr(args, "no_board", False) else _board_sample(step)
     if board is not None:
         roof["board"] = board
     mb, msrc = _mfma_busy("gemm_nt", "attn_causal32", "attn_win")
@@ -842,6 +891,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-board", action="store_true", help="skip the board power / shader clock sample (roofline.board)")
     ap.add_argument("--mode", choices=["headline", "forward", "train", "train_full", "sam2_stream", "lora_fp8", "ddp_selftest"], default="headline",
                     help="headline (default) = BASELINE metric: configs[2] per GPU, full RGA3 (Qwen2.5-VL-7B + SAM2-L, 16 SAM frames) fwd+bwd + AdamW as `value`, plus the "
                          "configs[1] forward roofline in the same line; forward = configs[1] only; train = LLM-side LoRA step without SAM2; train_full = headline without "

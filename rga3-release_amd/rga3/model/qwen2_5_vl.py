@@ -672,10 +672,21 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
         return self.lm_head
 
     def gradient_checkpointing_enable(self, *a, **k):
+        """reference train_joint.py:188.  Wired to the decoder's activation-recompute switch: a layer then saves only its input and recomputes the rest in backward
+        (qwen_train.set_activation_recompute) -- the reference's memory behaviour.  On a 288 GB part the kept activations (8 GB at S = 2112) fit: leave this call out,
+        or call gradient_checkpointing_disable() after it, for the faster keep-activations step (same arithmetic, tests/test_train_gpu.py)."""
+        from . import qwen_train
         self.gradient_checkpointing = True
+        qwen_train.set_activation_recompute(True)
 
     def gradient_checkpointing_disable(self):
+        from . import qwen_train
         self.gradient_checkpointing = False
+        qwen_train.set_activation_recompute(False)
+
+    @property
+    def is_gradient_checkpointing(self):
+        return bool(self.gradient_checkpointing)
 
     def enable_input_require_grads(self):
         self._input_require_grads = True

@@ -158,14 +158,25 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
         if images_sam is None or not images_sam.is_cuda or images_sam.requires_grad or any(p_.requires_grad for p_ in enc.parameters()):
             return
         if after is not None:
-            box = {}
+            # at most ONE pending hook on the model: a new request replaces the sample of a hook that never fired (backward skipped, parameter frozen
+            # later, micro-step without its gradient) instead of stacking another closure over a stale tensor; the hook reads the latest request when it fires.
+            pend = self.__dict__.get("_pf_sam_pending")
+            if pend is not None and pend["param"] is after:
+                pend["images"] = images_sam
+                return
+            self._drop_pending_sam_prefetch()
+            pend = self.__dict__["_pf_sam_pending"] = {"param": after, "images": images_sam}
 
             def fire(_p):
-                box.pop("h").remove()          # one shot
-                self.prefetch_sam(images_sam)
+                cur = self.__dict__.get("_pf_sam_pending")
+                if cur is None or cur is not pend:
+                    return
+                self._drop_pending_sam_prefetch()          # one shot
+                self.prefetch_sam(cur["images"])
 
-            box["h"] = after.register_post_accumulate_grad_hook(fire)
+            pend["handle"] = after.register_post_accumulate_grad_hook(fire)
             return
+        self._drop_pending_sam_prefetch()
         st = self.__dict__.get("_pf_sam_stream")
         if st is None:
             st = self.__dict__["_pf_sam_stream"] = torch.cuda.Stream(device=images_sam.device)
@@ -184,7 +195,15 @@ class UniGRModel(Qwen2_5_VLForConditionalGeneration):
                 done.record(st)
             cache[img.data_ptr()] = ((images_sam._version, tuple(img.shape), img.dtype), images_sam, lv, done)   # holds images_sam: its address cannot be recycled meanwhile
 
+    def _drop_pending_sam_prefetch(self):
+        pend = self.__dict__.pop("_pf_sam_pending", None)
+        if pend is not None and pend.get("handle") is not None:
+            pend["handle"].remove()
+
     def _prefetched_sam(self, images_sam, i):
+        pend = self.__dict__.get("_pf_sam_pending")
+        if pend is not None and pend["images"] is images_sam:
+            self._drop_pending_sam_prefetch()     # its gradient never arrived and the sample is being forwarded now: the request is moot
         cache = self.__dict__.get("_pf_sam_cache")
         img = images_sam[i]
         hit = cache.pop(img.data_ptr(), None) if cache else None

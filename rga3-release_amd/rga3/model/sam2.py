@@ -1063,6 +1063,10 @@ def _graph_cache(m, session=None):
     slot = getattr(session, "slot", 0) if session is not None else 0
     if ("pool", slot) not in cache:
         cache[("pool", slot)] = torch.cuda.graph_pool_handle()       # the graphs of one slot never run concurrently: one private pool per slot
+        # ... and one CAPTURE stream per slot: ops.py keys its scratch (stream-K slabs / flags, the memory-attention partial sums, the TN counters) by
+        # (device, current stream), and the pointers a capture sees are baked into the graph -- slots whose graphs replay concurrently (MultiObjectSession)
+        # must not share them.  Warm-up runs on the same stream so that every scratch buffer of that key exists before the capture.
+        cache[("stream", slot)] = torch.cuda.Stream()
     return cache
 
 
@@ -1140,13 +1144,13 @@ class VideoSession:
             return o["low_res_masks"], o["obj_ptr"], o["best_iou_inds"]
 
         if fresh:
-            side = torch.cuda.Stream()
+            side = cache[("stream", self.slot)]
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 body()
             torch.cuda.current_stream().wait_stream(side)
             ent["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)]):
+            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)], stream=side):
                 ent["outs"] = body()
         ent["graph"].replay()
         low, ptr, best = ent["outs"]
@@ -1268,13 +1272,13 @@ class VideoSession:
         moves += [(G["mem"][p0 + dd * k:p0 + (dd + 1) * k], self.non_cond[t - dd]["obj_ptr"].reshape(-1, m.mem_dim)) for dd in range(1, n_pp + 1)]
         ops.copy_many(moves)
         if fresh:
-            side = torch.cuda.Stream()
+            side = cache[("stream", self.slot)]
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):      # warm-up on a side stream: tuner picks, workspaces and lazily built tables exist before capture
+            with torch.cuda.stream(side):      # warm-up on the slot's capture stream: tuner picks, THIS stream's workspaces and lazily built tables exist before capture
                 body()
             torch.cuda.current_stream().wait_stream(side)
             ent["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)]):
+            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)], stream=side):
                 ent["outs"] = body()
         ent["graph"].replay()
         outs = [torch.empty_like(o_) for o_ in ent["outs"]]      # the graph's result buffers are overwritten by the next replay

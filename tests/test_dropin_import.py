@@ -36,3 +36,22 @@ def test_method_signatures_match_reference_contract():
     for key in ('"loss"', '"ce_loss"', '"mask_bce_loss"', '"mask_dice_loss"', '"mask_loss"', '"pred_masks"', '"gt_masks"'):
         assert key in src
     assert list(inspect.signature(UniGRModel.forward).parameters) == ["self", "kwargs"]
+
+
+def test_gradient_checkpointing_flag_drives_the_recompute_switch():
+    """reference train_joint.py:188 calls model.gradient_checkpointing_enable(): here that IS the decoder's activation-recompute switch."""
+    from rga3.model import qwen_train as QT
+    from rga3.model.qwen_2_5_vl_sam2 import UniGRConfig, UniGRModel
+
+    c = UniGRConfig(train_mask_decoder=True, out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=7, sam_pretrained=None,
+                    hidden_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, intermediate_size=64, vocab_size=32,
+                    vision_config=dict(depth=1, hidden_size=32, num_heads=2, intermediate_size=32, out_hidden_size=64))
+    m = UniGRModel(c)
+    assert QT._acts["store"] is True and not m.is_gradient_checkpointing
+    try:
+        m.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"use_reentrant": False})
+        assert QT._acts["store"] is False and m.is_gradient_checkpointing
+        m.gradient_checkpointing_disable()
+        assert QT._acts["store"] is True and not m.is_gradient_checkpointing
+    finally:
+        QT.set_activation_recompute(False)

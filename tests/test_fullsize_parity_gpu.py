@@ -191,6 +191,34 @@ def test_sam2_l_memory_attention_full_bank(dev):
     assert rel(y, ref) < 2e-2
 
 
+def test_sam2_l_concurrent_slot_graphs_bit_exact_at_bench_shape(dev):
+    """ADVICE r5 (high) at the configs[3] shape (SAM2-L, 1024 x 1024: the memory cross-attention runs its split form with partial sums in scratch, the products their
+    stream-K slabs): three object slots replaying already-captured frame graphs on three streams, clips 2 and 3 of the session cache, equal bit for bit to the same
+    objects tracked one after the other without graphs."""
+    from rga3.model.sam2 import MultiObjectSession, VideoSession
+
+    m, _ = _sam2_l(dev, 23)
+    n_obj, T = 3, 6
+    g = torch.Generator().manual_seed(3)
+    embs = [torch.randn(1, 1, 256, generator=g).to(torch.bfloat16).to(dev) for _ in range(n_obj)]
+
+    def track(vid, feats, **kw):
+        ms = MultiObjectSession(m.sam2_model, vid, n_obj, feats=feats)
+        for o in range(n_obj):
+            ms.add_language_embd(0, o, embs[o])
+        return torch.cat([mk for _, mk in ms.propagate(**kw)], 0)
+
+    with torch.no_grad():
+        for clip in range(3):
+            vid = torch.randn(T, 3, 1024, 1024, generator=g).to(torch.bfloat16).to(dev)
+            feats = VideoSession(m.sam2_model, vid)._ensure_feats()
+            got = track(vid, feats, use_graph=True, concurrent=True)
+            want = track(vid, feats, use_graph=False, concurrent=False)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"clip {clip}"
+    assert not torch.equal(got[0], got[1])
+
+
 def test_decoder_layer_7b_lora_r128_forward_backward_s2112(dev):
     """the TRAINING leg at full size.  One Qwen2.5-7B decoder layer (3584 wide, 28 Q / 4 KV heads x 128, SwiGLU 18 944) with LoRA r = 128 /
     alpha = 256 on q_proj and v_proj (reference train_joint.py:193-251, run_torchrun.sh:30-31), final RMSNorm, a trainable LM head (vocabulary cut to 8 192 rows

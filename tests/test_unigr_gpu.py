@@ -458,3 +458,40 @@ def test_sam_encoder_prefetch_is_bit_identical_and_optional(model, dev, G):
         for k in ref:
             assert torch.equal(ref[k], out3[k]), k
         model.__dict__["_pf_sam_cache"].clear()
+
+
+def test_deferred_sam_prefetch_keeps_one_pending_hook(model, dev, G):
+    """prefetch_sam(after=param) defers the launch to the moment `param`'s gradient has been accumulated.  A gradient that never arrives must not
+    leave hooks behind: a later request REPLACES the pending one (one handle on the model, the latest sample), a forward of the pending sample itself drops it, and
+    when the gradient finally arrives exactly one encoder pass runs -- for the latest request."""
+    b = to_dev(make_batch(CASES["11"], seed=3), dev)
+    b2 = to_dev(make_batch(CASES["11"], seed=4), dev)
+    p = model.text_hidden_fcs[0][2].weight
+    req = p.requires_grad
+    p.requires_grad_(True)
+    try:
+        for bb in (b, b2, b, b2):
+            model.prefetch_sam(bb["images_sam"], after=p)                     # no backward in between: the gradient "never arrives"
+        pend = model.__dict__["_pf_sam_pending"]
+        assert pend["images"] is b2["images_sam"] and len(p._post_accumulate_grad_hooks) == 1
+        model.__dict__.setdefault("_pf_sam_cache", {}).clear()
+        (p.float().sum() * 0.0).backward()                                    # the gradient arrives: ONE launch, for the latest request
+        p.grad = None
+        assert "_pf_sam_pending" not in model.__dict__ and not p._post_accumulate_grad_hooks
+        cache = model.__dict__["_pf_sam_cache"]
+        assert len(cache) == b2["images_sam"].shape[0] and all(v[1] is b2["images_sam"] for v in cache.values())
+        with torch.no_grad():
+            ref = model(**b2, inference=False)                                # consumes the prefetched features
+            assert len(cache) == 0
+            again = model(**b2, inference=False)
+        for k in ref:
+            assert torch.equal(ref[k], again[k]), k
+        # a pending request for the very sample now being forwarded is dropped by that forward
+        model.prefetch_sam(b["images_sam"], after=p)
+        with torch.no_grad():
+            model(**b, inference=False)
+        assert "_pf_sam_pending" not in model.__dict__ and not p._post_accumulate_grad_hooks
+    finally:
+        model._drop_pending_sam_prefetch()
+        p.requires_grad_(req)
+        p.grad = None
