@@ -159,6 +159,19 @@ int rga3_layernorm_fwd(const void* x, const void* weight, const void* bias, void
 int rga3_layernorm_stats(const void* x, float* stats, int64_t rows, int64_t dim, int64_t ldx, float eps, void* stream);
 int rga3_gemm_ln_bf16(const void* A, const void* Wf, const void* bias, const float* colc, const float* rowstat, void* C, int64_t M, int64_t N, int64_t K,
                       int64_t lda, int64_t ldw, int64_t ldc, int act, int tile, void* stream);
+/* The LayerNorm statistics out of the PRODUCER's epilogue (round 6): the residual-writing products of a Hiera MultiScaleBlock -- x = shortcut + proj(attn), which
+ * norm2 reads, and x = x + mlp(norm2(x)), which the next block's norm1 reads (reference model/sam2.py:1085-1117) -- leave, per output row r and TILE COLUMN t,
+ *   row_parts[r][t] = (sum, sum of squares) of the bf16 values written to row r inside tile column t          (f32 pairs, [M][slices][2])
+ * with slices = rga3_gemm_lnsum_slices(N, tile).  Plain stores, each element written exactly once (the waves of a workgroup combine through LDS in wave order): no
+ * atomics, nothing to zero, bitwise reproducible.  rga3_gemm_lnsum_bf16 = rga3_gemm_bf16 (bf16 output, M > 16, no activation, tiles -1 / 3 / 5 / 12 / 13 / 20 / 23:
+ * single-pass kernels instantiated for this epilogue, so no other product's kernel changes) with that output; rga3_gemm_lnq_bf16 = rga3_gemm_ln_bf16 reading such
+ * partial sums (norm_width = the row width they cover, eps the LayerNorm's; the partials of a row are added, and mean and the biased variance S2 / w - mean^2
+ * formed, in f64 inside the kernel).  Together they replace the stand-alone rga3_layernorm_stats pass over the rows. */
+int64_t rga3_gemm_lnsum_slices(int64_t N, int tile);
+int rga3_gemm_lnsum_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                         int64_t ldw, int64_t ldc, int64_t ldr, int tile, float* row_parts, void* stream);
+int rga3_gemm_lnq_bf16(const void* A, const void* Wf, const void* bias, const float* colc, const float* row_parts, int64_t slices, int64_t norm_width, float eps,
+                       void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int act, int tile, void* stream);
 
 /* In-place rotary embedding on q and k heads living inside one [T, nheads_total, D] buffer (fused QKV output):
  * x = x*cos + rotate_half(x)*sin in fp32, cos/sin: [T, D] f32 tables (HF apply_rotary_pos_emb_vision

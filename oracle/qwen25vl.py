@@ -203,6 +203,19 @@ class storage:
         _STORE[0] = self.old
 
 
+def _softmax_pv(scores, v):
+    """softmax(scores) @ v.  fp32 mode: exactly that.  bf16-storage mode: as the fused attention kernels store it (flash-attn 2 on the reference's GPUs, torch's
+    CPU flash kernel behind sdpa -- and this build's HIP kernels): the UN-normalised exponentials exp(s - rowmax) are rounded to bf16 for the second product, the row
+    sums are taken from the fp32 exponentials, and the fp32 product is divided by them before the one rounding of the output.  Pinned against transformers' own bf16
+    run by tests/golden/qwen_mid_bf16.npz (normalise-then-round, the eager form, sits 4 x further from that run)."""
+    if _STORE[0] is None:
+        return torch.nan_to_num(torch.softmax(scores, dim=-1)) @ v
+    m = scores.amax(-1, keepdim=True)
+    m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))     # fully masked (padding) query rows
+    e = torch.exp(scores - m)
+    return _r(torch.nan_to_num((_r(e) @ v) / e.sum(-1, keepdim=True)))
+
+
 def rms_norm(x, w, eps):
     """HF:74-79 (the normalised rows are cast back to the input dtype BEFORE the weight multiplies them)"""
     v = x.pow(2).mean(-1, keepdim=True)
@@ -229,10 +242,13 @@ def _lin(x, P, name):
     return y
 
 
-def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw, cfg: QwenCfg, return_pre_merge=False):
+def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw, cfg: QwenCfg, return_pre_merge=False, trace: Optional[list] = None,
+                blocks: Optional[Sequence[int]] = None, x_start: Optional[torch.Tensor] = None):
     """HF:408-471 Qwen2_5_VisionTransformerPretrainedModel.forward, fp32.
 
-    pixel_values [N, C*Tp*P*P] (rows ordered t, h/2, w/2, 2, 2; cols C, Tp, P, P)."""
+    pixel_values [N, C*Tp*P*P] (rows ordered t, h/2, w/2, 2, 2; cols C, Tp, P, P).
+    Test hooks: trace collects the (window-ordered) residual stream after the patch embedding and after every block; blocks = the block indices to run (default all)
+    starting from x_start [N, hidden] (window order) instead of the patch embedding -- one block on a GIVEN input (tests/test_oracle_qwen.py, teacher-forced pins)."""
     v = cfg.vision
     unit = v.spatial_merge_size ** 2
     hd = v.hidden_size // v.num_heads
@@ -247,6 +263,10 @@ def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw
     x = _r(pixel_values.float() @ w.t())
     N = x.shape[0]
     x = x.reshape(N // unit, unit, -1)[win_idx].reshape(N, -1)  # HF:434-438
+    if x_start is not None:
+        x = x_start.float()
+    if trace is not None:
+        trace.append(x)
 
     inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float32) / (hd // 2)))  # HF:125-134, dim = hd/2
     rot = (pos_ids.unsqueeze(-1).float() * inv_freq).flatten(1)  # [N, hd/2]
@@ -254,7 +274,7 @@ def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw
     emb = torch.cat((rot, rot), dim=-1)
     cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]
 
-    for li in range(v.depth):
+    for li in (range(v.depth) if blocks is None else blocks):
         pre = f"visual.blocks.{li}."
         cu = cu_full if li in v.fullatt_block_indexes else cu_win
         h = rms_norm(x, P[pre + "norm1.weight"], 1e-6)
@@ -267,18 +287,18 @@ def vit_forward(P: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grid_thw
         if len(lens) > 1 and (lens == lens[0]).all():  # equal-length segments: one batched product (same arithmetic)
             L = int(lens[0])
             qq, kk, vv = (z.reshape(-1, L, v.num_heads, hd).transpose(1, 2) for z in (q, k, val))
-            pr = _r(torch.softmax(qq @ kk.transpose(2, 3) * hd ** -0.5, dim=-1))
-            att = _r(pr @ vv).transpose(1, 2).reshape(N, v.num_heads, hd)
+            att = _softmax_pv(qq @ kk.transpose(2, 3) * hd ** -0.5, vv).transpose(1, 2).reshape(N, v.num_heads, hd)
         else:
             for s in range(len(cu) - 1):  # HF:266-287: independent segments
                 a, b = int(cu[s]), int(cu[s + 1])
                 qq, kk, vv = (z[a:b].transpose(0, 1) for z in (q, k, val))
-                pr = _r(torch.softmax(qq @ kk.transpose(1, 2) * hd ** -0.5, dim=-1))
-                att[a:b] = _r(pr @ vv).transpose(0, 1)
+                att[a:b] = _softmax_pv(qq @ kk.transpose(1, 2) * hd ** -0.5, vv).transpose(0, 1)
         x = _r(x + _lin(att.reshape(N, -1), P, pre + "attn.proj"))
         h = rms_norm(x, P[pre + "norm2.weight"], 1e-6)
         h = _lin(_r(_r(F.silu(_lin(h, P, pre + "mlp.gate_proj"))) * _lin(h, P, pre + "mlp.up_proj")), P, pre + "mlp.down_proj")
         x = _r(x + h)
+        if trace is not None:
+            trace.append(x)
     pre_merge = x
     # merger (HF:137-150) then undo the window permutation (HF:464-466)
     h = rms_norm(x, P["visual.merger.ln_q.weight"], 1e-6).reshape(N // unit, -1)
@@ -301,7 +321,7 @@ def mrope_cos_sin(position_ids: torch.Tensor, cfg: QwenCfg):
     return cos, sin
 
 
-def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, past=None, return_kv=False):
+def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, past=None, return_kv=False, hidden_states: Optional[list] = None):
     """HF:788-870 text model + :602-757 decoder layer, fp32, eager causal attention with key-padding mask.
 
     past: optional list of (k, v) [B,Hkv,Sp,hd] per layer (generate); returns post-final-norm hidden states."""
@@ -326,6 +346,8 @@ def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, pa
         mask = torch.where(eye & ~am[:, None, -S:, None], torch.zeros_like(mask), mask)
     x = inputs_embeds.float()
     new_kv = []
+    if hidden_states is not None:
+        hidden_states.append(x)
     for li in range(t.num_hidden_layers):
         pre = f"model.layers.{li}."
         h = rms_norm(x, P[pre + "input_layernorm.weight"], t.rms_norm_eps)
@@ -340,13 +362,13 @@ def llm_forward(P, inputs_embeds, position_ids, attention_mask, cfg: QwenCfg, pa
         new_kv.append((k, v))
         kk, vv = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
         sc = q @ kk.transpose(2, 3) * hd ** -0.5 + mask
-        pr = torch.softmax(sc, dim=-1)
-        pr = _r(torch.nan_to_num(pr))  # fully masked (padding) query rows
-        a = _r(pr @ vv).transpose(1, 2).reshape(B, S, -1)
+        a = _softmax_pv(sc, vv).transpose(1, 2).reshape(B, S, -1)     # (fully masked padding query rows -> 0)
         x = _r(x + _lin(a, P, pre + "self_attn.o_proj"))
         h = rms_norm(x, P[pre + "post_attention_layernorm.weight"], t.rms_norm_eps)
         h = _lin(_r(_r(F.silu(_lin(h, P, pre + "mlp.gate_proj"))) * _lin(h, P, pre + "mlp.up_proj")), P, pre + "mlp.down_proj")
         x = _r(x + h)
+        if hidden_states is not None:      # the residual stream after layer li (HF output_hidden_states[li + 1], the last one before the final norm)
+            hidden_states.append(x)
     x = rms_norm(x, P["model.norm.weight"], t.rms_norm_eps)
     return (x, new_kv) if return_kv else x
 

@@ -50,6 +50,15 @@ struct GemmArgs {
     float rs_in_scale = 0.f;                     // 2^-20 / (width of the normalised rows)
     float rs_eps = 0.f;
     unsigned long long* rs_out = nullptr;        // [M]: the output rows' sums of squares (of the bf16 values written) are ADDED here; null = off
+    // LayerNorm statistics out of the producer's epilogue (rga3_gemm_lnsum_bf16 / rga3_gemm_lnq_bf16; Hiera's MultiScaleBlock, reference sam2.py:1085-1117).  Kernels
+    // instantiated with LNM = 2 write, per output row and TILE COLUMN, (sum v, sum v^2) of the bf16 values that tile wrote: ln_parts [M][ntn][2] f32, plain stores
+    // (the waves of a workgroup combine through LDS in a fixed order: no atomics, nothing to zero, bitwise reproducible).  The LayerNorm-folded consumer (LNM = 1) adds
+    // the ln_ns partials of a row in f64 and derives (mean, 1 / sqrt(var + eps)) itself -- the stand-alone statistics pass over the rows (rga3_layernorm_stats)
+    // disappears.  (First form of this round: 64-bit fixed-point atomics per wave and row as rs_out does -- 1.6 M atomics per Hiera product cost more than the pass
+    // they replaced: DESIGN.md.)
+    float* ln_parts = nullptr;                   // producer: [M][ntn][2]
+    const float* ln_in = nullptr;                // consumer: [M][ln_ns][2]; 1 / width and eps travel in rs_in_scale / rs_eps
+    int ln_ns = 0;
     // Concatenated operands (rga3_gemm_cat_bf16, single-phase kernels only): LoRA's low-rank products folded into the frozen ones.
     //   K side:  C = [A | A2] . [W | W2]^T   -- K-tiles [0, K / 64) come from (A, W), the next K2 / 64 from (A2, W2)          (y = x W^T + t (sB)^T in one product)
     //   N side:  tile columns at or beyond N belong to a SECOND weight / output pair: Cn [M, N2] = A . Wn^T (no bias, residual or K side there)   ([dx | dt] = dy [W | sB])
@@ -152,11 +161,15 @@ __device__ __forceinline__ bool residual_stageable(const GemmArgs& p, int col0, 
 }
 
 // PARTS: part1 / part2 are read (stream-K owner slices); tab: this kernel's activation table in LDS (act_tab; GELU / SwiGLU epilogues only).
-template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32, bool LNF = false, bool PARTS = false>
+template <int MT, int NTL, int WTM, int WTN, int ACT, bool OUT_F32, int LNM = 0, bool PARTS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmArgs& p, char* est, const char* tab, int lane, int m0, int n0,
                                               int wm, int wn, const f32x4* part1 = nullptr, const f32x4* part2 = nullptr, const char* resl = nullptr,
-                                              float poison = 0.f) {
-    static_assert(!(LNF && ACT == ACT_SWIGLU), "the LayerNorm-folded epilogue has no SwiGLU form");
+                                              float poison = 0.f, int nwn = 1) {
+    // LNM: 0 plain, 1 = LNF, the LayerNorm-folded CONSUMER (rowstat / ln_in, colc), 2 = LayerNorm-sum PRODUCER (rs_out is an [M][2] pair array: rga3_gemm_lnsum_bf16).
+    // Compile-time, so the kernels of every other product keep the epilogue they had.
+    constexpr bool LNF = LNM == 1, LNP = LNM == 2;
+    static_assert(!(LNM != 0 && ACT == ACT_SWIGLU), "the LayerNorm-folded epilogues have no SwiGLU form");
+    static_assert(!(LNP && (OUT_F32 || PARTS)), "the LayerNorm-sum producer writes bf16 from the single-pass kernels");
     // part1 / part2 (stream-K owner slices only): this lane's view of up to two f32 partial-sum slabs in accumulator order
     // (quad (i, j) at [(i * NTL + j) * 64]).  They are added to the accumulators as those are READ, one m-tile ahead of use,
     // so the accumulator registers are never modified after the main loop (a post-loop "acc += slab" makes the register
@@ -232,10 +245,30 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
     float* const rs_lds = (float*)est;
     const unsigned tb = act_uses_table<ACT>() ? act_tab_base(tab) : 0u;
     if constexpr (LNF) {   // the same for the LayerNorm-folded products: (mean, 1 / std) of the wave's rows fetched up front, not one L2 round trip per m-tile in line
+        if (p.ln_in) {     // from the producer's per-tile-column partial sums: mean and variance in f64 (E[x^2] - mean^2 cancels; a handful of f64 operations per ROW)
+            const double sc = (double)p.rs_in_scale;
 #pragma unroll
-        for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
-            const int rl = lane + 64 * q;
-            if (rl < MT * 16) *(float2*)(rs_lds + 2 * rl) = *(const float2*)(p.rowstat + 2L * min(m0 + wm * WTM + rl, p.M - 1));
+            for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
+                const int rl = lane + 64 * q;
+                if (rl < MT * 16) {
+                    const float2* pp = (const float2*)p.ln_in + (long)min(m0 + wm * WTM + rl, p.M - 1) * p.ln_ns;
+                    double sx = 0.0, sxx = 0.0;
+                    for (int k = 0; k < p.ln_ns; ++k) {
+                        const float2 v = pp[k];
+                        sx += (double)v.x;
+                        sxx += (double)v.y;
+                    }
+                    const double mean = sx * sc;
+                    const double var = fmax(sxx * sc - mean * mean, 0.0);
+                    *(float2*)(rs_lds + 2 * rl) = make_float2((float)mean, __builtin_amdgcn_rsqf((float)var + p.rs_eps));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
+                const int rl = lane + 64 * q;
+                if (rl < MT * 16) *(float2*)(rs_lds + 2 * rl) = *(const float2*)(p.rowstat + 2L * min(m0 + wm * WTM + rl, p.M - 1));
+            }
         }
     }
     if (p.rs_in) {
@@ -366,7 +399,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 }
             }
         } else {
-            float rs_ss = 0.f;
+            float rs_ss = 0.f, rs_s = 0.f;
 #pragma unroll
             for (int jo = 0; jo + 1 < OUT_NT; jo += 2) {
                 const auto r0 = __builtin_amdgcn_permlane16_swap(pk[jo][0], pk[jo + 1][0], false, false);
@@ -400,11 +433,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                     } else {
                         for (int e = 0; e < 8 && col + e < Nout; ++e) dst[e] = (unsigned short)(val[e >> 1] >> (16 * (e & 1)));
                     }
-                    if (p.rs_out) {
+                    if (LNP || p.rs_out) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float v1 = (col + e < Nout) ? __uint_as_float((e & 1) ? (val[e >> 1] & 0xffff0000u) : (val[e >> 1] << 16)) : 0.f;
                             rs_ss = __builtin_fmaf(v1, v1, rs_ss);
+                            if constexpr (LNP) rs_s += v1;
                         }
                     }
                 }
@@ -432,16 +466,24 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
                 } else {
                     for (int e = 0; e < 4 && col + e < Nout; ++e) dst[e] = (unsigned short)(val[e >> 1] >> (16 * (e & 1)));
                 }
-                if (p.rs_out) {
+                if (LNP || p.rs_out) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v1 = (col + e < Nout) ? __uint_as_float((e & 1) ? (val[e >> 1] & 0xffff0000u) : (val[e >> 1] << 16)) : 0.f;
                         rs_ss = __builtin_fmaf(v1, v1, rs_ss);
+                        if constexpr (LNP) rs_s += v1;
                     }
                 }
             }
             }
-            if (p.rs_out) {
+            if constexpr (LNP) {
+                // the four lanes (g = 0..3) of a row hold different columns: one (sum, sum of squares) per row and wave, parked in the wave's epilogue bytes
+                rs_ss += __shfl_xor(rs_ss, 16, 64);
+                rs_ss += __shfl_xor(rs_ss, 32, 64);
+                rs_s += __shfl_xor(rs_s, 16, 64);
+                rs_s += __shfl_xor(rs_s, 32, 64);
+                if (g == 0) *(float2*)(rs_lds + 2 * (i * 16 + c)) = make_float2(rs_s, rs_ss);
+            } else if (p.rs_out) {
                 // the four lanes (g = 0..3) of a row hold different columns: one sum per row and wave, added as a fixed-point integer (order-free)
                 rs_ss += __shfl_xor(rs_ss, 16, 64);
                 rs_ss += __shfl_xor(rs_ss, 32, 64);
@@ -456,9 +498,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NTL], const GemmA
             }
         }
     }
+    if constexpr (LNP) {
+        // every wave of the workgroup has parked its rows' partial sums (wave id = wm * nwn + wn: the waves of one row block sit 1024 bytes apart); the wn = 0 wave
+        // of each row block adds them in wave order and writes ONE pair per row and tile column.  (Single-pass kernels: every wave runs this epilogue exactly once.)
+        __syncthreads();
+        if (wn == 0) {
+            const int tcol = n0 / (nwn * WTN);
+#pragma unroll
+            for (int q = 0; q < (MT * 16 + 63) / 64; ++q) {
+                const int rl = lane + 64 * q;
+                const int row = m0 + wm * WTM + rl;
+                if (rl < MT * 16 && row < p.M) {
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int w = 0; w < nwn; ++w) {
+                        const float2 v = *(const float2*)(est + w * 1024 + 8 * rl);
+                        s1 += v.x;
+                        s2 += v.y;
+                    }
+                    *(float2*)(p.ln_parts + 2 * ((long)row * p.ntn + tcol)) = make_float2(s1, s2);
+                }
+            }
+        }
+    }
 }
 
-template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE, bool LNF = false>
+template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE, int LNF = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int BK = 64;
@@ -680,7 +744,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
         }
     }
     gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + est_stage * STAGE + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + tab_stage * STAGE, lane, m0,
-                                                        n0, wm, wn, nullptr, nullptr, resl);
+                                                        n0, wm, wn, nullptr, nullptr, resl, 0.f, WN);
 }
 
 // =====================================================================================================================
@@ -702,7 +766,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmArgs p) {
 // N = 576 is 3 x 192 against 2.25 x 256: a quarter of the 256-wide tiles' MFMAs multiply padding).  A half-tile: 4 wave rows x 32 rows; B half-tile: 2 wave columns x 48
 // columns = 96 LDS rows of its 128-row region (waves 4-7 repeat the second staging piece of waves 0-3, as the 192-ROW form of the persistent kernel does, so that every
 // wave still issues two loads per half-tile); quadrant = 2 x 3 x 2 = 12 MFMAs.
-template <int ACT, bool OUT_F32, bool LNF = false, bool N192 = false>
+template <int ACT, bool OUT_F32, int LNF = 0, bool N192 = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = N192 ? 192 : 256, BK = 64, ROWB = 128;
     constexpr int HALF = 128 * ROWB;  // 16 KiB
@@ -882,7 +946,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs p) {
             resl = dst;
         }
     }
-    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + 2 * BUF, lane, m0, n0, wr, wc, nullptr, nullptr, resl);
+    gemm_epilogue<MT, NTL, WTM, WTN, ACT, OUT_F32, LNF>(acc, p, smem + wid * epi_wave_bytes<NTL, ACT, OUT_F32>(), smem + 2 * BUF, lane, m0, n0, wr, wc, nullptr, nullptr, resl, 0.f, WC);
 }
 
 // In-place accumulate (C-in register == C-out register).  The builtin lets the register allocator pick a different
@@ -1831,7 +1895,7 @@ static inline int sk_plain_slabs() {
 #endif
 }
 
-template <int ACT, bool OUT_F32, bool LNF = false, bool N192 = false>
+template <int ACT, bool OUT_F32, int LNF = 0, bool N192 = false>
 static int launch_pp(const GemmArgs& a0, hipStream_t st);
 
 // ---- run tables of the stream-K tail (SkArgs::start)
@@ -2036,7 +2100,7 @@ static int launch_splitk(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
-template <int ACT, bool OUT_F32, bool LNF, bool N192>
+template <int ACT, bool OUT_F32, int LNF, bool N192>
 static int launch_pp(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, 256);
@@ -2070,7 +2134,7 @@ static int launch_w4(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE, bool LNF = false>
+template <int BM, int BN, int WM, int WN, int ACT, bool OUT_F32, int PIPE, int LNF = 0>
 static int launch_cfg(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.ntm = (int)cdiv(a.M, BM);
@@ -2775,6 +2839,41 @@ extern "C" int rga3_gemm_rms_bf16(const void* A, const void* W, const void* bias
                           (const unsigned long long*)row_sumsq_in, norm_width, eps, (unsigned long long*)row_sumsq_out, stream);
 }
 
+// rga3_gemm_bf16 whose epilogue also leaves the LayerNorm statistics of the rows it writes (Hiera MultiScaleBlock: x = shortcut + proj(attn) feeds norm2, x = x + mlp(..)
+// feeds the next block's norm1; reference sam2.py:1085-1117): row_parts [M][slices][2] f32 with slices = rga3_gemm_lnsum_slices(N, tile) -- for row r and tile column
+// t, (sum, sum of squares) of the bf16 values this launch wrote to columns of that tile.  Plain stores, every element written once: nothing to zero, bitwise
+// reproducible.  bf16 output, no activation (proj / fc2 have none), tiles 3 / 5 / 12 / 13 / 20 / 23 (kernels of their own: LNM = 2).  Consumer: rga3_gemm_lnq_bf16.
+static int lnsum_tile_width(int tile) { return (tile == 3 || tile == 20) ? 256 : (tile == 5 || tile == 23) ? 192 : (tile == 13) ? 64 : 128; }
+extern "C" int64_t rga3_gemm_lnsum_slices(int64_t N, int tile) {
+    if (N <= 0 || !(tile == -1 || tile == 3 || tile == 5 || tile == 12 || tile == 13 || tile == 20 || tile == 23)) return -1;
+    return cdiv(N, lnsum_tile_width(tile));
+}
+extern "C" int rga3_gemm_lnsum_bf16(const void* A, const void* W, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                    int64_t ldw, int64_t ldc, int64_t ldr, int tile, float* row_parts, void* stream) {
+    RGA3_CHECK_ARG(A && W && C && row_parts && (((uintptr_t)row_parts) & 7) == 0, "gemm_lnsum: null pointer / row_parts must be 8-byte aligned");
+    RGA3_CHECK_ARG(M > 16 && N > 0 && K > 0 && K % 8 == 0, "gemm_lnsum: bad shape M=%ld N=%ld K=%ld (M > 16, K %% 8)", (long)M, (long)N, (long)K);
+    RGA3_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "gemm_lnsum: lda/ldw must be multiples of 8 elements (16-byte rows)");
+    RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0, "gemm_lnsum: pointers must be 16-byte aligned");
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || tile == 5 || tile == 12 || tile == 13 || tile == 20 || tile == 23, "gemm_lnsum: tile %d (3 / 5 / 12 / 13 / 20 / 23)", tile);
+    RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm_lnsum: operands must be < 2^32 elements (32-bit staging offsets)");
+    GemmArgs a;
+    a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.C = C;
+    a.bias = (const unsigned short*)bias; a.res = (const unsigned short*)residual; a.colscale = nullptr;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = nullptr; a.colc = nullptr;
+    a.ln_parts = row_parts;
+    hipStream_t st = (hipStream_t)stream;
+    switch (tile) {
+        case 3: return launch_cfg<128, 256, 2, 4, ACT_NONE, false, 0, 2>(a, st);
+        case 5: return launch_cfg<128, 192, 2, 4, ACT_NONE, false, 0, 2>(a, st);
+        case 13: return launch_cfg<64, 64, 2, 2, ACT_NONE, false, 0, 2>(a, st);
+        case 20: return launch_pp<ACT_NONE, false, 2, false>(a, st);
+        case 23: return launch_pp<ACT_NONE, false, 2, true>(a, st);
+        default: return launch_cfg<128, 128, 2, 2, ACT_NONE, false, 0, 2>(a, st);
+    }
+}
+
 // SwiGLU product that ALSO stores its bf16 pre-activations (training forward of the decoder MLP: the backward of silu(gate) * up needs gate and up; HF Qwen2MLP,
 // autograd under reference train_joint.py:534): C [M, N / 2] = silu(gate) * up as rga3_gemm_bf16 with RGA3_ACT_SWIGLU, pre [M, N] = the interleaved gate | up values
 // rounded to bf16 (what a plain rga3_gemm_bf16 on the same packed weight writes) -- the stand-alone SwiGLU launch (read 2 x, write 1 x the widest activation) disappears.
@@ -2897,6 +2996,31 @@ extern "C" int rga3_gemm_ln_bf16(const void* A, const void* Wf, const void* bias
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = 0;
     a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = rowstat; a.colc = colc;
+    hipStream_t st = (hipStream_t)stream;
+    if (act == ACT_GELU) return launch_ln<ACT_GELU>(a, tile, st);
+    if (act == ACT_RELU) return launch_ln<ACT_RELU>(a, tile, st);
+    return launch_ln<ACT_NONE>(a, tile, st);
+}
+
+// rga3_gemm_ln_bf16 reading the statistics as the producer's partial sums (rga3_gemm_lnsum_bf16) instead of (mean, 1 / std): row_parts [M][slices][2] f32, norm_width
+// = the width the sums were taken over (= K here), eps the LayerNorm's.  mean = S1 / w, var = S2 / w - mean^2 (f64 inside the kernel), biased variance as nn.LayerNorm.
+extern "C" int rga3_gemm_lnq_bf16(const void* A, const void* Wf, const void* bias, const float* colc, const float* row_parts, int64_t slices, int64_t norm_width,
+                                  float eps, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int act, int tile, void* stream) {
+    RGA3_CHECK_ARG(A && Wf && C && colc && row_parts, "gemm_lnq: null pointer");
+    RGA3_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0 && norm_width > 0 && eps >= 0.f && slices >= 1 && slices <= 4096,
+                   "gemm_lnq: bad shape M=%ld N=%ld K=%ld slices=%ld (K %% 8, N %% 4)", (long)M, (long)N, (long)K, (long)slices);
+    RGA3_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0, "gemm_lnq: lda/ldw must be multiples of 8 elements");
+    RGA3_CHECK_ARG((((uintptr_t)A | (uintptr_t)Wf | (uintptr_t)C | (uintptr_t)colc) & 15) == 0 && (((uintptr_t)row_parts) & 7) == 0, "gemm_lnq: pointer alignment");
+    RGA3_CHECK_ARG(act == ACT_NONE || act == ACT_GELU || act == ACT_RELU, "gemm_lnq: act %d", act);
+    RGA3_CHECK_ARG(tile == -1 || tile == 3 || (tile >= 5 && tile <= 7) || tile == 12 || tile == 13 || tile == 20, "gemm_lnq: tile %d", tile);
+    RGA3_CHECK_ARG(M * lda < (1LL << 32) && N * ldw < (1LL << 32), "gemm_lnq: operands must be < 2^32 elements");
+    GemmArgs a;
+    a.A = (const unsigned short*)A; a.W = (const unsigned short*)Wf; a.C = C;
+    a.bias = (const unsigned short*)bias; a.res = nullptr; a.colscale = nullptr;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = 0;
+    a.ws = nullptr; a.ws_bytes = 0; a.ksl = 0; a.rowstat = nullptr; a.colc = colc;
+    a.ln_in = row_parts; a.ln_ns = (int)slices; a.rs_in_scale = 1.0f / (float)norm_width; a.rs_eps = eps;
     hipStream_t st = (hipStream_t)stream;
     if (act == ACT_GELU) return launch_ln<ACT_GELU>(a, tile, st);
     if (act == ACT_RELU) return launch_ln<ACT_RELU>(a, tile, st);

@@ -32,6 +32,9 @@ SIGNATURES = {
     "rga3_layernorm_fwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _i, _p],
     "rga3_layernorm_stats": [_p, _p, _i64, _i64, _i64, _f, _p],
     "rga3_gemm_ln_bf16": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p],
+    "rga3_gemm_lnsum_slices": [_i64, _i],
+    "rga3_gemm_lnsum_bf16": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _p, _p],
+    "rga3_gemm_lnq_bf16": [_p, _p, _p, _p, _p, _i64, _i64, _f, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _p],
     "rga3_rope_inplace": [_p, _p, _p, _i64, _i, _i, _i, _i64, _i64, _p],
     "rga3_gather_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "rga3_scatter_rows": [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
@@ -106,7 +109,7 @@ SIGNATURES = {
     "rga3_bce_dice_grad_dev": [_p, _p, _p, _p, _i64, _i64, _p, _p, _p],
 }
 
-_INT64_RESULTS = ("rga3_hiera_mlp288_pack_bytes", "rga3_gemm_workspace_bytes", "rga3_memattn_cross_ws_floats", "rga3_gemm_timeout_counter_offset", "rga3_layernorm_bwd_ws_floats", "rga3_colsum_ws_floats", "rga3_mask_product_bwd_ws_floats", "rga3_bce_dice_sums_ws_floats")
+_INT64_RESULTS = ("rga3_gemm_lnsum_slices", "rga3_hiera_mlp288_pack_bytes", "rga3_gemm_workspace_bytes", "rga3_memattn_cross_ws_floats", "rga3_gemm_timeout_counter_offset", "rga3_layernorm_bwd_ws_floats", "rga3_colsum_ws_floats", "rga3_mask_product_bwd_ws_floats", "rga3_bce_dice_sums_ws_floats")
 
 _lib = None
 

@@ -65,6 +65,9 @@ def gemm_stream_k_timeouts(device=None) -> int:
     return tot
 
 
+_LNSUM_TILES = (20, 3, 5, 12, 13, 23)      # the tilings rga3_gemm_lnsum_bf16 has kernels for
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, residual=None, act: str = "none", out_dtype=torch.bfloat16,
          out=None, tile: int = -1, colscale=None, rms_in=None, rms_out=None) -> torch.Tensor:
     """out = residual + colscale * act(a @ w.T + bias).  a [M,K], w [N,K] (nn.Linear layout), bf16.
@@ -295,12 +298,59 @@ hiera_mlp144 = hiera_mlp      # the round-3 name (stage 1 only)
 _LN_TILES = (20, 3, 5, 12, 13)
 
 
+class LnSums:
+    """Row statistics as the PRODUCER's partial sums: t [M, slices, 2] f32 = (sum x, sum x^2) per row and tile column of the product that wrote the rows
+    (gemm_lnsum), eps of the LayerNorm that will consume them.  gemm_ln takes it in place of layernorm_stats' (mean, 1 / std)."""
+    __slots__ = ("t", "eps")
+
+    def __init__(self, t, eps):
+        self.t, self.eps = t, float(eps)
+
+
+def gemm_lnsum(a, w, bias=None, residual=None, tile: int = -1):
+    """(out, parts): out = residual + a @ w.T + bias as gemm(), parts [M, slices, 2] f32 = per row and tile column the (sum, sum of squares) of the bf16 values
+    written (rga3_gemm_lnsum_bf16) -- LnSums(parts, eps) is the statistics input of the gemm_ln that consumes `out`.  M > 16, bf16, no activation."""
+    _need_cuda(a, w, bias, residual)
+    assert a.dtype == w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    assert M > 16 and K % 8 == 0 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    L = _lib.load()
+    if tile == -1 and M * N * K >= (1 << 24):
+        ws = gemm_workspace(a.device)
+
+        def trial(t):      # the plain kernel of the same tiling (same main loop; the tuner only ranks tilings)
+            _lib.check(L.rga3_gemm_bf16(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), None, out.data_ptr(), M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr,
+                                        ACT["none"], BF16, t, ws.data_ptr(), ws.numel(), _stream()), "gemm_bf16")
+
+        cands = _LNSUM_TILES if (N % 192 == 0 and N % 256 != 0 and M >= 1024) else tuple(t for t in _LNSUM_TILES if t != 23)
+        tile = _tuner.pick(_tuner.key_of(M, N, K, "lnsum", BF16, bias is not None, residual is not None), trial, candidates=cands)
+    if tile not in _LNSUM_TILES:
+        tile = -1
+    ns = int(L.rga3_gemm_lnsum_slices(N, tile))
+    if ns < 1:
+        raise _lib.Rga3Error("rga3_gemm_lnsum_slices failed")
+    parts = torch.empty((M, ns, 2), dtype=torch.float32, device=a.device)
+    _lib.check(L.rga3_gemm_lnsum_bf16(a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr,
+                                      tile, parts.data_ptr(), _stream()), "gemm_lnsum_bf16")
+    return out, parts
+
+
 def gemm_ln(a, stats, wf, colc, biasf, act: str = "none", out=None, tile: int = -1):
-    """act(LayerNorm(a) @ W.T + b) with the LayerNorm folded into the product: a [M, K] UN-normalised bf16 rows, stats = layernorm_stats(a), (wf, colc, biasf) =
-    fold_layernorm(...).  The normalised activations are never materialised."""
+    """act(LayerNorm(a) @ W.T + b) with the LayerNorm folded into the product: a [M, K] UN-normalised bf16 rows, stats = layernorm_stats(a) or the LnSums the
+    producer of `a` left (rga3_gemm_lnq_bf16), (wf, colc, biasf) = fold_layernorm(...).  The normalised activations are never materialised."""
+    sums = stats if isinstance(stats, LnSums) else None
+    if sums is not None:
+        stats = sums.t
     _need_cuda(a, stats, wf, colc, biasf, out)
     assert a.dtype == wf.dtype == torch.bfloat16 and a.dim() == 2 and wf.dim() == 2 and a.shape[1] == wf.shape[1] and a.stride(1) == 1 and wf.is_contiguous()
-    assert stats.dtype == colc.dtype == torch.float32 and stats.shape == (a.shape[0], 2) and stats.is_contiguous() and colc.numel() == wf.shape[0]
+    assert stats.dtype == colc.dtype == torch.float32 and stats.is_contiguous() and colc.numel() == wf.shape[0]
+    assert (stats.dim() == 3 and stats.shape[0] == a.shape[0] and stats.shape[2] == 2) if sums is not None else stats.shape == (a.shape[0], 2)
     assert act in ("none", "gelu", "relu") and a.shape[1] % 8 == 0 and wf.shape[0] % 4 == 0
     M, K = a.shape
     N = wf.shape[0]
@@ -308,10 +358,15 @@ def gemm_ln(a, stats, wf, colc, biasf, act: str = "none", out=None, tile: int = 
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.bfloat16
     fn = _lib.load().rga3_gemm_ln_bf16
+    fnq = _lib.load().rga3_gemm_lnq_bf16
 
     def run(t):
-        _lib.check(fn(a.data_ptr(), wf.data_ptr(), _ptr(biasf), colc.data_ptr(), stats.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), wf.stride(0), out.stride(0),
-                      ACT[act], t, _stream()), "gemm_ln_bf16")
+        if sums is not None:
+            _lib.check(fnq(a.data_ptr(), wf.data_ptr(), _ptr(biasf), colc.data_ptr(), stats.data_ptr(), stats.shape[1], K, sums.eps, out.data_ptr(), M, N, K, a.stride(0),
+                           wf.stride(0), out.stride(0), ACT[act], t, _stream()), "gemm_lnq_bf16")
+        else:
+            _lib.check(fn(a.data_ptr(), wf.data_ptr(), _ptr(biasf), colc.data_ptr(), stats.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), wf.stride(0), out.stride(0),
+                          ACT[act], t, _stream()), "gemm_ln_bf16")
 
     if tile == -1 and M * N * K >= (1 << 24):
         tile = _tuner.pick(_tuner.key_of(M, N, K, "ln+" + act, BF16, biasf is not None, False), run, candidates=_LN_TILES)

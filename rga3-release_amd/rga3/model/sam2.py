@@ -38,6 +38,7 @@ _DECIMG = True    # mask decoder at inference: the image side of a two-way block
 _ROWCHAIN = True  # memory attention at inference: the row-wise steps between the attention kernels in one launch each (csrc/memlayer.hip)
 _MLP_FUSE = True  # stage-1 / stage-2 MLP of the frozen Hiera trunk as one launch (csrc/hiera_mlp.hip); tools/ flip it for A/B runs
 _MLP_FUSE_DIMS = (144, 288)
+_LN_SUMS = True   # ... and its row statistics taken from the epilogue of the product that wrote the rows (rga3_gemm_lnsum_bf16 -> rga3_gemm_lnq_bf16) instead of a pass over them
 _LN_FOLD = True   # LayerNorm of the frozen Hiera trunk folded into the consuming product (tools/ flip this module attribute for A/B runs; no environment switch)
 
 
@@ -188,19 +189,29 @@ class MultiScaleBlock(nn.Module):
             c = self._fold_cache[which] = (key, ops.fold_layernorm(lin.weight, lin.bias, norm.weight, norm.bias))
         return c[1]
 
-    def forward(self, x, Fn, H, W, layout_w):
-        """x [Fn*H*W, dim] in window-major(layout_w) order. Returns (x, H, W, layout_w)."""
+    def forward(self, x, Fn, H, W, layout_w, sums=None):
+        """x [Fn*H*W, dim] in window-major(layout_w) order. Returns (x, H, W, layout_w).
+        sums (frozen trunk only): a _SumsFeed -- `sums.of_x` holds the per-tile-column (sum, sum of squares) of the rows of x if the product that wrote x left them
+        (ops.gemm_lnsum); on return it holds those of the block's output (or None).  The LayerNorm statistics then never cost a pass over the rows."""
         ws = self.window
         if ws > 0 and (H % ws or W % ws):
             raise NotImplementedError("Hiera window padding (map not divisible by the window) is not on the RGA3 path (images are 1024x1024)")
         if ws > 0:
+            if layout_w != ws and sums is not None:
+                sums.of_x = None          # the rows move: the producer's per-row sums no longer line up
             x = relayout(x, Fn, H, W, layout_w, ws)
             layout_w = ws
         heads, do = self.attn.num_heads, self.dim_out
         # frozen trunk (no autograd): both LayerNorms are folded into the products that consume them -- a row-statistics pass (one read of x) and a
         # gamma-folded weight replace the LayerNorm pass (read + write) and the re-read of its output (rga3_gemm_ln_bf16)
         fold = _LN_FOLD and not _ag() and x.is_contiguous() and self.dim % 8 == 0
-        st1 = ops.layernorm_stats(x, self.norm1.eps) if fold else None
+        feed = sums if (fold and sums is not None and _LN_SUMS) else None
+        if feed is not None and feed.of_x is not None:
+            st1 = ops.LnSums(feed.of_x, self.norm1.eps)       # left by the previous block's fc2 epilogue
+        else:
+            st1 = ops.layernorm_stats(x, self.norm1.eps) if fold else None
+        if sums is not None:
+            sums.of_x = None
         h = None if fold else self.norm1(x)
         T = H * W
         nwin = Fn * (T // (ws * ws)) if ws > 0 else Fn
@@ -234,21 +245,38 @@ class MultiScaleBlock(nn.Module):
         else:   # max_k: windows of <= 256 keys take the whole-segment-in-LDS kernel
             att = ops.attn_varlen(qv, kv[:, heads:2 * heads], kv[:, 2 * heads:], _cu(nwin, seg_q, x.device), _cu(nwin, seg, x.device), seg_q,
                                   hd ** -0.5, causal=False, max_k=seg)
-        x = self.attn.proj(att.view(att.shape[0], do), residual=shortcut)
+        l0, l1 = self.mlp.layers[0], self.mlp.layers[1]
+        fused_mlp = (fold and _MLP_FUSE and self.dim_out in _MLP_FUSE_DIMS and l0.out_features == 4 * self.dim_out and self.mlp.num_layers == 2 and self.mlp.act == "gelu"
+                     and l0.bias is not None and l1.bias is not None)
+        # the two residual-writing products leave the statistics of the rows they write (rga3_gemm_lnsum_bf16): proj's feed norm2 -> fc1, fc2's the next block's norm1
+        lnq = feed is not None and not fused_mlp and self.dim_out % 8 == 0 and att.shape[0] > 16
+        pr = self.attn.proj
+        if lnq:
+            x, s2 = ops.gemm_lnsum(att.view(att.shape[0], do), pr.weight, pr.bias, residual=shortcut)
+        else:
+            x = pr(att.view(att.shape[0], do), residual=shortcut)
         if self.pool_q:
             H, W, layout_w = H // 2, W // 2, ws // 2
-        l0, l1 = self.mlp.layers[0], self.mlp.layers[1]
-        if (fold and _MLP_FUSE and self.dim_out in _MLP_FUSE_DIMS and l0.out_features == 4 * self.dim_out and self.mlp.num_layers == 2 and self.mlp.act == "gelu"
-                and l0.bias is not None and l1.bias is not None and x.is_contiguous()):
+        if fused_mlp and x.is_contiguous():
             # stage-1 / stage-2 MLP (144 -> 576 -> 144 over 65 536 tokens per frame, 288 -> 1152 -> 288 over 16 384) in one launch: the hidden activation and the
             # LayerNorm statistics never reach HBM
             x = ops.hiera_mlp(x, *self._folded("fc1"), l1.weight, l1.bias, self.norm2.eps)
+        elif lnq:
+            hmid = ops.gemm_ln(x, ops.LnSums(s2, self.norm2.eps), *self._folded("fc1"), act="gelu")
+            x, feed.of_x = ops.gemm_lnsum(hmid, l1.weight, l1.bias, residual=x)
         elif fold and self.dim_out % 8 == 0:
             hmid = ops.gemm_ln(x, ops.layernorm_stats(x, self.norm2.eps), *self._folded("fc1"), act="gelu")
             x = self.mlp.layers[1](hmid, residual=x)
         else:
             x = self.mlp(self.norm2(x), residual=x)
         return x, H, W, layout_w
+
+
+class _SumsFeed:
+    """`of_x`: the LayerNorm partial sums (ops.gemm_lnsum) of the rows currently flowing between two blocks of one frozen trunk pass, or None."""
+
+    def __init__(self):
+        self.of_x = None
 
 
 class Hiera(nn.Module):
@@ -298,8 +326,10 @@ class Hiera(nn.Module):
         x = ops.add_bcast(x, self.pos_tokens(H, W))
         layout = 0
         outs = []
+        # frozen pass: the blocks hand the LayerNorm statistics of their outputs forward
+        feed = _SumsFeed() if (not _ag() and _LN_SUMS and x.is_cuda) else None
         for i, blk in enumerate(self.blocks):
-            x, H, W, layout = blk(x, Fn, H, W, layout)
+            x, H, W, layout = blk(x, Fn, H, W, layout, feed)
             if i in self.stage_ends:
                 outs.append((x, H, W, layout))
         return outs

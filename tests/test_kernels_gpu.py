@@ -97,6 +97,53 @@ def test_gemm_layernorm_folded(dev, M, N, K, act, tile):
     assert _rel_l2(out, unf.float().cpu()) < 8e-3
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(4096, 576, 576, 5), (4096, 576, 2304, 23), (65536, 576, 2304, -1), (3000, 1152, 4608, 20), (2500, 1152, 1152, 3),
+                                        (1000, 144, 144, 13), (513, 264, 72, 12), (37, 192, 576, -1), (16389, 1152, 4608, -1)])
+def test_layernorm_sums_out_of_the_producer_epilogue(dev, M, N, K, tile):
+    """the residual-writing products of a Hiera block (x = shortcut + proj(attn), x = x + fc2(..); reference model/sam2.py:1085-1117) leave the
+    LayerNorm statistics of the rows they write -- rga3_gemm_lnsum_bf16: (sum v, sum v^2) per row and tile column, f32, plain stores -- and the
+    LayerNorm-folded consumer reads them (rga3_gemm_lnq_bf16) instead of the (mean, 1 / std) of a stand-alone pass over the rows (rga3_layernorm_stats).
+    (1) the product itself is bit-identical to the plain kernel of the same tiling; (2) the partial sums add up to those of the bf16 rows written (f32 accumulation)
+    and are bit-reproducible; (3) the consumer on the sums equals the consumer on layernorm_stats to bf16 rounding, and fp32 LayerNorm + linear to the
+    tolerance of test_gemm_layernorm_folded; rows with a common offset of several standard deviations exercise E[x^2] - mean^2 (formed in f64)."""
+    import torch.nn.functional as F
+    from rga3.hip import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * (K ** -0.5)).to(torch.bfloat16).to(dev)
+    b = (torch.randn(N, generator=g) * 0.2).to(torch.bfloat16).to(dev)
+    res = (torch.randn(M, N, generator=g) * 0.7 + torch.randn(M, 1, generator=g) * 3.0).to(torch.bfloat16).to(dev)      # offset rows: |mean| ~ 3 sigma
+    out, parts = ops.gemm_lnsum(a, w, b, residual=res, tile=tile)
+    plain = ops.gemm(a, w, b, residual=res, tile=tile if tile != -1 else 12)
+    if tile != -1:
+        assert torch.equal(out, plain)
+    else:
+        assert _rel_l2(out, plain.float().cpu()) < 1e-2
+    assert parts.dim() == 3 and parts.shape[0] == M and parts.shape[2] == 2
+    of = out.double().cpu()
+    s1, s2 = parts[:, :, 0].double().sum(1).cpu(), parts[:, :, 1].double().sum(1).cpu()     # f32 partials per tile column, summed exactly here
+    assert float((s1 - of.sum(1)).abs().max()) <= 2e-5 * float(of.abs().sum(1).max())
+    assert float((s2 - (of * of).sum(1)).abs().max()) <= 2e-5 * float((of * of).sum(1).max())
+    out_b, parts_b = ops.gemm_lnsum(a, w, b, residual=res, tile=tile)
+    assert torch.equal(out, out_b) and torch.equal(parts, parts_b)                  # no atomics: fixed combination order, the same bits
+    sums = parts
+    # consumer
+    N2 = 3 * N if N % 8 == 0 else 64
+    w2 = (torch.randn(N2, N, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    b2 = (torch.randn(N2, generator=g) * 0.2).to(torch.bfloat16).to(dev)
+    gamma = (1 + 0.2 * torch.randn(N, generator=g)).to(torch.bfloat16).to(dev)
+    beta = (0.1 * torch.randn(N, generator=g)).to(torch.bfloat16).to(dev)
+    wf, colc, bf = ops.fold_layernorm(w2, b2, gamma, beta)
+    for act in ("none", "gelu"):
+        y_q = ops.gemm_ln(out, ops.LnSums(sums, 1e-6), wf, colc, bf, act=act)
+        y_s = ops.gemm_ln(out, ops.layernorm_stats(out, 1e-6), wf, colc, bf, act=act)
+        ref = F.layer_norm(out.float().cpu(), (N,), gamma.float().cpu(), beta.float().cpu(), 1e-6) @ w2.float().cpu().t() + b2.float().cpu()
+        ref = F.gelu(ref) if act == "gelu" else ref
+        assert _rel_l2(y_q, y_s.float().cpu()) < 3e-3, (M, N, K, act)
+        assert _rel_l2(y_q, ref) < 8e-3, (M, N, K, act)
+
+
 def test_gemm_stream_k_split_shapes(dev):
     """Tiles 22 / 32 (256- / 192-row stream-K) on shapes whose last round is split over K (1, 2 contributors per tile, ragged M): equal to the unsplit result up to
     the f32 re-association of the split tiles, reproducible run to run, and no slab wait ever timed out."""

@@ -72,3 +72,115 @@ def test_full_forward_and_loss(gold):
     assert np.abs(r["hidden"].numpy() - gold["full_hidden_last"])[am].max() < 2e-4
     assert np.abs(r["logits"].numpy() - gold["full_logits"])[am].max() < 2e-4
     assert abs(float(r["loss"]) - float(gold["full_loss"])) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------
+# The bf16-STORAGE mode of the oracle (oracle.qwen25vl.storage), pinned to transformers' own bf16 run.  The full-depth GPU test
+# (tests/test_fulldepth_parity_gpu.py) states its bound against what bf16 storage costs the fp32 restatement; that yardstick must be reference-derived, not
+# builder-defined.  Fixture: tests/golden/qwen_mid_bf16.npz -- the installed transformers Qwen2.5-VL at a mid size (8 ViT blocks d = 256, 12 decoder layers d = 512,
+# conditioned random weights) run on the CPU in bf16 and, same weights, in fp32 (tests/golden/make_qwen_mid_bf16_fixtures.py).
+@pytest.fixture(scope="module")
+def mid():
+    from tests import qwen_mid as QM
+
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    g = QM.gold()
+    P, cfg, px = QM.params(g), QM.oracle_cfg(), QM.pixel_values(g)
+    ids = torch.from_numpy(g["input_ids"])
+    am, pos = torch.ones_like(ids), torch.from_numpy(g["position_ids"])
+
+    def run():
+        with torch.no_grad():
+            e = Q.vit_forward(P, px, g["grid"], cfg)
+            x = P["model.embed_tokens.weight"][ids]
+            x[ids == QM.VIDEO_TOKEN] = e
+            hs = []
+            hid = Q.llm_forward(P, x, pos, am, cfg, hidden_states=hs)[0]
+            lg = hid @ P["lm_head.weight"].t()
+        return {"vit": e, "hidden4": hs[4][0], "hidden8": hs[8][0], "hidden12": hid, "logits_tail": lg[-32:]}
+
+    o32 = run()
+    with Q.storage(torch.bfloat16):
+        o16 = run()
+        o16["logits_tail"] = Q._r(o16["logits_tail"])
+    return {"g": g, "P": P, "px": px, "am": am, "pos": pos, "o32": o32, "o16": o16, "QM": QM}
+
+
+POINTS = ("vit", "hidden4", "hidden8", "hidden12", "logits_tail")
+
+
+def test_mid_size_fp32_restatement_equals_transformers_fp32(mid):
+    g, QM = mid["g"], mid["QM"]
+    for k in POINTS:
+        assert QM.rel(mid["o32"][k], g[k + "_fp32"]) < 2e-6, k
+
+
+def test_bf16_storage_mode_one_block_at_a_time_against_transformers_bf16(mid):
+    """Teacher-forced: every pinned block / layer of transformers' bf16 run is re-run by the oracle ON THAT RUN'S OWN INPUT.  In storage mode the output must equal
+    the stored bf16 output up to rounding flips of differently-ordered fp32 sums (measured 2.1 - 2.6e-4 for a ViT block, 5.2 - 5.4e-4 for a decoder layer); in
+    plain fp32 mode the same block sits 2.3e-3 away -- the roundings are where transformers puts them, not merely of the right size.  (The conditioned random weights
+    give near-uniform attention, so THIS check does not see how the probabilities are rounded: test_storage_attention_core_rounds_like_the_fused_kernel does.)"""
+    g, QM, P, px = mid["g"], mid["QM"], mid["P"], mid["px"]
+    U = QM.unbits
+    for k in g["vit_pins"]:
+        xin, xout = U(g[f"pin_vit{k}_in"]), U(g[f"pin_vit{k}_out"])
+        with torch.no_grad():
+            tr = []
+            Q.vit_forward(P, px, g["grid"], QM.oracle_cfg(), trace=tr, blocks=[int(k)], x_start=xin)
+            with Q.storage(torch.bfloat16):
+                tr16 = []
+                Q.vit_forward(P, px, g["grid"], QM.oracle_cfg(), trace=tr16, blocks=[int(k)], x_start=xin)
+        assert QM.rel(tr16[1], xout) < 4e-4, (int(k), QM.rel(tr16[1], xout))
+        assert QM.rel(tr[1], xout) > 1.5e-3                                    # fp32 arithmetic is NOT what the bf16 run computes
+    for k in g["llm_pins"]:
+        xin, xout = U(g[f"pin_llm{k}_in"]), U(g[f"pin_llm{k}_out"])
+        Pk, c1 = QM.layer_params(P, int(k)), QM.oracle_cfg(layers=1)
+        with torch.no_grad():
+            hs = []
+            Q.llm_forward(Pk, xin[None], mid["pos"], mid["am"], c1, hidden_states=hs)
+            with Q.storage(torch.bfloat16):
+                hs16 = []
+                Q.llm_forward(Pk, xin[None], mid["pos"], mid["am"], c1, hidden_states=hs16)
+        assert QM.rel(hs16[1][0], xout) < 8e-4, (int(k), QM.rel(hs16[1][0], xout))
+        assert QM.rel(hs[1][0], xout) > 1.5e-3
+
+
+def test_bf16_storage_yardstick_equals_what_transformers_bf16_costs(mid):
+    """End to end (20 blocks): the distance between the oracle's storage mode and its fp32 mode -- the YARDSTICK of the full-depth GPU test -- equals the distance
+    between transformers' bf16 and fp32 runs at every recorded depth to 2 % (measured: 8.06 / 8.05e-3 at the ViT output, 5.64 / 5.63, 7.39 / 7.39, 11.05 / 10.98e-3
+    along the decoder, 8.61 / 8.59e-3 on the logits), and the two bf16 runs themselves are 0.36 - 0.57 of a yardstick apart: same rounding points, and from the
+    first flipped rounding on, later roundings of slightly different values decorrelate (independent noise of equal size would sit at 1.41)."""
+    g, QM = mid["g"], mid["QM"]
+    for k in POINTS:
+        hf16, hf32 = QM.unbits(g[k + "_bf16"]), torch.from_numpy(g[k + "_fp32"])
+        y_hf, y_or = QM.rel(hf16, hf32), QM.rel(mid["o16"][k], mid["o32"][k])
+        assert abs(y_or / y_hf - 1.0) < 0.02, (k, y_or, y_hf)
+        assert QM.rel(mid["o16"][k], hf16) < 0.7 * y_hf, (k, QM.rel(mid["o16"][k], hf16), y_hf)
+    # the yardstick grows like a random walk over the decoder (sqrt of the depth), not linearly: what the GPU test's growth check relies on
+    y4, y8, y12 = (QM.rel(mid["o16"][k], mid["o32"][k]) for k in ("hidden4", "hidden8", "hidden12"))
+    assert y8 / y4 < (8 / 4) ** 0.5 * 1.1 and y4 < y8
+
+
+def test_storage_attention_core_rounds_like_the_fused_kernel():
+    """softmax(S) V inside a fused attention kernel (flash-attn 2 on the reference's GPUs, train_joint.py:181; torch's CPU flash kernel behind
+    attn_implementation="sdpa"; this build's HIP kernels): the UN-normalised exponentials are rounded to bf16 for the second product, the row sums stay fp32, one
+    rounding of the output.  On peaked scores the oracle's storage mode must sit on torch's bf16 kernel (measured 6 - 7e-4: the kernel's fast exponential flips
+    a few roundings) and the normalise-then-round form (eager attention) must not (2.9e-3)."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(0)
+    for L, causal in ((64, False), (304, True)):
+        q, k, v = (torch.randn(1, 4, L, 64, generator=g).to(torch.bfloat16) for _ in range(3))
+        q = q * 2
+        ref = F.scaled_dot_product_attention(q, k, v, is_causal=causal).float()
+        s = q.float() @ k.float().transpose(2, 3) * 64 ** -0.5
+        if causal:
+            s = s + torch.full((L, L), float("-inf")).triu(1)
+        with Q.storage(torch.bfloat16):
+            got = Q._softmax_pv(s, v.float())
+            eager = Q._r(Q._r(torch.softmax(s, -1)) @ v.float())
+        plain = Q._softmax_pv(s, v.float())
+        r = lambda a, b: float((a - b).norm() / b.norm())
+        assert r(got, ref) < 1.2e-3, r(got, ref)
+        assert r(eager, ref) > 2e-3 and r(eager, ref) > 2.5 * r(got, ref)
+        assert r(plain, ref) > 1.2e-3                                              # fp32 mode: no rounding at all

@@ -16,6 +16,18 @@ with torch.no_grad():
     for _ in range(it): m.sam2_model.forward_image(x)
     torch.cuda.synchronize()
     print(f"{(time.perf_counter()-t0)/it*1e3:.1f} ms per {NF} frames")
+    # A/B in one process (boards differ by +-2 %): module switches named in AB="_LN_SUMS,_MLP_FUSE" are turned off one at a time, interleaved with the default
+    import rga3.model.sam2 as S2
+    def timed():
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(it): m.sam2_model.forward_image(x)
+        torch.cuda.synchronize(); return (time.perf_counter() - t1) / it * 1e3
+    for name in [n for n in os.environ.get("AB", "").split(",") if n]:
+        res = {"on": [], "off": []}
+        for _ in range(3):
+            res["on"].append(timed())
+            setattr(S2, name, False); m.sam2_model.forward_image(x); res["off"].append(timed()); setattr(S2, name, True); m.sam2_model.forward_image(x)
+        print(f"A/B {name}: on {min(res['on']):.2f} ms  off {min(res['off']):.2f} ms   (min of 3 x {it}, {NF} frames)")
 from rga3.hip import tuner
 for k, v in tuner.timings().items():
     Mb, N, K = k[0], k[1], k[2]
