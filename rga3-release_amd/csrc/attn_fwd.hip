@@ -354,9 +354,9 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
 // LDS rows are D padded to an ODD number of 16-byte chunks (72 -> 144 B, 80 -> 176 B): the 16 rows a quarter-wave reads then start in 16 different
 // 4-bank groups, and a 256-key window of 72-d heads takes 2 x 36 KiB, so two workgroups share a CU.  Fragment reads of the padded d range (D..DP) run
 // into the next row: finite numbers that meet Q's zero padding (scores) or land in output columns >= D that are never stored.
-template <int DP, int NW, int QT, bool ROPE = false>
-__global__ __launch_bounds__(64 * NW, (QT == 1 ? 16 : 8) / NW) void attn_win_kernel(AttnArgs p) {
-    constexpr int NT = 64 * NW, BLOCK_M = 16 * QT * NW, DS = DP / 32, DT = DP / 16;
+template <int DP, int NW, int QT, bool ROPE = false, int DTO = DP / 16>   // DTO: 16-column tiles of the OUTPUT (D = 72 needs 5 of the 6 that DP = 96 spans)
+__global__ __launch_bounds__(64 * NW, (QT == 1 ? 16 : (NW == 8 ? 32 : 8)) / NW) void attn_win_kernel(AttnArgs p) {
+    constexpr int NT = 64 * NW, BLOCK_M = 16 * QT * NW, DS = DP / 32, DT = DTO;
     constexpr int LDMAX = (256 * (DP / 8 + 1) + 511) / 512;   // 16-byte chunks per thread, operand and staging pass (8 waves: the largest segment in one pass)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -635,12 +635,12 @@ static int launch_rope_win(const AttnArgs& a, int nseg, hipStream_t st) {
     return 0;
 }
 
-template <int DP, int NW, int QT, bool ROPE = false>
+template <int DP, int NW, int QT, bool ROPE = false, int DTO = DP / 16>
 static int launch_win(const AttnArgs& a, int nseg, int max_q, int max_k, hipStream_t st) {
     const int chr = (((a.D * 2 + 15) >> 4) | 1);
     const int nrows = (max_k + 63) & ~63;
     const int lds = 2 * nrows * chr * 16 + 256;
-    auto kern = attn_win_kernel<DP, NW, QT, ROPE>;
+    auto kern = attn_win_kernel<DP, NW, QT, ROPE, DTO>;
     static LdsGrant lds_grant;   // per device, grows monotonically; a racing second setter only repeats the call
     if (int rc = grant_dyn_lds((const void*)kern, lds, lds_grant, "attn")) return rc;
     AttnArgs b = a;
@@ -703,7 +703,8 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
-    RGA3_CHECK_ARG(impl >= 0 && impl <= 7, "attn: impl %d", impl);
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 15, "attn: impl %d", impl);
+    const bool win_q16 = (impl & 8) != 0;       // A/B switch: 256-query windows on the 16-rows-per-wave form (two workgroups per window and head)
     g_attn_variant = (impl & 2) ? 1 : 0;
     const bool no_causal32 = (impl & 4) != 0;   // A/B and parity switch: keep the long causal rows on the general kernel
     impl &= 1;
@@ -745,6 +746,13 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
         (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0) {
         // (4 waves x 32 rows per 256-token window -- half the fragment reads per row, one wave fewer per SIMD -- measured slower: 129 vs 112 us)
         if (max_q <= 64) return (D <= 64) ? launch_win<64, 4, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 4, 1>(a, nseg, max_q, max_k, st);
+        // 256-query windows at D > 64 (Hiera stage 3: 16 x 16 tokens, 8 heads x 72): ONE 8-wave workgroup per window and head, 32 query rows per wave -- K / V of the
+        // window are fetched and staged once instead of twice, and every K / V fragment read from LDS feeds two MFMAs (the 16-row form is bound by the LDS array:
+        // 96 KiB of fragment reads per wave against 1 536 MFMA cycles, four waves per SIMD): 118 -> 93 us per stage-3 block of 16 frames.  (A PERSISTENT form --
+        // one workgroup per CU walking (window, head) items with the next item's K | V images arriving by LDS-DMA into a second LDS buffer while this one is
+        // multiplied, all loads and the counted wait in one inline-asm statement -- was built, bit-checked and measured at 122 us: with one workgroup per CU an
+        // item's 72 KiB take ~13 us to arrive, two independent workgroups per CU keep twice the bytes in flight; profiles/r06_hiera_attn_probe.log)
+        if (D > 64 && max_q > 128 && !win_q16) return (D <= 80) ? launch_win<96, 8, 2, false, 5>(a, nseg, max_q, max_k, st) : launch_win<96, 8, 2>(a, nseg, max_q, max_k, st);
         return (D <= 64) ? launch_win<64, 8, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 8, 1>(a, nseg, max_q, max_k, st);
     }
     if (impl == 0) return launch_any<true>(a, nseg, max_q, st);

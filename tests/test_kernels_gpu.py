@@ -721,6 +721,33 @@ def test_attn_window_kernel(dev, lq, lk, Hq, Hkv, D, block):
     assert float((lse.float().cpu() - rlse).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("nwin,H,qscale", [(6, 8, 0.8), (70, 8, 0.8), (33, 3, 6.0), (300, 8, 2.0)])
+def test_attn_window256_rows32(dev, nwin, H, qscale):
+    """Hiera-L stage-3 windows (16 x 16 tokens, heads of 72; reference model/sam2.py:986-1033): 256-query windows at D > 64 run ONE 8-wave workgroup per window and
+    head with 32 query rows per wave (attn_win_kernel<96, 8, 2, false, 5>: each K / V fragment read from LDS feeds two MFMAs, the output spans 5 of the 6 sixteen-column
+    tiles).  Against the softmax oracle, against the 16-row form (impl 8), with the log-sum-exp, peaked scores (running-max rescale in every tile); bit-reproducible."""
+    from rga3.hip import ops
+
+    D, T = 72, 256 * nwin
+    buf = _rand((T, 3 * H, D), dev, 0.8, seed=nwin)
+    q, k, v = (buf[:, :H] * qscale).to(torch.bfloat16), buf[:, H:2 * H], buf[:, 2 * H:]
+    qkv = torch.cat([q, k, v], 1).contiguous()                      # packed rows, as the model hands them over
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    cu = torch.arange(0, T + 1, 256, dtype=torch.int32)
+    cud = cu.to(dev)
+    scale = D ** -0.5
+    out, lse = ops.attn_varlen(q, k, v, cud, cud, 256, scale, causal=False, return_lse=True, max_k=256)
+    again = ops.attn_varlen(q, k, v, cud, cud, 256, scale, causal=False, max_k=256)
+    assert torch.equal(out, again)
+    o16 = ops.attn_varlen(q, k, v, cud, cud, 256, scale, causal=False, max_k=256, impl=8)
+    assert _rel_l2(out, o16.float().cpu()) < 4e-3
+    n = min(nwin, 40)                                                # the oracle on the first and the last windows
+    for sl in (slice(0, 256 * n), slice(T - 256 * n, T)):
+        ref, rlse = R.attn_varlen_ref(q[sl].cpu(), k[sl].cpu(), v[sl].cpu(), cu[:n + 1], cu[:n + 1], scale, False)
+        assert _rel_l2(out[sl], ref) < 8e-3
+        assert float((lse[:, sl].float().cpu() - rlse).abs().max()) < 2e-2
+
+
 def test_attn_forced_rescale(dev):
     """Spike one key so the running max jumps at a later tile (exercises the alpha rescale path)."""
     from rga3.hip import ops

@@ -41,6 +41,8 @@ def main():
             out = torch.empty(N, heads, hd, dtype=torch.bfloat16, device=dev)
             us = t_us(lambda: ops.attn_varlen(kv[:, :heads], kv[:, heads:2 * heads], kv[:, 2 * heads:], cu, cu, seg, hd ** -0.5, causal=False, out=out, max_k=seg))
             print(f"{label:24s} packed qkv  window kernel: {us:8.1f} us  {fl / us / 1e6:6.0f} TF/s", flush=True)
+            us = t_us(lambda: ops.attn_varlen(kv[:, :heads], kv[:, heads:2 * heads], kv[:, 2 * heads:], cu, cu, seg, hd ** -0.5, causal=False, out=out, max_k=seg, impl=8))
+            print(f"{label:24s} packed qkv  window kernel, 16 rows per wave (impl=8): {us:8.1f} us  {fl / us / 1e6:6.0f} TF/s", flush=True)
         q, k, v = (kv[:, i * heads:(i + 1) * heads].contiguous() for i in range(3))
         out = torch.empty(N, heads, hd, dtype=torch.bfloat16, device=dev)
         us = t_us(lambda: ops.attn_varlen(q, k, v, cu, cu, seg, hd ** -0.5, causal=False, out=out))
