@@ -241,6 +241,9 @@ class GemmTimer:
         return out
 
 
+PROFILE_ROUND = "r06"      # the counter profiles bench.py quotes: profiles/<round>_bench_<tag>_<family>_traffic.json, profiles/<round>_pmc_pipe_util.json
+
+
 def _tree():
     from rga3.utils.fingerprint import tree_fingerprint
     return tree_fingerprint()
@@ -251,7 +254,7 @@ def _traffic(tag, family="gemm"):
     FETCH_SIZE / WRITE_SIZE collection of this same command, summarised by tools/pmc_traffic.py -- and ONLY from a collection made on THIS tree: the profile records
     the fingerprint of the kernel sources + package it was measured on (rga3.utils.fingerprint), and a profile of another tree is refused.
     -> (bytes per launch or None, source text, stale flag)."""
-    path = os.path.join(ROOT, "profiles", f"r05_bench_{tag}_{family}_traffic.json")
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_bench_{tag}_{family}_traffic.json")
     if not os.path.exists(path):
         return None, None, False
     tj = json.load(open(path))
@@ -273,18 +276,19 @@ def _put_traffic(roof, tag, family="gemm"):
 
 def _mfma_busy(*needles):
     """Matrix-pipe utilisation of the shipped kernels (SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs)) cannot be sampled inside the timed run either: it
-    comes from the committed rocprofv3 --pmc passes over tools/pmc_pipe_util.py (each kernel at its bench shape), profiles/r05_pmc_pipe_util.json -- same tree only."""
-    path = os.path.join(ROOT, "profiles", "r05_pmc_pipe_util.json")
+    comes from the committed rocprofv3 --pmc passes over tools/pmc_pipe_util.py (each kernel at its bench shape), profiles/<round>_pmc_pipe_util.json -- same tree only."""
+    name = f"{PROFILE_ROUND}_pmc_pipe_util.json"
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, None
     pj = json.load(open(path))
     if pj.get("_tree") != _tree():
-        return None, f"profiles/r05_pmc_pipe_util.json REFUSED: collected on tree {pj.get('_tree')}, running tree is {_tree()}"
+        return None, f"profiles/{name} REFUSED: collected on tree {pj.get('_tree')}, running tree is {_tree()}"
     out = {}
     for k, v in pj.items():
         if isinstance(v, dict) and "mfma_busy" in v and (not needles or any(n in k for n in needles)):
             out[k] = v["mfma_busy"]
-    return (out or None), f"profiles/r05_pmc_pipe_util.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE passes over tools/pmc_pipe_util.py on tree {pj['_tree']}, per kernel at its bench shape)"
+    return (out or None), f"profiles/{name} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE passes over tools/pmc_pipe_util.py on tree {pj['_tree']}, per kernel at its bench shape)"
 
 
 # ------------------------------------------------------------------------------------------------ cpu baseline (oracle "port")

@@ -350,6 +350,10 @@ int rga3_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const vo
  * the mask is a counter hash of (seed, element index), so a recompute with the same seed reproduces it.  nn.Dropout(lora_dropout) on the
  * LoRA branch input (PEFT LoraLayer; reference train_joint.py:193-232) and its backward (accumulate = 1 into the input gradient). */
 int rga3_dropout_bf16(const void* x, void* y, int64_t n, float p, int64_t seed, int accumulate, void* stream);
+/* The pair form for a decoder layer's two LoRA branches (q_proj and v_proj drop the SAME normed input with two masks, and their input gradients meet in one
+ * buffer; PEFT LoraLayer under reference train_joint.py:193-232): sum == 0: ya = dropout_a(xa), yb = dropout_b(xb) (xa may equal xb: read once);
+ * sum == 1: ya += dropout_a(xa) + dropout_b(xb) with one bf16 rounding (yb unused).  Masks bit-identical to rga3_dropout_bf16's for the same (seed, index). */
+int rga3_dropout_pair_bf16(const void* xa, const void* xb, void* ya, void* yb, int64_t n, float pa, int64_t seed_a, float pb, int64_t seed_b, int sum, void* stream);
 /* a [T, I] = silu(gate) * up from the interleaved [T, 2I] pre-activations of RGA3_ACT_SWIGLU's weight packing (un-fused form, used after rga3_gemm_fp8) */
 int rga3_swiglu_fwd(const void* gu, void* a, int64_t T, int64_t I, void* stream);
 /* backward of silu(gate)*up on the interleaved [T, 2I] pre-activation layout of RGA3_ACT_SWIGLU: dgu from da [T, I] */

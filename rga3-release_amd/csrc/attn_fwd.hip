@@ -745,7 +745,8 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
     if (impl == 0 && g_attn_variant == 0 && !causal && a.nsplit == 1 && max_k > 0 && max_k <= 256 && D <= 96 && D % 8 == 0 &&
         (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && q_st % 8 == 0 && q_sh % 8 == 0 && k_st % 8 == 0 && k_sh % 8 == 0 && v_st % 8 == 0 && v_sh % 8 == 0) {
         // (4 waves x 32 rows per 256-token window -- half the fragment reads per row, one wave fewer per SIMD -- measured slower: 129 vs 112 us)
-        if (max_q <= 64) return (D <= 64) ? launch_win<64, 4, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 4, 1>(a, nseg, max_q, max_k, st);
+        // (64 < D <= 80 -- Hiera's 72, the ViT's 80 -- spans 5 of the 6 sixteen-column output tiles of DP = 96: a sixth of the P V work and of the V fragment reads)
+        if (max_q <= 64) return (D <= 64) ? launch_win<64, 4, 1>(a, nseg, max_q, max_k, st) : (D <= 80) ? launch_win<96, 4, 1, false, 5>(a, nseg, max_q, max_k, st) : launch_win<96, 4, 1>(a, nseg, max_q, max_k, st);
         // 256-query windows at D > 64 (Hiera stage 3: 16 x 16 tokens, 8 heads x 72): ONE 8-wave workgroup per window and head, 32 query rows per wave -- K / V of the
         // window are fetched and staged once instead of twice, and every K / V fragment read from LDS feeds two MFMAs (the 16-row form is bound by the LDS array:
         // 96 KiB of fragment reads per wave against 1 536 MFMA cycles, four waves per SIMD): 118 -> 93 us per stage-3 block of 16 frames.  (A PERSISTENT form --
@@ -753,7 +754,7 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
         // multiplied, all loads and the counted wait in one inline-asm statement -- was built, bit-checked and measured at 122 us: with one workgroup per CU an
         // item's 72 KiB take ~13 us to arrive, two independent workgroups per CU keep twice the bytes in flight; profiles/r06_hiera_attn_probe.log)
         if (D > 64 && max_q > 128 && !win_q16) return (D <= 80) ? launch_win<96, 8, 2, false, 5>(a, nseg, max_q, max_k, st) : launch_win<96, 8, 2>(a, nseg, max_q, max_k, st);
-        return (D <= 64) ? launch_win<64, 8, 1>(a, nseg, max_q, max_k, st) : launch_win<96, 8, 1>(a, nseg, max_q, max_k, st);
+        return (D <= 64) ? launch_win<64, 8, 1>(a, nseg, max_q, max_k, st) : (D <= 80) ? launch_win<96, 8, 1, false, 5>(a, nseg, max_q, max_k, st) : launch_win<96, 8, 1>(a, nseg, max_q, max_k, st);
     }
     if (impl == 0) return launch_any<true>(a, nseg, max_q, st);
     return launch_any<false>(a, nseg, max_q, st);
@@ -793,7 +794,7 @@ extern "C" int rga3_attn_varlen_fwd_rope(const void* q, const void* k, const voi
     constexpr bool old_rope = false;
 #endif
     if (!old_rope && !causal && cu_q == cu_k && D <= 96 && D % 8 == 0)   // self-attention windows: key range = query range <= 64
-        return (D <= 64) ? launch_win<64, 4, 1, true>(a, nseg, max_q, max_q, st) : launch_win<96, 4, 1, true>(a, nseg, max_q, max_q, st);
+        return (D <= 64) ? launch_win<64, 4, 1, true>(a, nseg, max_q, max_q, st) : (D <= 80) ? launch_win<96, 4, 1, true, 5>(a, nseg, max_q, max_q, st) : launch_win<96, 4, 1, true>(a, nseg, max_q, max_q, st);
     if (D <= 32) return launch_rope_win<32>(a, nseg, st);
     if (D <= 64) return launch_rope_win<64>(a, nseg, st);
     if (D <= 96) return launch_rope_win<96>(a, nseg, st);

@@ -376,6 +376,38 @@ __global__ __launch_bounds__(256) void dropout_kernel(const unsigned short* __re
     }
 }
 
+// The two LoRA branches of a decoder layer (q_proj, v_proj: reference train_joint.py:199-212) drop the SAME input with two masks, and their gradients meet in the
+// same dh1: one launch for the pair.  sum == 0: ya = drop_a(xa), yb = drop_b(xb) (xa == xb in the forward: read once).  sum == 1: ya += drop_a(xa) + drop_b(xb)
+// with ONE rounding (yb unused).  Masks exactly as dropout_kernel's.
+__global__ __launch_bounds__(256) void dropout_pair_kernel(const unsigned short* __restrict__ xa, const unsigned short* __restrict__ xb, unsigned short* ya,
+                                                           unsigned short* yb, long n8, unsigned thr_a, float ik_a, unsigned long long seed_a, unsigned thr_b,
+                                                           float ik_b, unsigned long long seed_b, int sum) {
+    const bool same = xa == xb;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n8; g += (long)gridDim.x * 256) {
+        const u32x4 va = *(const u32x4*)(xa + g * 8);
+        const u32x4 vb = same ? va : *(const u32x4*)(xb + g * 8);
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (sum) o = *(const u32x4*)(ya + g * 8);
+        u32x4 oa, ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ha = dropout_hash(seed_a, (unsigned long long)g * 4 + j), hb = dropout_hash(seed_b, (unsigned long long)g * 4 + j);
+            const float alo = ((ha & 0xffffu) >= thr_a) ? __uint_as_float(va[j] << 16) * ik_a : 0.f;
+            const float ahi = ((ha >> 16) >= thr_a) ? __uint_as_float(va[j] & 0xffff0000u) * ik_a : 0.f;
+            const float blo = ((hb & 0xffffu) >= thr_b) ? __uint_as_float(vb[j] << 16) * ik_b : 0.f;
+            const float bhi = ((hb >> 16) >= thr_b) ? __uint_as_float(vb[j] & 0xffff0000u) * ik_b : 0.f;
+            if (sum) {
+                oa[j] = pack_bf2(__uint_as_float(o[j] << 16) + alo + blo, __uint_as_float(o[j] & 0xffff0000u) + ahi + bhi);
+            } else {
+                oa[j] = pack_bf2(alo, ahi);
+                ob[j] = pack_bf2(blo, bhi);
+            }
+        }
+        *(u32x4*)(ya + g * 8) = oa;
+        if (!sum) *(u32x4*)(yb + g * 8) = ob;
+    }
+}
+
 }  // namespace rga3
 
 using namespace rga3;
@@ -412,6 +444,20 @@ extern "C" int rga3_dropout_bf16(const void* x, void* y, int64_t n, float p, int
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, (long)(n / 8),
                        thr, inv_keep, (unsigned long long)seed, accumulate);
     RGA3_CHECK_LAUNCH("dropout_kernel");
+    return 0;
+}
+
+extern "C" int rga3_dropout_pair_bf16(const void* xa, const void* xb, void* ya, void* yb, int64_t n, float pa, int64_t seed_a, float pb, int64_t seed_b, int sum,
+                                      void* stream) {
+    RGA3_CHECK_ARG(xa && xb && ya && (sum || yb) && n > 0 && n % 8 == 0, "dropout_pair: null pointer / n=%ld must be a positive multiple of 8", (long)n);
+    RGA3_CHECK_ARG(pa >= 0.f && pa < 1.f && pb >= 0.f && pb < 1.f, "dropout_pair: p=%f / %f", pa, pb);
+    RGA3_CHECK_ARG((((uintptr_t)xa | (uintptr_t)xb | (uintptr_t)ya | (uintptr_t)yb) & 15) == 0, "dropout_pair: pointers must be 16-byte aligned");
+    const unsigned ta = (unsigned)(pa * 65536.0f + 0.5f), tb = (unsigned)(pb * 65536.0f + 0.5f);
+    long blocks = cdiv(n / 8, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(dropout_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (cus)xa, (cus)xb, (us)ya, (us)yb, (long)(n / 8), ta,
+                       1.0f / (1.0f - (float)ta / 65536.0f), (unsigned long long)seed_a, tb, 1.0f / (1.0f - (float)tb / 65536.0f), (unsigned long long)seed_b, sum);
+    RGA3_CHECK_LAUNCH("dropout_pair_kernel");
     return 0;
 }
 

@@ -84,6 +84,7 @@ SIGNATURES = {
     "rga3_qwen_patchify_u8": [_p, _i64, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "rga3_rmsnorm_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _f, _p],
     "rga3_dropout_bf16": [_p, _p, _i64, _f, _i64, _i, _p],
+    "rga3_dropout_pair_bf16": [_p, _p, _p, _p, _i64, _f, _i64, _f, _i64, _i, _p],
     "rga3_swiglu_fwd": [_p, _p, _i64, _i64, _p],
     "rga3_swiglu_bwd": [_p, _p, _p, _i64, _i64, _p],
     "rga3_transpose16": [_p, _p, _i64, _i64, _i64, _i64, _p],

@@ -295,7 +295,7 @@ def hiera_mlp(x, wf, colc, biasf, w2, b2, eps: float):
 hiera_mlp144 = hiera_mlp      # the round-3 name (stage 1 only)
 
 
-_LN_TILES = (20, 3, 5, 12, 13)
+_LN_TILES = (20, 3, 5, 12, 13, 6, 7)     # (6 / 7: the three-stage 128 x 256 / 128 x 192 forms -- two K-tiles in flight; offered to the tuner since round 6)
 
 
 class LnSums:
@@ -1033,6 +1033,24 @@ def dropout(x, p: float, seed: int, out=None, accumulate: bool = False):
     assert out.is_contiguous() and out.shape == x.shape and out.dtype == torch.bfloat16
     _lib.check(_lib.load().rga3_dropout_bf16(x.data_ptr(), out.data_ptr(), x.numel(), float(p), int(seed) & 0x7FFFFFFFFFFFFFFF, int(bool(accumulate)), _stream()),
                "dropout")
+    return out
+
+
+def dropout_pair(xa, pa: float, seed_a: int, xb, pb: float, seed_b: int, accumulate_into=None):
+    """The two LoRA branches of a layer in one launch (rga3_dropout_pair_bf16).  accumulate_into None: (dropout_a(xa), dropout_b(xb)) -- xa may be xb (read once);
+    else accumulate_into += dropout_a(xa) + dropout_b(xb) with one rounding, returns it.  Masks as dropout()'s for the same seeds."""
+    _need_cuda(xa, xb, accumulate_into)
+    assert xa.dtype == xb.dtype == torch.bfloat16 and xa.is_contiguous() and xb.is_contiguous() and xa.shape == xb.shape and xa.numel() % 8 == 0
+    L = _lib.load()
+    if accumulate_into is None:
+        ya, yb = torch.empty_like(xa), torch.empty_like(xb)
+        _lib.check(L.rga3_dropout_pair_bf16(xa.data_ptr(), xb.data_ptr(), ya.data_ptr(), yb.data_ptr(), xa.numel(), float(pa), int(seed_a), float(pb), int(seed_b), 0,
+                                            _stream()), "dropout_pair_bf16")
+        return ya, yb
+    out = accumulate_into
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == xa.shape
+    _lib.check(L.rga3_dropout_pair_bf16(xa.data_ptr(), xb.data_ptr(), out.data_ptr(), None, xa.numel(), float(pa), int(seed_a), float(pb), int(seed_b), 1, _stream()),
+               "dropout_pair_bf16")
     return out
 
 

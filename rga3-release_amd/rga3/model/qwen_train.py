@@ -111,11 +111,17 @@ def _fp8_pack(owner, key, *srcs, build):
     return _wt(owner, "fp8:" + key, *srcs, build=mk)
 
 
+_fp8_tap = [None]     # tests only: callable(key, codes uint8 [M, K], scales f32 [M]) sees the e4m3 operand of every frozen contraction (tests/test_fulldepth_parity_gpu.py
+                      # hands the SAME codes to the oracle's e4m3 step, so that the comparison prices the kernels, not code flips of one-ulp activation differences)
+
+
 def _fgemm(x, owner, key, srcs, build, bias=None, residual=None, out=None):
     """x [M, K] @ build()^T for a FROZEN weight: e4m3 when enabled and K % 128 == 0, else the bf16 GEMM on the cached bf16 matrix."""
     if _fp8["on"] and x.shape[1] % 128 == 0:
         q, sc = _fp8_pack(owner, key, *srcs, build=build)
         xq, xs = ops.quant_fp8_rows(x)
+        if _fp8_tap[0] is not None:
+            _fp8_tap[0](key, xq, xs)
         return ops.gemm_fp8(xq, xs, q, sc, bias=bias, residual=residual, out=out)
     w = _wt(owner, key, *srcs, build=build)
     return ops.gemm(x, w, bias, residual=residual, out=out)
@@ -124,6 +130,8 @@ def _fgemm(x, owner, key, srcs, build, bias=None, residual=None, out=None):
 def _fgemm_q(xq, xs, owner, key, srcs, build, bias=None, residual=None, out=None):
     """_fgemm for an activation that is ALREADY quantised (the producer kernel emitted e4m3 + row scales: ops.swiglu_fwd_quant / swiglu_bwd_quant)."""
     q, sc = _fp8_pack(owner, key, *srcs, build=build)
+    if _fp8_tap[0] is not None:
+        _fp8_tap[0](key, xq, xs)
     return ops.gemm_fp8(xq, xs, q, sc, bias=bias, residual=residual, out=out)
 
 
@@ -295,6 +303,13 @@ def _lora_dropout(at):
     return pq, pv
 
 
+def _drop_pair(h1, pq, pv, seeds):
+    """(dropout_q(h1), dropout_v(h1)): both masks in one launch that reads h1 once when both branches drop (ops.dropout_pair; same masks as ops.dropout)."""
+    if pq > 0.0 and pv > 0.0 and h1.is_contiguous():
+        return ops.dropout_pair(h1, pq, seeds[0], h1, pv, seeds[1])
+    return (ops.dropout(h1, pq, seeds[0]) if pq > 0.0 else h1), (ops.dropout(h1, pv, seeds[1]) if pv > 0.0 else h1)
+
+
 def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
     """Fused q/k/v projection (+ LoRA updates on q and v accumulated in place); returns (qkv2 [T, (Hq+2Hk)D], tq, tv[, hq, hv]).
     seeds = (seed_q, seed_v) of the LoRA-branch dropout masks (None: fresh seeds when dropout is active); hq / hv are the (dropped)
@@ -309,8 +324,7 @@ def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
     if not _fp8["on"] and h1.shape[0] > 16 and _lora_cat_ok(at):
         # B side folded into the frozen product: t_q, t_v first (column halves of one buffer), then ONE product over K = H + 2 r
         r = lq[0].shape[0]
-        hq = ops.dropout(h1, pq, seeds[0]) if pq > 0.0 else h1
-        hv = ops.dropout(h1, pv, seeds[1]) if pv > 0.0 else h1
+        hq, hv = _drop_pair(h1, pq, pv, seeds)
         tt = torch.empty((h1.shape[0], 2 * r), dtype=h1.dtype, device=h1.device)
         tq = ops.gemm(hq, _lora_ops(at.q_proj)[0], out=tt[:, :r])          # t_s = drop(h) (sA)^T
         tv = ops.gemm(hv, _lora_ops(at.v_proj)[0], out=tt[:, r:])
@@ -322,6 +336,9 @@ def qkv_with_lora(at, h1, seeds=None, want_inputs=False):
         qkv2 = ops.gemm(h1, wqkv, bqkv)
     tq = tv = None
     hq = hv = h1
+    if lq is not None and lv is not None and pq > 0.0 and pv > 0.0:
+        hq, hv = _drop_pair(h1, pq, pv, seeds)
+        pq = pv = 0.0                                          # (done)
     if lq is not None:
         if pq > 0.0:
             hq = ops.dropout(h1, pq, seeds[0])
@@ -499,6 +516,7 @@ class DecoderLayerFn(torch.autograd.Function):
             grads = [None, None, None, None]
             if lq is not None or lv is not None:
                 tn_pairs, tn_slots = [], []      # the layer's weight-gradient products (dB = dsl^T t_s, dA = dt^T dropout(h1) per LoRA module): ONE grouped launch below
+                pend = []                        # (dt A, p, seed) of branches whose input gradient still has to pass its dropout mask on the way into dh1
                 for slot, lp, lin, t_, cols, pdrop, hin, sd in ((0, lq, at.q_proj, tq, (0, Hq * D), pq, hq_in, 0),
                                                                 (2, lv, at.v_proj, tv, ((Hq + Hk) * D, (Hq + 2 * Hk) * D), pv, hv_in, 1)):
                     if lp is None:
@@ -515,7 +533,12 @@ class DecoderLayerFn(torch.autograd.Function):
                     if pdrop == 0.0:
                         ops.gemm(dt, At, residual=dh1, out=dh1)                         # dh1 += dt A
                     else:                                                               # dh1 += mask / keep * (dt A): same seed, same mask
-                        ops.dropout(ops.gemm(dt, At), pdrop, ctx.seeds[sd], out=dh1, accumulate=True)
+                        pend.append((ops.gemm(dt, At), pdrop, ctx.seeds[sd]))
+                if len(pend) == 2 and dh1.is_contiguous():      # both branches: one launch, one rounding of dh1
+                    ops.dropout_pair(pend[0][0], pend[0][1], pend[0][2], pend[1][0], pend[1][1], pend[1][2], accumulate_into=dh1)
+                else:
+                    for xg, pg, sg in pend:
+                        ops.dropout(xg, pg, sg, out=dh1, accumulate=True)
                 for sl, gw in zip(tn_slots, ops.gemm_tn_many(tn_pairs)):
                     grads[sl] = gw
             dx = ops.rmsnorm_bwd(x, w1.weight, dh1, w1.variance_epsilon, add=dx1)

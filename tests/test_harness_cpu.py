@@ -179,22 +179,22 @@ def test_bench_refuses_counter_profiles_of_another_tree(tmp_path, monkeypatch):
     roof = {}
     bench._put_traffic(roof, "forward")
     assert roof == {"traffic": None}                                     # nothing collected: null, not stale
-    (prof / "r05_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 123456789.4, "tree": "0123456789abcdef"}))
+    (prof / f"{bench.PROFILE_ROUND}_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 123456789.4, "tree": "0123456789abcdef"}))
     roof = {}
     bench._put_traffic(roof, "forward")
     assert roof["traffic"] is None and roof["traffic_stale"] is True and "REFUSED" in roof["traffic_source"]
-    (prof / "r05_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 123456789.4, "tree": fp}))
+    (prof / f"{bench.PROFILE_ROUND}_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 123456789.4, "tree": fp}))
     roof = {}
     bench._put_traffic(roof, "forward")
     assert roof["traffic"] == 123456789 and "traffic_stale" not in roof and fp in roof["traffic_source"]
     # a counter pass that recorded no launches (the profiler died) is no figure either -- never a zero
-    (prof / "r05_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 0.0, "launches_fetch_pass": 0, "launches_write_pass": 0, "tree": fp}))
+    (prof / f"{bench.PROFILE_ROUND}_bench_forward_gemm_traffic.json").write_text(json.dumps({"traffic_bytes_per_launch": 0.0, "launches_fetch_pass": 0, "launches_write_pass": 0, "tree": fp}))
     roof = {}
     bench._put_traffic(roof, "forward")
     assert roof["traffic"] is None and "no launches" in roof["traffic_source"]
-    (prof / "r05_pmc_pipe_util.json").write_text(json.dumps({"gemm_nt_sk_kernel<2,": {"mfma_busy": 0.56}, "_tree": "feedfeedfeedfeed"}))
+    (prof / f"{bench.PROFILE_ROUND}_pmc_pipe_util.json").write_text(json.dumps({"gemm_nt_sk_kernel<2,": {"mfma_busy": 0.56}, "_tree": "feedfeedfeedfeed"}))
     mb, src = bench._mfma_busy("gemm_nt")
     assert mb is None and "REFUSED" in src
-    (prof / "r05_pmc_pipe_util.json").write_text(json.dumps({"gemm_nt_sk_kernel<2,": {"mfma_busy": 0.56}, "_tree": fp}))
+    (prof / f"{bench.PROFILE_ROUND}_pmc_pipe_util.json").write_text(json.dumps({"gemm_nt_sk_kernel<2,": {"mfma_busy": 0.56}, "_tree": fp}))
     mb, src = bench._mfma_busy("gemm_nt")
     assert mb == {"gemm_nt_sk_kernel<2,": 0.56}

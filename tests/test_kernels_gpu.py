@@ -69,7 +69,8 @@ def test_gemm_split64_skinny(dev, M, N, K, f32):
 
 @pytest.mark.parametrize("M,N,K,act,tile", [(4096, 1728, 576, "none", -1), (4096, 2304, 576, "gelu", 5), (3000, 432, 144, "none", 13), (2500, 1152, 288, "gelu", 3),
                                             (1000, 576, 576, "none", 20), (700, 48, 16, "none", -1), (513, 260, 72, "relu", 12), (65536, 1728, 576, "none", -1),
-                                            (1030, 384, 1152, "none", -1), (37, 192, 576, "none", -1), (16389, 3456, 1152, "none", -1)])   # round 5: the shared-row statistics kernels (576 / 1152 channels), ragged row counts
+                                            (1030, 384, 1152, "none", -1), (37, 192, 576, "none", -1), (16389, 3456, 1152, "none", -1),
+                                            (4100, 2304, 576, "gelu", 7), (4100, 1728, 576, "none", 6)])   # round 5: the shared-row statistics kernels (576 / 1152 channels), ragged row counts
 def test_gemm_layernorm_folded(dev, M, N, K, act, tile):
     """LayerNorm folded into the consuming product (rga3_layernorm_stats + rga3_gemm_ln_bf16, Hiera norm1 -> qkv / norm2 -> fc1): against fp32 LayerNorm + linear
     (+ GELU) of the same bf16 operands, and against the un-folded kernels (ops.layernorm + ops.gemm); rows with a large common offset exercise the

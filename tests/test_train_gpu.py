@@ -237,6 +237,24 @@ def test_dropout_kernel_matches_oracle_mask(dev):
     assert not torch.equal(ops.dropout(x, 0.5, 1).cpu(), ops.dropout(x, 0.5, 2).cpu())
 
 
+def test_dropout_pair_kernel_equals_two_single_launches(dev):
+    """rga3_dropout_pair_bf16 (the q / v LoRA branches of a layer in one launch): the forward form is bit-identical to two rga3_dropout_bf16 launches -- same masks
+    from the same (seed, index) hash, pinned to the oracle's restatement above --, the accumulating form equals out + a + b with ONE bf16 rounding."""
+    from rga3.hip import ops
+
+    for n, pa, pb in [(2112 * 3584, 0.05, 0.05), (8 * 1001, 0.25, 0.5), (64, 0.0, 0.3)]:
+        x, z = rnd((n,), dev, seed=3), rnd((n,), dev, seed=6)
+        ya, yb = ops.dropout_pair(x, pa, 111, x, pb, 222)                      # the forward: both branches drop the same input
+        assert torch.equal(ya, ops.dropout(x, pa, 111)) and torch.equal(yb, ops.dropout(x, pb, 222))
+        yc, yd = ops.dropout_pair(x, pa, 111, z, pb, 222)
+        assert torch.equal(yc, ya) and torch.equal(yd, ops.dropout(z, pb, 222))
+        acc = rnd((n,), dev, seed=4)
+        (ka, sa), (kb, sb) = R.dropout_mask_ref(n, pa, 111), R.dropout_mask_ref(n, pb, 222)
+        want = ((acc.float().cpu() + x.float().cpu() * torch.from_numpy(ka).float() * sa) + z.float().cpu() * torch.from_numpy(kb).float() * sb).to(torch.bfloat16)
+        got = ops.dropout_pair(x, pa, 111, z, pb, 222, accumulate_into=acc)
+        assert got.data_ptr() == acc.data_ptr() and torch.equal(acc.cpu(), want)
+
+
 def test_llm_training_step_gradients_with_lora_dropout(dev):
     """LoRA dropout (reference train_joint.py lora_dropout = 0.05; here 0.25 for a strong signal): the product's masks are reproduced
     from its seeds by the oracle's restatement of the counter hash, then loss and gradients are compared with fp32 autograd as above."""

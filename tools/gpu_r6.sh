@@ -32,6 +32,8 @@ for s in "$@"; do
     attnwin)
       timeout -k 10 1200 python3 -m pytest -x -q -m gpu tests/test_kernels_gpu.py tests/test_sam2_kernels_gpu.py -k "attn or attention" > $O/r06_attn_tests.log 2>&1; echo "rc $?"; tail -3 $O/r06_attn_tests.log | cut -c1-400
       timeout -k 10 600 python3 tools/hiera_attn_probe.py > $O/r06_hiera_attn_probe.log 2>&1; cat $O/r06_hiera_attn_probe.log | cut -c1-200 ;;
+    train)
+      timeout -k 10 2400 python3 -m pytest -x -q -m gpu tests/test_train_gpu.py tests/test_kernels_gpu.py -k "dropout or training or attn_window or lora" > $O/r06_train_tests.log 2>&1; echo "rc $?"; tail -4 $O/r06_train_tests.log | cut -c1-400 ;;
     suite)
       timeout -k 10 3000 python3 -m pytest tests/ -x -q -m gpu > $O/r06_gpu_tests.log 2>&1; echo "suite rc $?"; tail -3 $O/r06_gpu_tests.log | cut -c1-300
       timeout -k 10 600 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke.log 2>&1; echo "smoke rc $?"; tail -2 $O/r06_smoke.log ;;

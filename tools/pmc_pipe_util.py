@@ -12,11 +12,11 @@ Targets (kernel name needle -> the call that launches it at the shape of the hea
   gemm_nt_sk_kernel<0,       LLM down projection + residual, 2112 x 3584 x 18944 (tile 22)
   gemm_nt_kernel<128, 192    Hiera-L stage-3 qkv, 32768 x 1728 x 576 (8 frames; tile 5)
   gemm_nt_kernel<128, 256    LLM o-proj + residual, 2112 x 3584 x 3584 (tile 3)
-  gemm_nt_pp_kernel<0, false, false, true>   Hiera stage-3 fc2 + residual, 65536 x 576 x 2304 on 256 x 192 tiles (tile 23)
-  gemm_nt_pp_kernel<1, false, true, false>   Hiera stage-3 fc1 + GELU, LayerNorm folded, 65536 x 2304 x 576 (tile 20)
+  gemm_nt_pp_kernel<0, false, 2, true>   Hiera stage-3 fc2 + residual + the LayerNorm partial sums of the rows written (round 6), 65536 x 576 x 2304 on 256 x 192 tiles (tile 23)
+  gemm_nt_pp_kernel<1, false, 1, false>   Hiera stage-3 fc1 + GELU, LayerNorm folded (statistics from the producer's partial sums), 65536 x 2304 x 576 (tile 20)
   attn_fwd_kernel<128        causal decoder attention, S = 2112, 28 / 4 heads x 128
   attn_bwd_dkv / attn_bwd_dq its backward
-  attn_win_kernel<96, 8      Hiera stage-3 windows: 128 windows x 256 tokens, 8 heads x 72
+  attn_win_kernel<96, 8      Hiera stage-3 windows: 128 windows x 256 tokens, 8 heads x 72 (round 6: 32 query rows per wave, one workgroup per window and head)
   memattn_cross_kernel       SAM2 memory cross-attention, 4096 queries x 28 736 keys
 
 Derivations (MI355X_MICROARCH.md, rocprofv3 PMC slots + cycle constants):
@@ -35,7 +35,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-TARGETS = ["gemm_nt_sk_kernel<2, false, 4, true>", "gemm_nt_sk_kernel<2, false, 4, false>", "gemm_nt_sk_kernel<0, false, 4, false>", "gemm_nt_sk_kernel<0, false, 3, false>", "gemm_nt_w4_kernel<0, false>", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel<0, false, false, true>", "gemm_nt_pp_kernel<1, false, true, false>", "attn_fwd_kernel<128", "attn_causal32_kernel",
+TARGETS = ["gemm_nt_sk_kernel<2, false, 4, true>", "gemm_nt_sk_kernel<2, false, 4, false>", "gemm_nt_sk_kernel<0, false, 4, false>", "gemm_nt_sk_kernel<0, false, 3, false>", "gemm_nt_w4_kernel<0, false>", "gemm_nt_kernel<128, 192", "gemm_nt_kernel<128, 256", "gemm_nt_pp_kernel<0, false, 2, true>", "gemm_nt_pp_kernel<1, false, 1, false>", "attn_fwd_kernel<128", "attn_causal32_kernel",
            "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel", "attn_win_kernel<96, 8", "memattn_cross_kernel", "hiera_mlp_kernel<rga3::HmCfg<144", "hiera_mlp_kernel<rga3::HmCfg<288"]
 
 
@@ -100,11 +100,10 @@ def run():
     xh, xr = rn(65536, 2304), rn(65536, 576)
     w2h = [rn(576, 2304, scale=0.04) for _ in range(2)]
     for i in range(R):
-        ops.gemm(xh, w2h[i % 2], bias=rn(576), residual=xr, tile=23)
-    st = ops.layernorm_stats(xr, 1e-6)
+        xo, parts = ops.gemm_lnsum(xh, w2h[i % 2], rn(576), residual=xr, tile=23)
     wf, colc, bfold = ops.fold_layernorm(rn(2304, 576, scale=0.04), rn(2304), rn(576) + 1, rn(576, scale=0.1))
     for i in range(R):
-        ops.gemm_ln(xr, st, wf, colc, bfold, act="gelu", tile=20)
+        ops.gemm_ln(xo, ops.LnSums(parts, 1e-6), wf, colc, bfold, act="gelu", tile=20)
     del xh, w2h
     # ---- fused Hiera MLP, stage 1 (8 frames: 524 288 rows x 144) and stage 2 (131 072 rows x 288)
     for C, rows in ((144, 8 * 65536), (288, 8 * 16384)):
