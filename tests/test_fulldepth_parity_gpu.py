@@ -204,7 +204,7 @@ def test_decoder_layer_7b_fp8_frozen_lora_r128_s4160(dev):
     from rga3.model import qwen_index as QI
     from rga3.model import qwen_train as QT
     from rga3.model.qwen2_5_vl import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
-    from oracle.fp8step import fp8_frozen_linears
+    from oracle.fp8step import fp8_frozen_linears, fp8_frozen_linears_on_codes
 
     _threads()
     V, S_ = 8192, 4160
@@ -237,11 +237,15 @@ def test_decoder_layer_7b_fp8_frozen_lora_r128_s4160(dev):
     for n, p in md.named_parameters():
         p.requires_grad_(n in train)
     QT.set_fp8_frozen_gemms(True)
+    codes = {}
+    QT._fp8_tap[0] = lambda key, q_, s_: codes.__setitem__(key, (q_.clone(), s_.clone()))     # the e4m3 operand of every frozen contraction, as the build quantised it
     try:
         out = md(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev), position_ids=torch.from_numpy(pos_np).to(dev))
         out.loss.backward()
     finally:
         QT.set_fp8_frozen_gemms(False)
+        QT._fp8_tap[0] = None
+    assert set(codes) == {"wqkv", "wo", "wgu", "wd", "wqkv_t", "wo_t", "wgu_t", "wd_t"}, sorted(codes)
     assert any(k.startswith("fp8:") for k in md.model.layers[0].mlp.__dict__.get("_wt_cache", {})), "the e4m3 weight packs were not built: the bf16 route ran"
     cfg = Q.QwenCfg(vision=Q.VisionCfg(depth=0, fullatt_block_indexes=()), text=Q.TextCfg(num_hidden_layers=1, vocab_size=V))
     okeys = [n.replace(".base_layer.", ".") for n in train]
@@ -258,9 +262,20 @@ def test_decoder_layer_7b_fp8_frozen_lora_r128_s4160(dev):
     got = dict(md.named_parameters())
     errs = {n: rel(got[n].grad, g8[k]) for n, k in zip(train, okeys)}
     yard = {n: rel(g8[k], P[k].grad) for n, k in zip(train, okeys)}
+    # ---- the same step once more on the build's OWN operand codes: no code flips between the two sides, what is left is kernel arithmetic
+    for k in okeys:
+        P[k].grad = None
+    with fp8_frozen_linears_on_codes(codes):
+        refc = Q.forward(P, cfg, ids, am, position_ids=torch.from_numpy(pos_np), labels=labels)
+        refc["loss"].backward()
+    errs_c = {n: rel(got[n].grad, P[k].grad) for n, k in zip(train, okeys)}
     rec = {"loss": out.loss.item(), "oracle_fp8_loss": ref["loss"].item(), "oracle_fp32_loss": ref32["loss"].item(), "grad_rel_l2": errs,
-           "oracle_fp8_vs_oracle_fp32_grad_rel_l2": yard}
+           "oracle_fp8_vs_oracle_fp32_grad_rel_l2": yard, "oracle_on_build_codes_loss": refc["loss"].item(), "grad_rel_l2_on_build_codes": errs_c}
     print("FP8_LAYER_S4160", json.dumps(rec))
     _record("fp8_layer_s4160_parity.json", rec)
     assert abs(out.loss.item() - ref["loss"].item()) / ref["loss"].item() < 1e-2, rec
     assert len(errs) == 6 and all(errs[n] < max(3e-2, 1.25 * yard[n]) for n in errs), rec
+    # on shared codes the bound is the bf16 layer's (tests/test_fullsize_parity_gpu.py::test_decoder_layer_7b_lora_r128_forward_backward_s2112): a 5 % error in any
+    # backward kernel of the e4m3 step now fails, where the own-codes comparison above could not see it under ~10 % of code-flip noise
+    assert abs(out.loss.item() - refc["loss"].item()) / refc["loss"].item() < 5e-3, rec
+    assert all(errs_c[n] < 3e-2 for n in errs_c), rec

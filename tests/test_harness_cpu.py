@@ -198,3 +198,18 @@ def test_bench_refuses_counter_profiles_of_another_tree(tmp_path, monkeypatch):
     (prof / f"{bench.PROFILE_ROUND}_pmc_pipe_util.json").write_text(json.dumps({"gemm_nt_sk_kernel<2,": {"mfma_busy": 0.56}, "_tree": fp}))
     mb, src = bench._mfma_busy("gemm_nt")
     assert mb == {"gemm_nt_sk_kernel<2,": 0.56}
+
+
+def test_oracle_gate_up_column_order_is_the_builds_interleave():
+    """oracle/fp8step.py::fp8_frozen_linears_on_codes re-orders the columns of [Wg; Wu]^T to the build's gate | up pack (16-row blocks alternating, the layout of
+    rga3_gemm_swiglu_pre_bf16's weight): its index map must be exactly rga3.model.qwen2_5_vl._interleave_rows applied to the row numbers."""
+    import torch
+
+    from rga3.model.qwen2_5_vl import _interleave_rows
+
+    for I in (16, 64, 18944):
+        rows_g, rows_u = torch.arange(I).view(I, 1), (torch.arange(I) + I).view(I, 1)
+        packed = _interleave_rows(rows_g, rows_u, I).view(-1)
+        blk = torch.arange(I).view(I // 16, 16)
+        order_b = torch.stack([blk, blk + I], 1).reshape(-1)
+        assert torch.equal(packed, order_b)
