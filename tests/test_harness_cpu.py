@@ -213,3 +213,59 @@ def test_oracle_gate_up_column_order_is_the_builds_interleave():
         blk = torch.arange(I).view(I // 16, 16)
         order_b = torch.stack([blk, blk + I], 1).reshape(-1)
         assert torch.equal(packed, order_b)
+
+
+def test_board_sample_never_spawns_under_a_profiler(monkeypatch, tmp_path):
+    """bench.py reads board power / shader clock from sysfs hwmon in-process; rocm-smi (a '#!/usr/bin/env python3' script: an exec hop with the GPU
+    already initialised by a profiler's preloaded library) is a fallback only, never under a profiler's environment."""
+    import importlib
+    import os
+    import subprocess
+
+    bench = importlib.import_module("bench")
+    for var in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_ATT_LIBRARY_PATH"):
+        for k in list(os.environ):
+            if k == "LD_PRELOAD" or k.startswith(("ROCP", "HSA_TOOLS")):
+                monkeypatch.delenv(k, raising=False)
+        assert not bench._under_profiler()
+        monkeypatch.setenv(var, "x")
+        assert bench._under_profiler(), var
+        monkeypatch.delenv(var)
+    # no sysfs cards + profiler environment: no sample and no child process
+    monkeypatch.setattr(bench, "_sysfs_board", lambda: [])
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    called = []
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: called.append(a) or (_ for _ in ()).throw(AssertionError("spawned")))
+    assert bench._board_sample(lambda: None, seconds=0.1) is None and not called
+    # sysfs present: read in-process (the busiest card), still no child
+    pw, fq = tmp_path / "power1_average", tmp_path / "freq1_input"
+    pw.write_text("1310000000\n")
+    fq.write_text("2100000000\n")
+    monkeypatch.setattr(bench, "_sysfs_board", lambda: [(str(pw), str(fq))])
+    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda *a, **k: None)
+    got = bench._board_sample(lambda: None, seconds=1.5)
+    assert got is not None and got["source"] == "sysfs hwmon" and got["power_w"][0] == 1310.0 and got["sclk_mhz"][0] == 2100 and not called
+
+
+def test_stom_closing_against_an_independent_library():
+    """VERDICT r5 weak 4 (cv2 is not in the image: the OpenCV restatement of reference STOM.py:186-200 is unpinned against cv2 itself).  Second opinion from SciPy's
+    grey morphology -- an independent implementation of the same definition (max / min over the element's support, outside pixels never win) -- for the odd,
+    anchor-symmetric ellipses the reference's `min(h, w) // 15` produces on typical frames, and SciPy's centre of mass for the centroid the circle is drawn at."""
+    import numpy as np
+    from scipy import ndimage
+
+    rng = np.random.default_rng(11)
+    for k, shape in ((3, (45, 60)), (5, (75, 100)), (7, (105, 140)), (9, (135, 180)), (15, (240, 225))):
+        m = np.zeros(shape, np.uint8)
+        m[rng.integers(0, shape[0], 90), rng.integers(0, shape[1], 90)] = 255
+        m[shape[0] // 3: shape[0] // 3 + k, shape[1] // 2] = 255
+        m[0, :7] = 255
+        m[-1, -5:] = 255                                  # border contact: outside pixels must not win the erosion
+        ker = ST.ellipse_kernel(k).astype(bool)
+        dil = ndimage.grey_dilation(m, footprint=ker, mode="constant", cval=0)
+        want = ndimage.grey_erosion(dil, footprint=ker, mode="constant", cval=255)
+        got = ST.morph_close(m, k)
+        assert np.array_equal(got, want), k
+        ys, xs = np.nonzero(got)
+        cy, cx = ndimage.center_of_mass(got)
+        assert abs(cy - ys.mean()) < 1e-9 and abs(cx - xs.mean()) < 1e-9      # cv2.moments m01 / m00, m10 / m00 of a 0 / 255 image = the mean coordinates
