@@ -215,6 +215,7 @@ class GemmTimer:
         self._wrap("gemm_fp8", lambda a: (a[0].shape[0], a[2].shape[0], a[0].shape[1]))
         self._wrap("gemm_ln", lambda a: (a[0].shape[0], a[2].shape[0], a[0].shape[1]), w_index=2)   # LayerNorm-folded products of the Hiera trunk
         self._wrap("gemm_swiglu_pre", lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]))
+        self._wrap("gemm_lnsum", lambda a: (a[0].shape[0], a[1].shape[0], a[0].shape[1]))   # the Hiera trunk's residual-writing products (+ LayerNorm partial sums; round 6)
         # concatenated operands: [a | a2] [w | w2]^T and a wn^T from one launch (flop count of both sides)
         self._wrap("gemm_cat", lambda a, k: 2.0 * a[0].shape[0] * (a[1].shape[0] * (a[0].shape[1] + (k["a2"].shape[1] if k.get("a2") is not None else 0)) +
                                                                     (k["wn"].shape[0] * a[0].shape[1] if k.get("wn") is not None else 0)), takes_kw=True)

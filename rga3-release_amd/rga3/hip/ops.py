@@ -39,12 +39,37 @@ def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:
 
 
 _gemm_ws = {}
+_ws_scope = [None]
+
+
+class workspace_scope:
+    """``with ops.workspace_scope(token): ...`` -- every scratch buffer this module hands to a kernel (stream-K slabs / flags, the memory cross-attention's partial
+    sums, the TN ticket words) is keyed by (device, token) instead of (device, current stream) inside the block.  A captured hipGraph bakes the POINTERS it saw, and a
+    graph is replayed on whatever stream is current -- so the scratch of a capture must belong to the graph's owner, not to a stream handle: torch.cuda.Stream() hands
+    out streams of a pool of 32 round-robin, and a later eager launch on a stream that happens to BE some capture stream would share that graph's scratch while the
+    graph replays elsewhere (round 6: an intermittent mismatch of the concurrent object slots at the configs[3] shape).  The owner replays its graphs one after the
+    other; warm-up and capture both run inside the scope so that every buffer exists before the capture."""
+
+    def __init__(self, token):
+        self.token = ("scope", token)
+
+    def __enter__(self):
+        self.old, _ws_scope[0] = _ws_scope[0], self.token
+        return self
+
+    def __exit__(self, *exc):
+        _ws_scope[0] = self.old
+
+
+def _ws_key(device):
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    return (dev, _ws_scope[0] if _ws_scope[0] is not None else torch.cuda.current_stream(device).cuda_stream)
 
 
 def gemm_workspace(device) -> torch.Tensor:
-    """The caller-owned workspace of the stream-K / split-K GEMM tilings for (device, current stream): allocated from PyTorch's caching
-    allocator on first use, zeroed once (the flag words; the kernels leave them zero), then kept for the life of the process."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    """The caller-owned workspace of the stream-K / split-K GEMM tilings for (device, current stream) -- or (device, workspace_scope token): allocated from PyTorch's
+    caching allocator on first use, zeroed once (the flag words; the kernels leave them zero), then kept for the life of the process."""
+    key = _ws_key(device)
     t = _gemm_ws.get(key)
     if t is None:
         with torch.cuda.device(device):
@@ -437,8 +462,8 @@ _tn_cnt = {}
 
 
 def _tn_counters(device):
-    """128 ticket words per (device, stream) for the fused slab sum of gemm_tn: zeroed once, the kernel leaves them zero."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    """128 ticket words per (device, stream or workspace_scope) for the fused slab sum of gemm_tn: zeroed once, the kernel leaves them zero."""
+    key = _ws_key(device)
     t = _tn_cnt.get(key)
     if t is None:
         t = _tn_cnt[key] = torch.zeros(256, dtype=torch.int32, device=device)     # [0, 128): gemm_tn tiles; [128, 256): colsum column blocks
@@ -861,7 +886,7 @@ def memattn_cross(q, k, m, scale: float, nsplit: int = 0, partials: bool = False
     n = int(L.rga3_memattn_cross_ws_floats(Nq, nsplit))
     if n < 0:
         raise _lib.Rga3Error("memattn_cross: bad workspace query")
-    key = (q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+    key = _ws_key(q.device)
     ws = _memattn_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = _memattn_ws[key] = torch.empty(n, dtype=torch.float32, device=q.device)

@@ -925,14 +925,15 @@ class Qwen2_5_VLForConditionalGeneration(nn.Module):
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            body()
-        torch.cuda.current_stream().wait_stream(side)
-        st["pos3"] -= 1                # rewind the state the warm-up advanced; the warm-up wrote cache row n_stored, the capture rewrites it
-        st["kv"].reset(n_stored)
-        st["graph"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(st["graph"]):
-            st["logits"] = body()
+        with ops.workspace_scope(("decode-graph", id(st))):     # the scratch the capture bakes in belongs to THIS graph, not to a stream handle (ops.workspace_scope)
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream().wait_stream(side)
+            st["pos3"] -= 1                # rewind the state the warm-up advanced; the warm-up wrote cache row n_stored, the capture rewrites it
+            st["kv"].reset(n_stored)
+            st["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st["graph"]):
+                st["logits"] = body()
         st["graph"].replay()          # capturing executes nothing: the state still says "this step" -- now run it for real
         cache.lens[0] = n_stored      # the host-side bookkeeping of the eager cache is not used any more during this call
         return st

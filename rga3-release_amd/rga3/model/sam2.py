@@ -1093,10 +1093,13 @@ def _graph_cache(m, session=None):
     slot = getattr(session, "slot", 0) if session is not None else 0
     if ("pool", slot) not in cache:
         cache[("pool", slot)] = torch.cuda.graph_pool_handle()       # the graphs of one slot never run concurrently: one private pool per slot
-        # ... and one CAPTURE stream per slot: ops.py keys its scratch (stream-K slabs / flags, the memory-attention partial sums, the TN counters) by
-        # (device, current stream), and the pointers a capture sees are baked into the graph -- slots whose graphs replay concurrently (MultiObjectSession)
-        # must not share them.  Warm-up runs on the same stream so that every scratch buffer of that key exists before the capture.
+        # ... and one CAPTURE stream + one scratch scope per slot: ops.py keys its scratch (stream-K slabs / flags, the memory-attention partial sums, the TN
+        # counters) by (device, current stream), and the pointers a capture sees are baked into the graph -- slots whose graphs replay concurrently
+        # (MultiObjectSession) must not share them.  A capture stream of its own is not enough: torch.cuda.Stream() cycles through a pool of 32,
+        # so some later eager stream IS a slot's capture stream and would share that graph's scratch while the graph replays elsewhere -- warm-up and capture
+        # therefore run inside ops.workspace_scope(("sam2", id(m), slot)): the baked scratch is keyed by the slot, and no eager launch can ever see it.
         cache[("stream", slot)] = torch.cuda.Stream()
+        cache[("scope", slot)] = ("sam2-frames", id(m), slot)
     return cache
 
 
@@ -1176,12 +1179,13 @@ class VideoSession:
         if fresh:
             side = cache[("stream", self.slot)]
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                body()
-            torch.cuda.current_stream().wait_stream(side)
-            ent["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)], stream=side):
-                ent["outs"] = body()
+            with ops.workspace_scope(cache[("scope", self.slot)]):
+                with torch.cuda.stream(side):
+                    body()
+                torch.cuda.current_stream().wait_stream(side)
+                ent["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)], stream=side):
+                    ent["outs"] = body()
         ent["graph"].replay()
         low, ptr, best = ent["outs"]
         return {"low_res_masks": low.clone(), "obj_ptr": ptr.clone(), "best_iou_inds": best.clone()}
@@ -1304,12 +1308,13 @@ class VideoSession:
         if fresh:
             side = cache[("stream", self.slot)]
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):      # warm-up on the slot's capture stream: tuner picks, THIS stream's workspaces and lazily built tables exist before capture
-                body()
-            torch.cuda.current_stream().wait_stream(side)
-            ent["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)], stream=side):
-                ent["outs"] = body()
+            with ops.workspace_scope(cache[("scope", self.slot)]):
+                with torch.cuda.stream(side):      # warm-up on the slot's capture stream: tuner picks, THIS slot's workspaces and lazily built tables exist before capture
+                    body()
+                torch.cuda.current_stream().wait_stream(side)
+                ent["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ent["graph"], pool=cache[("pool", self.slot)], stream=side):
+                    ent["outs"] = body()
         ent["graph"].replay()
         outs = [torch.empty_like(o_) for o_ in ent["outs"]]      # the graph's result buffers are overwritten by the next replay
         ops.copy_many(list(zip(outs, ent["outs"])))

@@ -54,3 +54,34 @@ def test_cpu_tensor_is_rejected_loudly():
 
     with pytest.raises(lib.Rga3Error):
         ops.rmsnorm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.ones(64, dtype=torch.bfloat16), 1e-6)
+
+
+def test_device_code_has_no_swapped_half_packed_f32():
+    """The shipped code objects hold no v_pk_{mul,fma,add}_f32 whose op_sel swaps a source's halves: those forms (the SLP pass's pairing of independent
+    f32 lanes, e.g. the RoPE rotation of memlayer_rows) returned wrong lanes 48-63 when the kernel shared a CU with other work -- the concurrent
+    object-slot graphs' mismatch of round 6 (DESIGN 4 erratum note, tools/probes/coexec_probe3.py).  csrc/Makefile builds with -fno-slp-vectorize."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    from rga3.hip import lib
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    assert os.path.exists(objdump) and os.path.exists(lib.LIB_PATH)
+    with tempfile.TemporaryDirectory() as d:
+        so = shutil.copy(lib.LIB_PATH, os.path.join(d, "lib.so"))
+        subprocess.run([objdump, "--offloading", so], cwd=d, check=True, capture_output=True, timeout=120)
+        objs = sorted(glob.glob(os.path.join(d, "lib.so.*gfx950")))
+        assert len(objs) >= 10, objs
+        packed = swapped = 0
+        for o in objs:
+            text = subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True, timeout=300).stdout
+            for line in text.splitlines():
+                if re.search(r"\bv_pk_\w+_f32\b", line):
+                    packed += 1
+                    m = re.search(r"op_sel:\[([01,]+)\]", line)
+                    if m and "1" in m.group(1):
+                        swapped += 1
+        assert packed > 1000      # the explicit float2 / float4 code (attention rescale, epilogues) is still packed: the grep sees the code objects
+        assert swapped == 0, swapped

@@ -209,7 +209,8 @@ def test_sam2_l_concurrent_slot_graphs_bit_exact_at_bench_shape(dev):
         return torch.cat([mk for _, mk in ms.propagate(**kw)], 0)
 
     with torch.no_grad():
-        for clip in range(3):
+        for clip in range(5):
+            _shift = [torch.cuda.Stream() for _ in range(7 * clip % 32)]      # walk the 32-handle stream pool: eager streams meet the slots' capture streams
             vid = torch.randn(T, 3, 1024, 1024, generator=g).to(torch.bfloat16).to(dev)
             feats = VideoSession(m.sam2_model, vid)._ensure_feats()
             got = track(vid, feats, use_graph=True, concurrent=True)

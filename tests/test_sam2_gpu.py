@@ -354,8 +354,11 @@ def test_concurrent_replay_of_captured_slot_graphs_is_bit_exact(model, dev):
         return ms, torch.cat([m for _, m in ms.propagate(**kw)], 0)
 
     with torch.no_grad():
-        for clip in range(4):
-            img = images(5).roll(clip, 0).to(torch.bfloat16).to(dev)
+        for clip in range(12):
+            # torch.cuda.Stream() cycles through a pool of 32 handles: shift the cycle so that, over the clips, the objects' eager streams coincide with every
+            # slot's CAPTURE stream in turn -- with stream-keyed scratch an eager launch then shared a replaying graph's scratch (the round-6 intermittent mismatch)
+            _shift = [torch.cuda.Stream() for _ in range(3 * clip % 32)]
+            img = images(5).roll(clip % 5, 0).to(torch.bfloat16).to(dev)
             feats = model.get_sam2_embeddings(img)._ensure_feats()
             ms, got = track(img, feats, use_graph=True, concurrent=True)
             _, want = track(img, feats, use_graph=False, concurrent=False)
@@ -364,7 +367,7 @@ def test_concurrent_replay_of_captured_slot_graphs_is_bit_exact(model, dev):
     # distinct objects really produced distinct masks (the comparison above is not between constants)
     assert not torch.equal(got[0], got[1])
     cache = _graph_cache(model.sam2_model)
-    streams = {cache[("stream", o)].cuda_stream for o in range(n_obj)}
-    assert len(streams) == n_obj                                       # one capture stream per slot ...
-    keys = {k for k in ops._gemm_ws if k[1] in streams} | {k for k in ops._memattn_ws if k[1] in streams}
-    assert {k[1] for k in keys} <= streams and len({k[1] for k in keys}) >= 2      # ... and scratch keyed by them
+    scopes = {("scope", cache[("scope", o)]) for o in range(n_obj)}
+    assert len(scopes) == n_obj                                        # one scratch scope per slot ...
+    keyed = {k[1] for k in list(ops._gemm_ws) + list(ops._memattn_ws) + list(ops._tn_cnt) if k[1] in scopes}
+    assert len(keyed) >= 2, (keyed, scopes)                            # ... and the graphs' scratch is keyed by it, not by a stream handle

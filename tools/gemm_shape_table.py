@@ -92,14 +92,24 @@ def main():
         rec.append((("nt", a.shape[0], w.shape[0], a.shape[1], "swiglu+pre"), s, e))
         return r
 
-    ops.gemm, ops.gemm_tn, ops.gemm_ln = gemm, gemm_tn, gemm_ln
+    real_lnsum = ops.gemm_lnsum
+
+    def gemm_lnsum(a, w, bias=None, residual=None, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = real_lnsum(a, w, bias, residual=residual, **k)
+        e.record()
+        rec.append((("nt", a.shape[0], w.shape[0], a.shape[1], "none" + ("+res" if residual is not None else "") + "+lnsum"), s, e))
+        return r
+
+    ops.gemm, ops.gemm_tn, ops.gemm_ln, ops.gemm_lnsum = gemm, gemm_tn, gemm_ln, gemm_lnsum
     ops.gemm_cat, ops.gemm_tn_many, ops.gemm_swiglu_pre = gemm_cat, gemm_tn_many, gemm_swiglu_pre
     nst = 3
     try:
         for _ in range(nst):
             step()
     finally:
-        ops.gemm, ops.gemm_tn, ops.gemm_ln = real_gemm, real_tn, real_ln
+        ops.gemm, ops.gemm_tn, ops.gemm_ln, ops.gemm_lnsum = real_gemm, real_tn, real_ln, real_lnsum
         ops.gemm_cat, ops.gemm_tn_many, ops.gemm_swiglu_pre = real_cat, real_many, real_pre
     torch.cuda.synchronize()
     agg = defaultdict(lambda: [0, 0.0, 0.0])
