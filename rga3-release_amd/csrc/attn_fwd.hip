@@ -42,7 +42,7 @@ __device__ __forceinline__ u32x4 rope_chunk(u32x4 z, const unsigned short* row_p
 
 constexpr int KV_TILE = 64;
 
-template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, bool SPLIT = false, bool ROPE = false, int KT = KV_TILE>
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, bool SPLIT = false, bool ROPE = false, int KT = KV_TILE, int DTO = DP / 16>
 __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     static_assert(!(PAIR && SPLIT), "pairing and KV splitting are alternatives");
     constexpr int NT = 64 * NWAVE;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * NWAVE) void attn_fwd_kernel(AttnArgs p) {
     constexpr int CH = DP / 8;            // 16-byte chunks per (padded) row
     constexpr int STRIDE = DP * 2 + 32;   // LDS row stride in bytes (see header comment)
     constexpr int DS = DP / 32;           // 32-wide d steps of the QK^T contraction
-    constexpr int DT = DP / 16;           // 16-wide d tiles of the output
+    constexpr int DT = DTO;               // 16-wide d tiles of the output (D = 72 / 80 need 5 of the 6 that DP = 96 spans: Hiera's global blocks, the ViT's heads)
     constexpr int LOADS = (KT * CH + NT - 1) / NT;   // the last pass may cover only part of the threads (D = 96 with 8 waves: 768 chunks over 512 threads)
     constexpr bool EVEN = (KT * CH) % NT == 0;
     constexpr int RING = (LOADS <= 2) ? 3 : (LOADS <= 3) ? 2 : 1;  // K/V register slots in flight (8 * LOADS registers each)
@@ -575,10 +575,15 @@ __global__ __launch_bounds__(256) void attn_split_combine_kernel(AttnArgs p) {
     if (p.lse && lane == 0) p.lse[(long)hq * p.total_q + tq] = wsum > 0.f ? (m + log2f(wsum)) * 0.6931471805599453f : -INFINITY;
 }
 
-template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, int KT = KV_TILE>
+static bool g_attn_full_tiles = false;  // A/B switch (impl bit 16): keep all DP / 16 output tiles where D <= 80 would need five of six
+
+template <int DP, int QT, int NWAVE, bool USE_TR, bool PAIR, int KT = KV_TILE, int DTO = DP / 16>
 static int launch_attn_p(const AttnArgs& a, int nseg, unsigned gx, hipStream_t st) {
+    if constexpr (DP == 96 && DTO == 6 && !PAIR) {
+        if (a.D <= 80 && !g_attn_full_tiles) return launch_attn_p<DP, QT, NWAVE, USE_TR, PAIR, KT, 5>(a, nseg, gx, st);
+    }
     constexpr int LDS = 2 * KT * (DP * 2 + 32);
-    auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, PAIR, false, false, KT>;
+    auto kern = attn_fwd_kernel<DP, QT, NWAVE, USE_TR, PAIR, false, false, KT, DTO>;
     static LdsGrant lds_grant;
     if (int rc = grant_dyn_lds((const void*)kern, LDS, lds_grant, "attn")) return rc;
     AttnArgs b = a;
@@ -703,7 +708,8 @@ extern "C" int rga3_attn_varlen_fwd(const void* q, const void* k, const void* v,
                    "attn: pointer alignment");
     RGA3_CHECK_ARG(nseg <= 65535 && Hq <= 65535, "attn: grid dims too large");
     RGA3_CHECK_ARG(k_st < (1 << 24) && v_st < (1 << 24), "attn: k/v row stride too large for 32-bit tile offsets");
-    RGA3_CHECK_ARG(impl >= 0 && impl <= 15, "attn: impl %d", impl);
+    RGA3_CHECK_ARG(impl >= 0 && impl <= 31, "attn: impl %d", impl);
+    g_attn_full_tiles = (impl & 16) != 0;
     const bool win_q16 = (impl & 8) != 0;       // A/B switch: 256-query windows on the 16-rows-per-wave form (two workgroups per window and head)
     g_attn_variant = (impl & 2) ? 1 : 0;
     const bool no_causal32 = (impl & 4) != 0;   // A/B and parity switch: keep the long causal rows on the general kernel

@@ -37,6 +37,10 @@ def main():
             f = lambda: ops.attn_varlen(kv[:, :heads], kv[:, heads:2 * heads], kv[:, 2 * heads:], cu, cu, seg, hd ** -0.5, causal=False, out=out, impl=impl)
             us = t_us(f)
             print(f"{label:24s} packed qkv  impl={impl}: {us:8.1f} us  {fl / us / 1e6:6.0f} TF/s", flush=True)
+        if seg > 256:    # five of six output tiles (D = 72 <= 80) against all six (impl bit 16): same bits, fewer MFMAs
+            ref = torch.empty(N, heads, hd, dtype=torch.bfloat16, device=dev)
+            us = t_us(lambda: ops.attn_varlen(kv[:, :heads], kv[:, heads:2 * heads], kv[:, 2 * heads:], cu, cu, seg, hd ** -0.5, causal=False, out=ref, impl=16))
+            print(f"{label:24s} packed qkv  six output tiles (impl=16): {us:8.1f} us  {fl / us / 1e6:6.0f} TF/s   bit-equal to impl=0: {bool(torch.equal(ref, out))}", flush=True)
         if seg <= 256:   # whole-segment-in-LDS window kernel (needs the key range)
             out = torch.empty(N, heads, hd, dtype=torch.bfloat16, device=dev)
             us = t_us(lambda: ops.attn_varlen(kv[:, :heads], kv[:, heads:2 * heads], kv[:, 2 * heads:], cu, cu, seg, hd ** -0.5, causal=False, out=out, max_k=seg))
