@@ -22,7 +22,8 @@ for s in "$@"; do
       timeout -k 10 900 python3 -m pytest -x -q -m gpu tests/test_fullsize_parity_gpu.py -k "concurrent_slot" >> $O/r06_newtests.log 2>&1; echo "rc $?"; tail -5 $O/r06_newtests.log | cut -c1-400 ;;
     encprof)
       NF=16 timeout -k 10 600 python3 tools/sam2_encoder_probe.py 5 > $O/r06_encoder_probe.log 2>&1; grep "ms per" $O/r06_encoder_probe.log
-      rm -rf $O/encprof; NF=16 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/encprof -o enc -- python3 tools/sam2_encoder_probe.py 3 > $O/r06_encoder_prof.log 2>&1
+      NF=16 RGA3_TUNE_SAVE=/tmp/enc_tuner.json timeout -k 10 600 python3 tools/sam2_encoder_probe.py 1 > /dev/null 2>&1    # the tilings first: the profiled run then holds no trial launches
+      rm -rf $O/encprof; NF=16 RGA3_TUNE_LOAD=/tmp/enc_tuner.json timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/encprof -o enc -- python3 tools/sam2_encoder_probe.py 8 > $O/r06_encoder_prof.log 2>&1
       f=$(find $O/encprof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r06_encoder_kernel_stats.csv && head -40 $O/r06_encoder_kernel_stats.csv | cut -c1-200
       rm -rf $O/encprof ;;
     lnsum)

@@ -29,6 +29,8 @@ with torch.no_grad():
             setattr(S2, name, False); m.sam2_model.forward_image(x); res["off"].append(timed()); setattr(S2, name, True); m.sam2_model.forward_image(x)
         print(f"A/B {name}: on {min(res['on']):.2f} ms  off {min(res['off']):.2f} ms   (min of 3 x {it}, {NF} frames)")
 from rga3.hip import tuner
+if os.environ.get("RGA3_TUNE_SAVE"):      # decisions of this run, so that a profiled run (RGA3_TUNE_LOAD) holds no trial launches
+    tuner.save(os.environ["RGA3_TUNE_SAVE"])
 for k, v in tuner.timings().items():
     Mb, N, K = k[0], k[1], k[2]
     best = tuner.table().get(k)
