@@ -7,6 +7,7 @@
 #   forward    python bench.py --mode forward
 #   stream     configs[3], 1 and 4 objects
 #   fp8        configs[4]
+#   fp8prof    rocprofv3 kernel statistics of one configs[4] optimizer step
 #   timeline   rocprofv3 kernel trace of one training step -> step timeline
 #   probe:<file.py>[:arg,arg,...]   python3 tools/probes/<file.py> arg arg ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -47,6 +48,10 @@ for s in "$@"; do
       python3 bench.py --mode sam2_stream --objects 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/r06_bench_sam2_stream_4obj.json 2> $O/r06_bench_sam2_stream_4obj.err; tail -c 300 $O/r06_bench_sam2_stream_4obj.json ;;
     fp8)
       python3 bench.py --mode lora_fp8 --steps 3 --warmup 1 > $O/r06_bench_lora_fp8.json 2> $O/r06_bench_lora_fp8.err; tail -c 300 $O/r06_bench_lora_fp8.json ;;
+    fp8prof)
+      rm -rf /tmp/p8; (cd /tmp && timeout -k 10 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p8 -o f8 -- python3 $R/bench.py --mode lora_fp8 --steps 1 --warmup 1 --no-cpu-baseline --no-board > $O/r06_prof_lora_fp8.log 2>&1)
+      f=$(find /tmp/p8 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r06_bench_lora_fp8_kernel_stats.csv && head -45 $O/r06_bench_lora_fp8_kernel_stats.csv | cut -c1-220
+      rm -rf /tmp/p8 ;;
     timeline)
       rm -rf /tmp/pt; timeout -k 10 1200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -o tr -- python3 bench.py --mode train_full --steps 4 --warmup 3 --no-cpu-baseline --no-board > $O/r06_timeline_run.log 2>&1
       python3 tools/step_timeline.py /tmp/pt --bin-ms 5 --from-ms 0 --to-ms 1000 --exclude gemm_ > $O/r06_train_step_timeline.txt 2>&1; head -70 $O/r06_train_step_timeline.txt | cut -c1-160
