@@ -896,6 +896,35 @@ def test_fp8_quant_and_gemm(dev, M, N, K):
     assert _rel_l2(plain, full) < 6e-2           # two e4m3 operands: ~2^-4 relative per element, averaged over K
 
 
+def test_fp8_quant_codes_equal_true_quotient_every_bf16_value(dev):
+    """The row quantisers divide by the row scale with r = RN(1 / scale), q0 = x r, q = q0 + (x - q0 scale) r (two FMAs: Markstein's step) instead of the IEEE
+    expansion.  Every e4m3 code must equal torch's cast of the TRUE quotient: all 65 280 finite bf16 values as one row each way round (the row's own amax fixes
+    the scale), 600 rows of them against 600 different outliers (600 different scales, quotients anywhere between two codes), and a million random values."""
+    from rga3.hip import ops
+
+    bits = torch.arange(0, 65536, dtype=torch.int32)
+    vals = bits.to(torch.int16).view(torch.bfloat16)
+    vals = vals[torch.isfinite(vals.float())]
+    n = (vals.numel() + 7) // 8 * 8
+    row = torch.zeros(n, dtype=torch.bfloat16)
+    row[:vals.numel()] = vals
+    g = torch.Generator().manual_seed(5)
+    rows = row[None].repeat(600, 1)
+    small = rows.float().abs() < 1e30                                  # (the scale of a row is its outlier's: values above it are zeroed so the outlier IS the amax)
+    out = (torch.rand(600, generator=g) * 6.0 - 3.0).exp() * 37.0      # amax between 1.8 and 740
+    rows = torch.where(small & (rows.float().abs() <= out[:, None]), rows, torch.zeros((), dtype=torch.bfloat16))
+    rows[:, 0] = out.to(torch.bfloat16)
+    rnd = (torch.randn(128, 8192, generator=g) * torch.rand(128, 1, generator=g) * 10).to(torch.bfloat16)
+    for x in (row[None].clone().masked_fill_(row[None].float().abs() > 3e38, 0), rows, rnd):
+        q, sc = ops.quant_fp8_rows(x.to(dev))
+        amax = x.float().abs().amax(1)
+        want_sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        assert torch.equal(sc.cpu(), want_sc)
+        want = (x.float() / want_sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+        got = q.cpu()
+        assert torch.equal(got, want), int((got != want).sum())
+
+
 @pytest.mark.parametrize("T,I", [(37, 512), (200, 18944), (3, 32)])
 def test_swiglu_quant_fused_equals_unfused(dev, T, I):
     """rga3_swiglu_{fwd,bwd}_quant_fp8 == swiglu_{fwd,bwd} followed by quant_fp8_rows, bit for bit (codes and scales), incl. a zero row and an outlier row."""
