@@ -1277,17 +1277,23 @@ class VideoSession:
             ent = cache[key] = {"G": G, "session": -1}
         G = ent["G"]
         p0 = (1 + n_nc) * hw                                             # first pointer row
-        if ent["session"] != self.uid:
-            # constant part of the bank for this session: the conditioning frame's memory and pointer, all positions (the memory encoder's
-            # position map is the same for every frame, pointers carry none)
-            G["pos"].copy_(f["pos"])
-            G["mem"][:hw].copy_(cond["maskmem_features"])
-            G["mem"][p0:p0 + k].copy_(cond["obj_ptr"].reshape(-1, m.mem_dim))
-            G["mem_pos"][:hw].copy_(ops.add_bcast(cond["maskmem_pos_enc"], m.maskmem_tpos_enc[n_mem - 1].view(1, -1)))
+        # Positions of the bank rows are a function of the bank STATE alone (the memory encoder's position map is one cached tensor per resolution, pointers carry
+        # none): built once per captured state, not once per session -- it was 2 (1 + n_nc) eager launches on the first frame a session spent in each of its 17
+        # states, 4 ms of a 42-ms stream.  Re-done only if the position map or the temporal table changes (identity + version).
+        pos_src = cond["maskmem_pos_enc"]
+        pos_key = (pos_src.data_ptr(), pos_src._version, m.maskmem_tpos_enc.data_ptr(), m.maskmem_tpos_enc._version)
+        if ent.get("pos_key") != pos_key:
+            G["mem_pos"][:hw].copy_(ops.add_bcast(pos_src, m.maskmem_tpos_enc[n_mem - 1].view(1, -1)))
             for i in range(n_nc):                                        # slot i holds frame t - n_nc + i, i.e. t_pos = n_mem - n_nc + i
                 t_pos = n_mem - n_nc + i
-                G["mem_pos"][(1 + i) * hw:(2 + i) * hw].copy_(ops.add_bcast(cond["maskmem_pos_enc"], m.maskmem_tpos_enc[n_mem - t_pos - 1].view(1, -1)))
+                G["mem_pos"][(1 + i) * hw:(2 + i) * hw].copy_(ops.add_bcast(pos_src, m.maskmem_tpos_enc[n_mem - t_pos - 1].view(1, -1)))
             G["mem_pos"][p0:].zero_()
+            ent["pos_key"] = pos_key
+        moves = []
+        if ent["session"] != self.uid:
+            # constant part of the bank for this session: the image position map, the conditioning frame's memory and pointer -- they ride in the frame's one
+            # copy launch below
+            moves = [(G["pos"], f["pos"]), (G["mem"][:hw], cond["maskmem_features"]), (G["mem"][p0:p0 + k], cond["obj_ptr"].reshape(-1, m.mem_dim))]
             ent["session"] = self.uid
         feats1 = {"feat_s0": G["s0"], "feat_s1": G["s1"], "feat": G["tok"], "hw": (h, w), "n": 1, "pos": G["pos"]}
         S = m.image_size
@@ -1301,7 +1307,7 @@ class VideoSession:
             return pm, o["obj_ptr"], mf, mask
 
         # the frame's inputs and the moving part of the bank into the graph's static buffers: one launch for all of them
-        moves = [(G["tok"], f["feat"][t * hw:(t + 1) * hw]), (G["s0"], f["feat_s0"][t * 16 * hw:(t + 1) * 16 * hw]), (G["s1"], f["feat_s1"][t * 4 * hw:(t + 1) * 4 * hw])]
+        moves += [(G["tok"], f["feat"][t * hw:(t + 1) * hw]), (G["s0"], f["feat_s0"][t * 16 * hw:(t + 1) * 16 * hw]), (G["s1"], f["feat_s1"][t * 4 * hw:(t + 1) * 4 * hw])]
         moves += [(G["mem"][(1 + i) * hw:(2 + i) * hw], self.non_cond[t - n_nc + i]["maskmem_features"]) for i in range(n_nc)]
         moves += [(G["mem"][p0 + dd * k:p0 + (dd + 1) * k], self.non_cond[t - dd]["obj_ptr"].reshape(-1, m.mem_dim)) for dd in range(1, n_pp + 1)]
         ops.copy_many(moves)

@@ -3,7 +3,7 @@
 kernel that runs once per frame (default: the memory encoder's first conv, conv3x3s2_direct); the LAST full frame is listed launch by launch (start offset, duration,
 gap to the previous launch) and summarised by kernel name, so dependent-chain latency (gaps) can be told from kernel time.
   python3 tools/frame_timeline.py <dir-or-csv> [--anchor NAME] [--group-ms G] [--list]      (G: anchor launches closer than this belong to one frame; 1.5 by default,
-  0.3 for an anchor that runs once per frame now that a frame is shorter than 1.5 ms)"""
+  0.3 for an anchor that runs once per frame now that a frame is shorter than 1.5 ms; --frame N lists the frame opened by the N-th anchor group instead of the last)"""
 import csv
 import glob
 import os
@@ -39,7 +39,8 @@ def main():
     per = [rows[starts[k + 1][0]][0] - rows[starts[k][0]][0] for k in range(len(starts) - 1)]
     per.sort()
     print(f"{len(starts)} anchor groups; period median {per[len(per) // 2] / 1e6:.3f} ms, min {per[0] / 1e6:.3f}, max {per[-1] / 1e6:.3f}")
-    a, b = starts[-3][0], starts[-2][0]
+    pick = int(arg("--frame", "-3"))     # which anchor group opens the listed frame (default: the last full one; e.g. 40 = a steady-state frame of the first timed pass)
+    a, b = starts[pick][0], starts[pick + 1][0]
     fr = rows[a:b]
     t0 = fr[0][0]
     span = rows[b][0] - t0

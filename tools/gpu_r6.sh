@@ -48,6 +48,11 @@ for s in "$@"; do
       python3 bench.py --mode sam2_stream --objects 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/r06_bench_sam2_stream_4obj.json 2> $O/r06_bench_sam2_stream_4obj.err; tail -c 300 $O/r06_bench_sam2_stream_4obj.json ;;
     fp8)
       python3 bench.py --mode lora_fp8 --steps 3 --warmup 1 > $O/r06_bench_lora_fp8.json 2> $O/r06_bench_lora_fp8.err; tail -c 300 $O/r06_bench_lora_fp8.json ;;
+    frameline)
+      rm -rf /tmp/pfs; (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/pfs -o st -- python3 $R/bench.py --mode sam2_stream --steps 2 --warmup 1 --no-cpu-baseline --no-board > $O/r06_prof_stream.log 2>&1)
+      python3 tools/frame_timeline.py /tmp/pfs --list --anchor "${ANCHOR:-sam_select_kernel}" --group-ms 0.3 --frame ${FRAME:-50} > $O/r06_stream_frame_timeline.txt 2>&1; head -150 $O/r06_stream_frame_timeline.txt | cut -c1-150
+      cut -d, -f8- $(find /tmp/pfs -name '*kernel_trace.csv' | head -1) | grep -o 'rga3::[a-z_0-9]*' | sort | uniq -c | sort -rn | head -50
+      rm -rf /tmp/pfs ;;
     fp8prof)
       rm -rf /tmp/p8; (cd /tmp && timeout -k 10 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p8 -o f8 -- python3 $R/bench.py --mode lora_fp8 --steps 1 --warmup 1 --no-cpu-baseline --no-board > $O/r06_prof_lora_fp8.log 2>&1)
       f=$(find /tmp/p8 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r06_bench_lora_fp8_kernel_stats.csv && head -45 $O/r06_bench_lora_fp8_kernel_stats.csv | cut -c1-220
