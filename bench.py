@@ -1071,6 +1071,33 @@ def main():
         elapsed = float(t.item())
     lv = torch.stack([l.float().reshape(()) for l in losses]).cpu()
     assert torch.isfinite(lv).all(), "non-finite loss"
+    if rank == 0 and os.environ.get("RGA3_BENCH_ATEN_CENSUS"):
+        # measurement aid (tools/gpu_r6.sh atencensus): the framework kernels (everything that is not rga3::) inside steady-state steps, with the aten op and shapes that launch them
+        from collections import defaultdict
+        N = 3
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU], record_shapes=True) as prof:
+            for _ in range(N):
+                step()
+            torch.cuda.synchronize()
+        kk = defaultdict(lambda: [0, 0.0])
+        for e in prof.events():
+            if e.device_type == torch.autograd.DeviceType.CUDA:
+                kk[e.name][0] += 1
+                kk[e.name][1] += e.device_time if hasattr(e, "device_time") else e.cuda_time
+        fw = {n: v for n, v in kk.items() if "rga3::" not in n}
+        with open(os.environ["RGA3_BENCH_ATEN_CENSUS"], "w") as fcen:
+            fcen.write(f"all kernels {sum(v[1] for v in kk.values()) / N:.0f} us per step; non-rga3 {sum(v[1] for v in fw.values()) / N:.0f} us per step in {sum(v[0] for v in fw.values()) / N:.1f} launches\n")
+            for n, v in sorted(fw.items(), key=lambda kv: -kv[1][1])[:30]:
+                fcen.write(f"  {v[1] / N:8.1f} us  {v[0] / N:5.1f} x  {n[:150]}\n")
+            ops_ = defaultdict(lambda: [0.0, 0])
+            for e in prof.key_averages(group_by_input_shape=True):
+                if e.key.startswith("aten::") and (getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)):
+                    ent = ops_[(e.key, str(e.input_shapes)[:110])]
+                    ent[0] += (getattr(e, "self_device_time_total", None) or getattr(e, "self_cuda_time_total", 0)) / N
+                    ent[1] += e.count / N
+            for (n, sh), (t, c) in sorted(ops_.items(), key=lambda kv: -kv[1][0])[:40]:
+                if t > 2:
+                    fcen.write(f"  op {t:8.1f} us {c:6.1f} x  {n:28s} {sh}\n")
     ms = elapsed / args.steps * 1e3
     value = world * accum / (elapsed / args.steps)
 

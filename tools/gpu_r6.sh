@@ -53,6 +53,8 @@ for s in "$@"; do
       python3 tools/frame_timeline.py /tmp/pfs --list --anchor "${ANCHOR:-sam_select_kernel}" --group-ms 0.3 --frame ${FRAME:-50} > $O/r06_stream_frame_timeline.txt 2>&1; head -150 $O/r06_stream_frame_timeline.txt | cut -c1-150
       cut -d, -f8- $(find /tmp/pfs -name '*kernel_trace.csv' | head -1) | grep -o 'rga3::[a-z_0-9]*' | sort | uniq -c | sort -rn | head -50
       rm -rf /tmp/pfs ;;
+    atencensus)
+      RGA3_BENCH_ATEN_CENSUS=$O/r06_train_step_aten_census.txt python3 bench.py --mode train_full --steps 3 --warmup 3 --no-cpu-baseline --no-board > /dev/null 2> $O/r06_atencensus.err; cat $O/r06_train_step_aten_census.txt | cut -c1-230 ;;
     fp8prof)
       rm -rf /tmp/p8; (cd /tmp && timeout -k 10 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p8 -o f8 -- python3 $R/bench.py --mode lora_fp8 --steps 1 --warmup 1 --no-cpu-baseline --no-board > $O/r06_prof_lora_fp8.log 2>&1)
       f=$(find /tmp/p8 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r06_bench_lora_fp8_kernel_stats.csv && head -45 $O/r06_bench_lora_fp8_kernel_stats.csv | cut -c1-220

@@ -72,3 +72,7 @@ python3 $R/tools/evaluate_probe.py > $O/r06_evaluate_probe.log 2>&1; tail -1 $O/
 python3 $R/tools/generate_probe.py 64 > $O/r06_generate_probe.log 2>&1; tail -1 $O/r06_generate_probe.log
 cd $R && python3 -m pytest tests/ -x -q -m gpu > $O/r06_gpu_tests.log 2>&1; tail -2 $O/r06_gpu_tests.log
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke.log 2>&1; tail -3 $O/r06_smoke.log
+# 6. one steady-state stream frame launch by launch, one configs[4] optimizer step and the encoder alone by kernel, the step's framework kernels
+cd $R && FRAME=93 bash tools/gpu_r6.sh frameline > /dev/null 2>&1; head -3 $O/r06_stream_frame_timeline.txt
+bash tools/gpu_r6.sh fp8prof encprof atencensus > $O/r06_extra_profiles.log 2>&1; grep "ms per" $O/r06_extra_profiles.log
+timeout -k 10 300 python3 tools/probes/swiglu_quant_probe.py > $O/r06_swiglu_quant_probe.log 2>&1
