@@ -557,6 +557,27 @@ class ConvTParams(nn.Module):
         return self.weight.permute(2, 3, 1, 0).reshape(-1, self.weight.shape[0]).contiguous()
 
 
+class _HeadsOut(dict):
+    """forward_sam_heads' result on the inference path: the reference's keys, with "ious" (the multimask IoU predictions, reference sam2.py:3360-3373 / :3398) made on first read."""
+
+    def __init__(self, d, iou):
+        super().__init__(d)
+        self._iou = iou
+
+    def __missing__(self, key):
+        if key != "ious":
+            raise KeyError(key)
+        v = self._iou[:, 1:].float()
+        self[key] = v
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key == "ious" else super().get(key, default)
+
+    def __contains__(self, key):
+        return key == "ious" or super().__contains__(key)
+
+
 class MaskDecoder(nn.Module):
     """reference sam2.py:1926-2160 with pred_obj_scores(+mlp), high-res features, multimask tokens for the object pointer."""
 
@@ -567,6 +588,7 @@ class MaskDecoder(nn.Module):
         self.iou_token = nn.Embedding(1, dim)
         self.num_mask_tokens = 4
         self.mask_tokens = nn.Embedding(4, dim)
+        self._tok_cache = None       # (key, tokens) of forward(..., const_sparse=True)
         self.obj_score_token = nn.Embedding(1, dim)
         self.output_upscaling = nn.Sequential(ConvTParams(dim, dim // 4), NormParams(dim // 4, 1e-6), nn.GELU(), ConvTParams(dim // 4, dim // 8), nn.GELU())
         self.conv_s0 = ConvParams(dim // 8, dim, 1, 1)
@@ -575,12 +597,23 @@ class MaskDecoder(nn.Module):
         self.iou_prediction_head = MLP(dim, iou_head_hidden_dim, 4, 3, sigmoid_output=True)
         self.pred_obj_score_head = MLP(dim, dim, 1, 3)
 
-    def forward(self, pix_tokens, pos_tokens, sparse, feat_s0, feat_s1, B, h, w):
-        """pix_tokens [B*h*w, C] (already + dense prompt), pos_tokens [h*w, C], sparse [B, n, C].
+    def forward(self, pix_tokens, pos_tokens, sparse, feat_s0, feat_s1, B, h, w, const_sparse=False):
+        """pix_tokens [B*h*w, C] (already + dense prompt), pos_tokens [h*w, C], sparse [B, n, C] (const_sparse: it is the prompt encoder's padding alone).
         Returns masks f32 [B, 4, 4h, 4w], iou [B, 4], mask tokens [B, 4, C], object score logits [B, 1]."""
         C = self.transformer_dim
-        out_tokens = torch.cat([self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight], dim=0)
-        tokens = torch.cat([out_tokens[None].expand(B, -1, -1), sparse.to(out_tokens.dtype)], dim=1).contiguous()
+        tokens = None
+        if const_sparse and not _ag():
+            # tracked frames carry no prompt: output tokens + the two padding points are a function of the weights alone -- built once, not with two concatenation
+            # launches per frame (a frame of the stream is ~115 dependent launches of >= 4.4 us each)
+            srcs = (self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight, sparse)
+            key = tuple((t_.data_ptr(), t_._version, tuple(t_.shape), t_.dtype) for t_ in srcs) + (B,)
+            if self._tok_cache is not None and self._tok_cache[0] == key:
+                tokens = self._tok_cache[1]
+        if tokens is None:
+            out_tokens = torch.cat([self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight], dim=0)
+            tokens = torch.cat([out_tokens[None].expand(B, -1, -1), sparse.to(out_tokens.dtype)], dim=1).contiguous()
+            if const_sparse and not _ag():
+                self._tok_cache = (key, tokens.detach())
         nq = tokens.shape[1]
         hs, src = self.transformer(pix_tokens, pos_tokens, tokens.view(B * nq, C), B, nq, h * w)
         hs = hs.view(B, nq, C)
@@ -984,8 +1017,7 @@ class SAM2VideoPredictor(nn.Module):
         if frame_slice is not None:
             a, b = frame_slice
             s0, s1 = s0[a * 16 * h * w: b * 16 * h * w], s1[a * 4 * h * w: b * 4 * h * w]
-        masks, iou, toks, obj = self.sam_mask_decoder(src, pe.dense_pe_tokens(src.dtype), sparse, s0, s1, B, h, w)
-        ious = iou[:, 1:].float()
+        masks, iou, toks, obj = self.sam_mask_decoder(src, pe.dense_pe_tokens(src.dtype), sparse, s0, s1, B, h, w, const_sparse=language_embd is None)
         proj = self.obj_ptr_proj
         if (not _ag() and proj.num_layers == 3 and proj.act == "relu" and not any(hasattr(l, "lora_A") for l in proj.layers) and toks.shape[2] % 8 == 0
                 and toks.shape[2] <= 512 and iou.dtype == torch.bfloat16):
@@ -994,8 +1026,10 @@ class SAM2VideoPredictor(nn.Module):
                                                        self.no_obj_ptr.view(-1))
             low = masks.reshape(B * 4, 4 * h, 4 * w)[sel64].unsqueeze(1)                              # chosen candidate, f32
             high = ops.bilinear(masks.view(B * 4, 4 * h, 4 * w), (self.image_size, self.image_size), sel).unsqueeze(1)
-            return {"low_res_multimasks": masks[:, 1:], "ious": ious, "low_res_masks": low, "high_res_masks": high, "obj_ptr": obj_ptr,
-                    "object_score_logits": obj, "best_iou_inds": best}
+            # ("ious" is converted when somebody reads it: nothing on the tracking path does, and a launch there is 4.4 us of a 1.3-ms frame)
+            return _HeadsOut({"low_res_multimasks": masks[:, 1:], "low_res_masks": low, "high_res_masks": high, "obj_ptr": obj_ptr,
+                              "object_score_logits": obj, "best_iou_inds": best}, iou)
+        ious = iou[:, 1:].float()
         best = torch.argmax(ious, dim=-1)
         bi = torch.arange(B, device=best.device)
         sel = (bi * 4 + 1 + best).to(torch.int32)
@@ -1303,7 +1337,9 @@ class VideoSession:
             o = m.forward_sam_heads(pix, feats1, None, frame_slice=(0, 1))
             mf, _ = m.encode_new_memory(feats1, 0, o["high_res_masks"])
             pm = o["low_res_masks"]
-            mask = ops.bilinear(pm.reshape(1, *pm.shape[-2:]).float().contiguous(), (S, S)).unsqueeze(0)
+            # the frame's mask at video resolution IS high_res_masks here (both are the bilinear image of the chosen low-resolution mask at image_size; the reference
+            # interpolates twice with the same mode, sam2.py:3388-3393 and :3761-3766): one launch instead of two
+            mask = o["high_res_masks"].reshape(1, 1, S, S)
             return pm, o["obj_ptr"], mf, mask
 
         # the frame's inputs and the moving part of the bank into the graph's static buffers: one launch for all of them
