@@ -55,3 +55,25 @@ def test_gradient_checkpointing_flag_drives_the_recompute_switch():
         assert QT._acts["store"] is True and not m.is_gradient_checkpointing
     finally:
         QT.set_activation_recompute(False)
+
+
+def test_heads_output_keeps_the_reference_keys_with_ious_made_on_first_read():
+    """forward_sam_heads' inference result (reference model/sam2.py:3262-3431 returns low_res_multimasks, ious, low_res_masks, high_res_masks, obj_ptr,
+    object_score_logits): "ious" is converted from the decoder's bf16 IoU logits when it is first read -- same key, same value, every dict access form."""
+    import torch
+
+    from rga3.model.sam2 import _HeadsOut
+
+    iou = torch.arange(8, dtype=torch.float32).reshape(2, 4).to(torch.bfloat16)
+    o = _HeadsOut({"low_res_masks": 1, "obj_ptr": 2}, iou)
+    assert "ious" in o and "low_res_masks" in o and "nope" not in o
+    assert o.get("nope") is None and o.get("obj_ptr") == 2
+    want = iou[:, 1:].float()
+    assert o["ious"].dtype == torch.float32 and torch.equal(o["ious"], want) and torch.equal(o.get("ious"), want)
+    assert o["ious"] is o["ious"]                       # made once
+    try:
+        o["missing"]
+    except KeyError:
+        pass
+    else:
+        raise AssertionError("unknown keys must raise KeyError")
